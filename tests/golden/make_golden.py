@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by running the UPSTREAM REFERENCE itself.
+
+Run in the build container only (needs /root/reference; the GPU box never has it):
+    python tests/golden/make_golden.py
+The reference is imported read-only with stubbed third-party modules (tests/golden/_refimport.py,
+recipe from SURVEY.md 8c).  Outputs are DATA (inputs + expected outputs), never reference source:
+    simplex_kat.npz      _init tables, noise3 point KATs (bit patterns), octave fields, C4 crops
+    diffusion_kat.npz    schedule tables (linear/cosine), sample_q / p_mean_variance / sample_p
+    unet_<name>.npz      UNetModel.forward outputs (+ per-block activation probes)
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import _refimport  # noqa: E402
+from oracle import unet_oracle  # noqa: E402  (only for the deterministic parameter fill)
+
+ref_simplex, ref_unet, ref_gd = _refimport.load()
+
+
+def classify(x, y, z):
+    """Which branch family of simplex.py:354/469/587 a point exercises (for coverage stats)."""
+    s = (x + y + z) * (-1.0 / 6)
+    xs, ys, zs = x + s, y + s, z + s
+    xi, yi, zi = xs - np.floor(xs), ys - np.floor(ys), zs - np.floor(zs)
+    t = xi + yi + zi
+    return 0 if t <= 1 else (1 if t >= 2 else 2)
+
+
+def gen_simplex():
+    out = {}
+    seeds = [3, 12345, -9999999999, 9999999999, 9726117423]
+    out["init_seeds"] = np.array(seeds, dtype=np.int64)
+    perms, pgis = [], []
+    for s in seeds:
+        p, g = ref_simplex._init(s)
+        perms.append(p)
+        pgis.append(g)
+    out["init_perm"] = np.stack(perms)
+    out["init_pgi3"] = np.stack(pgis)
+
+    rng = np.random.RandomState(20260926)
+    pts = np.concatenate([
+        rng.uniform(-60, 60, (5000, 3)),
+        rng.uniform(-2, 2, (3000, 3)),
+        rng.randint(-30, 30, (1500, 3)).astype(np.float64),          # exact lattice points
+        rng.randint(-60, 60, (1500, 3)) / 2.0,                       # f=0.5 style coordinates
+        rng.randint(0, 256, (1500, 3)) / 64.0,                       # octave-0 style coordinates
+        np.array([[0, 0, 0], [0.1, 0.2, 0.3], [1.5, 2.25, 0.15625],
+                  [3.984375, 3.984375, 3.890625], [510, 510, 1998]], dtype=np.float64),
+    ])
+    out["points"] = pts
+    hist = np.zeros(3, dtype=np.int64)
+    for p in pts:
+        hist[classify(*p)] += 1
+    out["points_region_hist"] = hist
+    for s in (3, 12345):
+        S = ref_simplex.Simplex_CLASS()
+        S.newSeed(s)
+        out[f"points_val_seed{s}"] = np.array([S.noise3(*p) for p in pts], dtype=np.float64)
+
+    S = ref_simplex.Simplex_CLASS()
+    S.newSeed(9726117423)
+    ts = [0, 1, 249, 999]
+    out["fixedT_t"] = np.array(ts, dtype=np.int64)
+    out["fixedT_seed"] = np.int64(9726117423)
+    out["fixedT_64x64_o6"] = np.stack(
+        [S.rand_3d_fixed_T_octaves((64, 64), np.array([t]), 6, 0.8, 64)[0] for t in ts])
+    out["fixedT_40x24_o8_f32"] = np.stack(
+        [S.rand_3d_fixed_T_octaves((40, 24), np.array([t]), 8, 0.7, 32)[0] for t in ts])
+
+    # crops of the BASELINE config-4 volume rand_3d_octaves((1000,256,256), 8, 0.8, 64), seed 12345
+    S.newSeed(12345)
+    zs = [0, 1, 499, 999]
+    crops = []
+    for (y0, x0) in ((0, 0), (224, 224)):
+        acc = np.zeros((len(zs), 32, 32))
+        f, a = 64, 1
+        for _ in range(8):
+            acc += a * S.noise3array(np.arange(x0, x0 + 32) / f, np.arange(y0, y0 + 32) / f,
+                                     np.array(zs) / f)
+            f /= 2
+            a *= 0.8
+        crops.append(acc)
+    out["c4_seed"] = np.int64(12345)
+    out["c4_z"] = np.array(zs, dtype=np.int64)
+    out["c4_crop_origin_yx"] = np.array([[0, 0], [224, 224]], dtype=np.int64)
+    out["c4_crops"] = np.stack(crops)
+    # a full tiny volume through the reference entry point itself
+    out["vol_5x12x20_o3"] = S.rand_3d_octaves((5, 12, 20), 3, 0.5, 8)
+    np.savez_compressed(os.path.join(HERE, "simplex_kat.npz"), **out)
+    print("simplex_kat.npz", {k: getattr(v, "shape", ()) for k, v in out.items()})
+
+
+def gen_diffusion():
+    out = {}
+    for name in ("linear", "cosine"):
+        betas = ref_gd.get_beta_schedule(1000, name)
+        d = ref_gd.GaussianDiffusionModel([16, 16], betas, noise="gauss")
+        out[f"{name}_betas"] = betas
+        for k in ("sqrt_alphas", "sqrt_betas", "alphas_cumprod", "alphas_cumprod_prev",
+                  "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+                  "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+                  "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+                  "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+            out[f"{name}_{k}"] = getattr(d, k)
+    out["linear_T250_betas"] = ref_gd.get_beta_schedule(250, "linear")
+
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(4, 1, 16, 16, generator=g) * 2 - 1
+    eps = torch.randn(4, 1, 16, 16, generator=g)
+    noise = torch.randn(4, 1, 16, 16, generator=g)
+    t = torch.tensor([0, 1, 500, 999])
+    out["x"], out["eps"], out["noise"], out["t"] = x.numpy(), eps.numpy(), noise.numpy(), t.numpy()
+    for name in ("linear", "cosine"):
+        d = ref_gd.GaussianDiffusionModel([16, 16], ref_gd.get_beta_schedule(1000, name), noise="gauss")
+        out[f"{name}_sample_q"] = d.sample_q(x, t, noise).numpy()
+        out[f"{name}_sample_q_gradual"] = d.sample_q_gradual(x, t, noise).numpy()
+        pmv = d.p_mean_variance(None, x, t, estimate_noise=eps)
+        for k, v in pmv.items():
+            out[f"{name}_pmv_{k}"] = v.contiguous().numpy()
+        sp = d.sample_p(lambda a, b: eps, x, t, denoise_fn=lambda a, b: noise)
+        out[f"{name}_sample_p_sample"] = sp["sample"].numpy()
+        out[f"{name}_sample_p_pred_x_0"] = sp["pred_x_0"].numpy()
+        out[f"{name}_predict_eps_from_x_0"] = d.predict_eps_from_x_0(x, t, pmv["pred_x_0"]).numpy()
+
+    # forward_backward structure with an injected model / noise (lengths + a short chain)
+    d = ref_gd.GaussianDiffusionModel([16, 16], ref_gd.get_beta_schedule(1000, "linear"), noise="gauss")
+    x1 = x[:1]
+    fixed = noise[:1]
+    d.noise_fn = lambda a, b: fixed
+    model = lambda a, b: 0.3 * a - 0.1
+    seq_half = d.forward_backward(model, x1, "half", 5, denoise_fn=lambda a, b: 0.5 * fixed)
+    seq_whole = d.forward_backward(model, x1, "whole", 4, denoise_fn=lambda a, b: 0.5 * fixed)
+    final = d.forward_backward(model, x1, None, 5, denoise_fn=lambda a, b: 0.5 * fixed)
+    out["fb_half_len"] = np.int64(len(seq_half))
+    out["fb_whole_len"] = np.int64(len(seq_whole))
+    out["fb_half_seq"] = torch.stack(seq_half).numpy()
+    out["fb_whole_seq"] = torch.stack(seq_whole).numpy()
+    out["fb_final"] = final.numpy()
+
+    # losses with injected t / noise
+    for lt in ("l1", "l2", "hybrid"):
+        d = ref_gd.GaussianDiffusionModel([16, 16], ref_gd.get_beta_schedule(1000, "linear"),
+                                          loss_type=lt, noise="gauss")
+        d.noise_fn = lambda a, b: noise
+        loss, x_t, est = d.calc_loss(model, x, t)
+        out[f"loss_{lt}"] = loss["loss"].numpy()
+        if lt == "hybrid":
+            out["loss_hybrid_vlb"] = loss["vlb"].numpy()
+    np.savez_compressed(os.path.join(HERE, "diffusion_kat.npz"), **out)
+    print("diffusion_kat.npz", len(out), "arrays")
+
+
+UNET_CASES = {
+    # name: (ctor kwargs, batch, timesteps)
+    "i32_b32_h1": (dict(img_size=32, base_channels=32), 2, [3, 977]),
+    "i32_b32_h2_a16_8": (dict(img_size=32, base_channels=32, n_heads=2, attention_resolutions="16,8"), 1, [500]),
+    "i64_b32_hc32": (dict(img_size=64, base_channels=32, n_head_channels=32, attention_resolutions="16,8"), 2, [0, 999]),
+    "i64_b64_c3": (dict(img_size=64, base_channels=64, n_heads=2, in_channels=3), 1, [42]),
+    "i128_b32_h2": (dict(img_size=128, base_channels=32, n_heads=2, attention_resolutions="16,8"), 1, [250]),
+}
+
+
+def run_unet_case(name, kw, batch, ts, probes=True):
+    kw = dict(kw)
+    model = ref_unet.UNetModel(**kw)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    oshapes = unet_oracle.param_shapes(
+        kw["img_size"], kw["base_channels"], kw.get("channel_mults", ""), 2,
+        kw.get("attention_resolutions", "32,16,8"), kw.get("in_channels", 1))
+    assert list(shapes.items()) == list(oshapes.items()), "state-dict layout mismatch vs oracle.param_shapes"
+    sd = unet_oracle.fill_deterministic(shapes)
+    model.load_state_dict(sd)
+    model.eval()
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    x = torch.rand(batch, kw.get("in_channels", 1), kw["img_size"], kw["img_size"], generator=g) * 2 - 1
+    t = torch.tensor(ts)
+    rec = {}
+    hooks = []
+    if probes:
+        def mk(key):
+            def hook(mod, inp, outp):
+                rec[key] = outp.detach()
+            return hook
+        for grp in ("down", "up"):
+            for i, seq in enumerate(getattr(model, grp)):
+                for j, m in enumerate(seq):
+                    hooks.append(m.register_forward_hook(mk(f"{grp}.{i}.{j}")))
+        for j, m in enumerate(model.middle):
+            hooks.append(m.register_forward_hook(mk(f"middle.{j}")))
+        hooks.append(model.time_embedding.register_forward_hook(mk("time_embed")))
+    with torch.no_grad():
+        y = model(x, t)
+    for h in hooks:
+        h.remove()
+    out = {"x": x.numpy(), "t": t.numpy(), "y": y.numpy(),
+           "n_params": np.int64(sum(int(np.prod(s)) for s in shapes.values())),
+           "n_tensors": np.int64(len(shapes))}
+    for k, v in rec.items():
+        f = v.flatten()
+        stride = max(1, f.numel() // 256)
+        out["probe/" + k] = f[::stride][:256].numpy().copy()
+        out["stat/" + k] = np.array([v.mean().item(), v.abs().mean().item(), v.std().item()], dtype=np.float64)
+        out["shape/" + k] = np.array(v.shape, dtype=np.int64)
+    out["keys"] = np.array(list(shapes.keys()))
+    out["key_shapes"] = np.array([",".join(map(str, s)) for s in shapes.values()])
+    return out
+
+
+def gen_unet():
+    for name, (kw, batch, ts) in UNET_CASES.items():
+        out = run_unet_case(name, kw, batch, ts)
+        np.savez_compressed(os.path.join(HERE, f"unet_{name}.npz"), **out)
+        print(f"unet_{name}.npz", "y", out["y"].shape, "params", int(out["n_params"]),
+              "|y| mean", float(np.abs(out["y"]).mean()))
+    # BASELINE config-2 shaped forward (256^2, base 128, heads 2, attn 16,8), batch 1
+    kw = dict(img_size=256, base_channels=128, n_heads=2, attention_resolutions="16,8")
+    out = run_unet_case("c2_256_b128", kw, 1, [123], probes=True)
+    out.pop("keys"); out.pop("key_shapes")
+    np.savez_compressed(os.path.join(HERE, "unet_c2_256_b128.npz"), **out)
+    print("unet_c2_256_b128.npz params", int(out["n_params"]), "|y| mean", float(np.abs(out["y"]).mean()))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["simplex", "diffusion", "unet"]
+    torch.set_num_threads(8)
+    if "simplex" in which:
+        gen_simplex()
+    if "diffusion" in which:
+        gen_diffusion()
+    if "unet" in which:
+        gen_unet()
