@@ -1,0 +1,181 @@
+"""ctypes binding of libanoddpm_hip.so (C ABI declared in include/anoddpm_hip.h).
+
+The library is mandatory: there is NO CPU or eager-PyTorch fallback anywhere in this package.
+`lib()` raises if the shared object is missing, and `require_cuda()` raises for non-HIP tensors.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
+ABI_VERSION = 1
+
+OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT = range(1, 9)
+
+
+class SimplexArgs(Structure):
+    _fields_ = [("out", c_void_p), ("zvals", c_void_p), ("tables", c_void_p), ("table_sel", c_void_p),
+                ("z0", c_int64), ("out_slice_stride", c_int64),
+                ("nslices", c_int32), ("H", c_int32), ("W", c_int32),
+                ("table_slice_stride", c_int32), ("table_sel_scale", c_int32), ("octaves", c_int32),
+                ("persistence", c_double), ("frequency", c_double)]
+
+
+class PUpdateArgs(Structure):
+    _fields_ = [("x_prev", c_void_p), ("pred_x0", c_void_p), ("mean_out", c_void_p), ("x_t", c_void_p),
+                ("eps", c_void_p), ("noise", c_void_p), ("t", c_void_p),
+                ("c_recip", c_void_p), ("c_recipm1", c_void_p), ("c_coef1", c_void_p),
+                ("c_coef2", c_void_p), ("c_sigma", c_void_p),
+                ("n", c_int64), ("B", c_int32), ("T", c_int32)]
+
+
+class IgemmArgs(Structure):
+    _fields_ = [("a0", c_void_p), ("a1", c_void_p), ("gn_scale", c_void_p), ("gn_shift", c_void_p),
+                ("bmat", c_void_p), ("bias", c_void_p), ("temb", c_void_p), ("res", c_void_p),
+                ("out", c_void_p), ("ws", c_void_p),
+                ("a0_bs", c_int64), ("a0_hs", c_int64), ("a1_bs", c_int64), ("a1_hs", c_int64),
+                ("b_bs", c_int64), ("b_hs", c_int64),
+                ("o_bs", c_int64), ("o_hs", c_int64), ("r_bs", c_int64), ("r_hs", c_int64),
+                ("c0", c_int32), ("c1", c_int32), ("a0_ld", c_int32), ("a1_ld", c_int32),
+                ("H", c_int32), ("W", c_int32), ("ks", c_int32), ("a_mode", c_int32), ("act", c_int32),
+                ("b_mode", c_int32), ("ldb", c_int32), ("N", c_int32), ("temb_ld", c_int32),
+                ("out_ld", c_int32), ("res_ld", c_int32), ("B", c_int32), ("heads", c_int32),
+                ("ksplit", c_int32), ("cfg", c_int32), ("alpha", c_float), ("gn_ld", c_int32)]
+
+
+class GnArgs(Structure):
+    _fields_ = [("a0", c_void_p), ("a1", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("scale", c_void_p), ("shift", c_void_p), ("partial", c_void_p),
+                ("a0_bs", c_int64), ("a1_bs", c_int64),
+                ("c0", c_int32), ("c1", c_int32), ("a0_ld", c_int32), ("a1_ld", c_int32),
+                ("P", c_int32), ("B", c_int32), ("groups", c_int32), ("nslab", c_int32), ("eps", c_float)]
+
+
+class SoftmaxArgs(Structure):
+    _fields_ = [("x", c_void_p), ("rows", c_int64), ("L", c_int32)]
+
+
+class ResampleArgs(Structure):
+    _fields_ = [("inp", c_void_p), ("out", c_void_p), ("B", c_int32), ("H", c_int32), ("W", c_int32),
+                ("C", c_int32), ("mode", c_int32)]
+
+
+class LinearArgs(Structure):
+    _fields_ = [("inp", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("out", c_void_p),
+                ("B", c_int32), ("K", c_int32), ("N", c_int32), ("act_in", c_int32), ("act_out", c_int32)]
+
+
+class PosembArgs(Structure):
+    _fields_ = [("t", c_void_p), ("freqs", c_void_p), ("out", c_void_p), ("B", c_int32), ("dim", c_int32),
+                ("scale", c_float)]
+
+
+class StemArgs(Structure):
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("out", c_void_p),
+                ("B", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32)]
+
+
+class LayoutArgs(Structure):
+    _fields_ = [("inp", c_void_p), ("out", c_void_p), ("B", c_int32), ("P", c_int32), ("C", c_int32),
+                ("in_ld", c_int32)]
+
+
+class Op(Structure):
+    _fields_ = [("code", c_int32), ("flags", c_int32), ("args", c_void_p)]
+
+
+class AdamwArgs(Structure):
+    _fields_ = [("p", c_void_p), ("m", c_void_p), ("v", c_void_p), ("ema", c_void_p), ("g", c_void_p),
+                ("grad_scale", c_void_p), ("n", c_int64),
+                ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float),
+                ("weight_decay", c_float), ("ema_decay", c_float), ("step", c_int32)]
+
+
+_STRUCTS = [SimplexArgs, PUpdateArgs, IgemmArgs, GnArgs, SoftmaxArgs, ResampleArgs, LinearArgs,
+            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs]
+
+# every symbol include/anoddpm_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "anoddpm_abi_version", "anoddpm_last_error", "anoddpm_device_count", "anoddpm_struct_size",
+    "anoddpm_simplex_perm_init", "anoddpm_simplex3_octaves_f64", "anoddpm_simplex3_octaves_f32",
+    "anoddpm_simplex3_grid_f64",
+    "anoddpm_q_sample", "anoddpm_p_sample_update", "anoddpm_chain_advance",
+    "anoddpm_igemm", "anoddpm_gn_stats", "anoddpm_softmax_rows", "anoddpm_resample2x",
+    "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_nhwc_to_nchw",
+    "anoddpm_run_ops", "anoddpm_prof_enable", "anoddpm_prof_collect",
+    "anoddpm_adamw_ema", "anoddpm_sumsq",
+]
+
+_lib = None
+
+
+class AnoddpmError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library (once).  Fails loudly: this package has no other compute path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise AnoddpmError(
+            f"{SO_PATH} is missing: build it with `python -m anoddpm_amd.build` "
+            "(hipcc --offload-arch=gfx950).  anoddpm_amd has no CPU / eager fallback.")
+    L = ctypes.CDLL(SO_PATH)
+    L.anoddpm_last_error.restype = ctypes.c_char_p
+    L.anoddpm_struct_size.argtypes = [c_int32]
+    if L.anoddpm_abi_version() != ABI_VERSION:
+        raise AnoddpmError("libanoddpm_hip.so ABI version mismatch; rebuild")
+    for i, st in enumerate(_STRUCTS):
+        if L.anoddpm_struct_size(i) != ctypes.sizeof(st):
+            raise AnoddpmError(f"ABI struct {st.__name__}: C sizeof {L.anoddpm_struct_size(i)} != ctypes {ctypes.sizeof(st)}")
+    L.anoddpm_simplex_perm_init.argtypes = [c_int64, POINTER(c_int16), POINTER(c_int16)]
+    for name in ("anoddpm_simplex3_octaves_f64", "anoddpm_simplex3_octaves_f32"):
+        getattr(L, name).argtypes = [POINTER(SimplexArgs), c_void_p]
+    L.anoddpm_simplex3_grid_f64.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32,
+                                            c_void_p, c_void_p]
+    L.anoddpm_q_sample.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int32, c_int64, c_int32, c_void_p]
+    L.anoddpm_p_sample_update.argtypes = [POINTER(PUpdateArgs), c_void_p]
+    L.anoddpm_chain_advance.argtypes = [c_void_p, c_int32, c_void_p, c_void_p]
+    L.anoddpm_igemm.argtypes = [POINTER(IgemmArgs), c_void_p]
+    L.anoddpm_gn_stats.argtypes = [POINTER(GnArgs), c_void_p]
+    L.anoddpm_softmax_rows.argtypes = [POINTER(SoftmaxArgs), c_void_p]
+    L.anoddpm_resample2x.argtypes = [POINTER(ResampleArgs), c_void_p]
+    L.anoddpm_linear_small.argtypes = [POINTER(LinearArgs), c_void_p]
+    L.anoddpm_posemb.argtypes = [POINTER(PosembArgs), c_void_p]
+    L.anoddpm_conv_stem.argtypes = [POINTER(StemArgs), c_void_p]
+    L.anoddpm_nhwc_to_nchw.argtypes = [POINTER(LayoutArgs), c_void_p]
+    L.anoddpm_run_ops.argtypes = [POINTER(Op), c_int32, c_void_p]
+    L.anoddpm_prof_enable.argtypes = [c_int32]
+    L.anoddpm_prof_collect.argtypes = [POINTER(c_double), POINTER(c_int64)]
+    L.anoddpm_adamw_ema.argtypes = [POINTER(AdamwArgs), c_void_p]
+    L.anoddpm_sumsq.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
+    _lib = L
+    return L
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().anoddpm_last_error()
+        raise AnoddpmError(f"{what or 'anoddpm'} failed (code {rc}): {msg.decode(errors='replace') if msg else ''}")
+
+
+def require_cuda(t, what):
+    """The HIP path is the only path: refuse CPU tensors instead of silently computing elsewhere."""
+    if not t.is_cuda:
+        raise AnoddpmError(
+            f"{what}: tensor is on '{t.device}', but anoddpm_amd runs on MI355X (HIP) devices only; "
+            "there is no CPU fallback (the CPU restatement lives in oracle/ and is test-only).")
+    return t
+
+
+def current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)

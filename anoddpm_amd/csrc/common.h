@@ -1,0 +1,38 @@
+// Shared host-side helpers for libanoddpm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/anoddpm_hip.h"
+
+namespace anoddpm {
+
+void set_error(const char *fmt, ...);
+
+#define ANODDPM_REQUIRE(cond, ...)                       \
+    do {                                                 \
+        if (!(cond)) {                                   \
+            ::anoddpm::set_error(__VA_ARGS__);           \
+            return ANODDPM_EINVAL;                       \
+        }                                                \
+    } while (0)
+
+inline int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return ANODDPM_ELAUNCH;
+    }
+    return ANODDPM_OK;
+}
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+__device__ __forceinline__ float silu_f(float x)
+{
+    // x * sigmoid(x); __expf/__fdividef are ~1e-6 relative, well inside the 1e-3 budget
+    return __fdividef(x, 1.0f + __expf(-x));
+}
+
+}  // namespace anoddpm

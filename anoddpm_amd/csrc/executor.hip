@@ -1,0 +1,144 @@
+// Native executor + library plumbing: error reporting, flat op-list runner (the C++ side of
+// UNetModel.forward, UNet.py:390-406 -- one call per forward instead of ~1000 ATen dispatches),
+// and HIP-event timing per op class for bench.py's roofline leg.
+#include <stdarg.h>
+#include <string.h>
+#include <vector>
+#include "common.h"
+
+namespace anoddpm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct ProfState {
+    bool on = false;
+    std::vector<hipEvent_t> pool;       // pairs: start, stop
+    std::vector<int> codes;
+    size_t used = 0;
+    double ms[16] = {0};
+    int64_t launches[16] = {0};
+};
+static ProfState g_prof;
+
+static int dispatch(const anoddpm_op &op, void *stream)
+{
+    switch (op.code) {
+        case ANODDPM_OP_IGEMM: return anoddpm_igemm(static_cast<const anoddpm_igemm_args *>(op.args), stream);
+        case ANODDPM_OP_GN_STATS: return anoddpm_gn_stats(static_cast<const anoddpm_gn_args *>(op.args), stream);
+        case ANODDPM_OP_SOFTMAX: return anoddpm_softmax_rows(static_cast<const anoddpm_softmax_args *>(op.args), stream);
+        case ANODDPM_OP_RESAMPLE: return anoddpm_resample2x(static_cast<const anoddpm_resample_args *>(op.args), stream);
+        case ANODDPM_OP_LINEAR: return anoddpm_linear_small(static_cast<const anoddpm_linear_args *>(op.args), stream);
+        case ANODDPM_OP_POSEMB: return anoddpm_posemb(static_cast<const anoddpm_posemb_args *>(op.args), stream);
+        case ANODDPM_OP_STEM: return anoddpm_conv_stem(static_cast<const anoddpm_stem_args *>(op.args), stream);
+        case ANODDPM_OP_LAYOUT: return anoddpm_nhwc_to_nchw(static_cast<const anoddpm_layout_args *>(op.args), stream);
+        default: set_error("run_ops: unknown op code %d", op.code); return ANODDPM_EINVAL;
+    }
+}
+
+}  // namespace anoddpm
+
+using namespace anoddpm;
+
+extern "C" int anoddpm_abi_version(void) { return 1; }
+
+extern "C" const char *anoddpm_last_error(void) { return g_err; }
+
+extern "C" int anoddpm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+extern "C" int anoddpm_run_ops(const anoddpm_op *ops, int32_t n, void *stream)
+{
+    ANODDPM_REQUIRE(ops || n == 0, "run_ops: null op list");
+    for (int i = 0; i < n; ++i) {
+        ANODDPM_REQUIRE(ops[i].args, "run_ops: op %d has null args", i);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool prof = g_prof.on && ops[i].code > 0 && ops[i].code < 16;
+        if (prof) {
+            if (g_prof.used + 2 > g_prof.pool.size()) {
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+                    set_error("run_ops: hipEventCreate failed");
+                    return ANODDPM_ELAUNCH;
+                }
+                g_prof.pool.push_back(a);
+                g_prof.pool.push_back(b);
+            }
+            e0 = g_prof.pool[g_prof.used];
+            e1 = g_prof.pool[g_prof.used + 1];
+            g_prof.used += 2;
+            g_prof.codes.push_back(ops[i].code);
+            (void)hipEventRecord(e0, as_stream(stream));
+        }
+        const int rc = dispatch(ops[i], stream);
+        if (prof) (void)hipEventRecord(e1, as_stream(stream));
+        if (rc != ANODDPM_OK) {
+            char tmp[400];
+            strncpy(tmp, g_err, sizeof(tmp) - 1);
+            tmp[sizeof(tmp) - 1] = 0;
+            set_error("op %d (code %d): %s", i, ops[i].code, tmp);
+            return rc;
+        }
+    }
+    return ANODDPM_OK;
+}
+
+extern "C" int anoddpm_prof_enable(int32_t enable)
+{
+    g_prof.on = enable != 0;
+    if (enable) {
+        g_prof.used = 0;
+        g_prof.codes.clear();
+        memset(g_prof.ms, 0, sizeof(g_prof.ms));
+        memset(g_prof.launches, 0, sizeof(g_prof.launches));
+    }
+    return ANODDPM_OK;
+}
+
+extern "C" int anoddpm_prof_collect(double *ms_per_code, int64_t *launches_per_code)
+{
+    ANODDPM_REQUIRE(ms_per_code && launches_per_code, "prof_collect: null pointer");
+    for (size_t i = 0; i < g_prof.codes.size(); ++i) {
+        hipEvent_t e0 = g_prof.pool[2 * i], e1 = g_prof.pool[2 * i + 1];
+        if (hipEventSynchronize(e1) != hipSuccess) { set_error("prof_collect: event sync failed"); return ANODDPM_ELAUNCH; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { set_error("prof_collect: elapsed failed"); return ANODDPM_ELAUNCH; }
+        g_prof.ms[g_prof.codes[i]] += ms;
+        g_prof.launches[g_prof.codes[i]] += 1;
+    }
+    g_prof.codes.clear();
+    g_prof.used = 0;
+    for (int c = 0; c < 16; ++c) { ms_per_code[c] = g_prof.ms[c]; launches_per_code[c] = g_prof.launches[c]; }
+    return ANODDPM_OK;
+}
+
+// sizeof() of every ABI struct, so that the Python ctypes mirror can verify its layout at load time.
+extern "C" int anoddpm_struct_size(int32_t which)
+{
+    switch (which) {
+        case 0: return (int)sizeof(anoddpm_simplex_args);
+        case 1: return (int)sizeof(anoddpm_p_update_args);
+        case 2: return (int)sizeof(anoddpm_igemm_args);
+        case 3: return (int)sizeof(anoddpm_gn_args);
+        case 4: return (int)sizeof(anoddpm_softmax_args);
+        case 5: return (int)sizeof(anoddpm_resample_args);
+        case 6: return (int)sizeof(anoddpm_linear_args);
+        case 7: return (int)sizeof(anoddpm_posemb_args);
+        case 8: return (int)sizeof(anoddpm_stem_args);
+        case 9: return (int)sizeof(anoddpm_layout_args);
+        case 10: return (int)sizeof(anoddpm_op);
+        case 11: return (int)sizeof(anoddpm_adamw_args);
+        default: return -1;
+    }
+}

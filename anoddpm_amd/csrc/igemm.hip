@@ -1,0 +1,342 @@
+// Implicit-GEMM convolution / GEMM for gfx950 on the fp32 matrix pipe.
+//
+// Replaces (reference file:line): nn.Conv2d 3x3 / 1x1 (UNet.py:172,193,200,387), nn.Conv1d k=1
+// (UNet.py:115,117), the QK^T and AV einsums of QKVAttention (UNet.py:148-152) and, fused into
+// the operand load, GroupNorm32-apply + SiLU (UNet.py:170-171,190-191,386), AvgPool2d /
+// nearest-x2 on the h path (UNet.py:70,89,206) and torch.cat([h, skip], 1) (UNet.py:402).
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 -- fp32 inputs, fp32 accumulate, bitwise an fmaf chain, so the
+// result is plain fp32 (no reduced-precision inputs; the 1e-3 parity budget is not spent here).
+// Roofline: compute (157.3 TFLOP/s fp32 matrix peak); AI of the 3x3 layers is ~280 flop/B.
+//
+// Tiling.  A workgroup (4 waves, 2x2) owns BM output pixels x BN output channels of ONE image;
+// the pixels form a TH x TW patch so that all nine taps of a 3x3 filter read one LDS-resident
+// halo tile ((TH+2) x (TW+2) pixels x 32 channels, staged once per 32-channel slice of K and
+// transformed -- affine, SiLU, resample -- exactly once on the way in).  The weight tile for
+// (tap, K-slice) is [8][BN][4] floats so that each lane's four consecutive k values are one
+// ds_read_b128; the next weight tile is prefetched into registers while the current one feeds the
+// MFMAs.  K order inside a 32-slice is permuted (lane half h takes k = 8j+4h..8j+4h+3) -- legal
+// because A and B use the same permutation.
+//
+// LDS layout.  A: [pixel][8 quads] with the quad index XOR-ed by (pixel>>1)&7, which spreads the 16
+// lanes of every ds_read_b128 service group (non-contiguous lane sets, MI355X_MICROARCH "LDS") over
+// all 16 16-byte slots of the 256-byte bank row.  B: [k/4][n][4], lanes read consecutive n ->
+// conflict-free by construction.
+#include "common.h"
+
+using anoddpm::silu_f;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KC = 32;  // K slice held in LDS
+
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void igemm_kernel(const anoddpm_igemm_args a, const int log2TW, const int TH, const int tiles_x)
+{
+    constexpr int MT = BM / 64, NT = BN / 64;          // 32x32 MFMA tiles per wave (2x2 waves)
+    constexpr int APIX = (BM == 128) ? 204 : 136;      // largest halo tile in pixels
+    constexpr int BJ = 8 * BN / 256;                   // B float4 slots per thread per step
+    __shared__ __attribute__((aligned(16))) float lds[APIX * KC + 8 * BN * 4];
+    f32x4 *ldsA = reinterpret_cast<f32x4 *>(lds);
+    f32x4 *ldsB = reinterpret_cast<f32x4 *>(lds + APIX * KC);
+    float *ldsBf = lds + APIX * KC;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const int KS = a.ks, pad = KS >> 1, taps = KS * KS;
+    const int TW = 1 << log2TW;
+    const int H = a.H, W = a.W;
+    const int HP = TW + 2 * pad;
+    const int npix = (TH + 2 * pad) * HP;
+    const int K = a.c0 + a.c1;
+    const int N = a.N;
+    const int K4 = K >> 2;
+
+    const int y0 = (blockIdx.x / tiles_x) * TH;
+    const int x0 = (blockIdx.x % tiles_x) << log2TW;
+    const int n0 = blockIdx.y * BN;
+    const int ksplit = a.ksplit;
+    const int ksi = blockIdx.z % ksplit;
+    const int z = blockIdx.z / ksplit;
+    const int b = z / a.heads, hd = z % a.heads;
+
+    const float *A0 = a.a0 + (int64_t)b * a.a0_bs + (int64_t)hd * a.a0_hs;
+    const float *A1 = a.a1 ? a.a1 + (int64_t)b * a.a1_bs + (int64_t)hd * a.a1_hs : nullptr;
+    const float *Bm = a.b_mode ? a.bmat + (int64_t)b * a.b_bs + (int64_t)hd * a.b_hs : a.bmat;
+    const float *gsc = a.gn_scale ? a.gn_scale + (int64_t)b * a.gn_ld : nullptr;
+    const float *gsh = a.gn_shift ? a.gn_shift + (int64_t)b * a.gn_ld : nullptr;
+
+    const int nchunks = (K + KC - 1) / KC;
+    const int cps = (nchunks + ksplit - 1) / ksplit;
+    const int c_begin = ksi * cps;
+    const int c_end = (c_begin + cps < nchunks) ? c_begin + cps : nchunks;
+    const int nsteps = (c_end > c_begin) ? (c_end - c_begin) * taps : 0;
+
+    // lane's pixel rows inside the halo tile (tap 0,0)
+    int pixbase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = (wm * MT + mt) * 32 + l31;
+        pixbase[mt] = (m >> log2TW) * HP + (m & (TW - 1));
+    }
+    int ncol[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) ncol[nt] = (wn * NT + nt) * 32 + l31;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    f32x4 breg[BJ];
+
+    // ---- B tile: global -> registers ----------------------------------------------------------
+    auto load_B = [&](int step) {
+        const int chunk = c_begin + step / taps;
+        const int tap = step % taps;
+        const int kbase = chunk * KC;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int idx = tid + j * 256;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a.b_mode == 0) {
+                const int r = idx / BN, n = idx % BN;
+                const int k4 = (kbase >> 2) + r;
+                if (k4 < K4 && n0 + n < N)
+                    v = ld4(Bm + (((int64_t)tap * K4 + k4) * N + n0 + n) * 4);
+            } else if (a.b_mode == 1) {            // rows [N][K]: B[k][n] = src[n][k]
+                const int n = idx >> 3, r = idx & 7;
+                const int k = kbase + r * 4;
+                if (k < K && n0 + n < N) v = ld4(Bm + (int64_t)(n0 + n) * a.ldb + k);
+            } else {                               // rows [K][N]
+                const int k = idx / (BN / 4), n4 = idx % (BN / 4);
+                if (kbase + k < K && n0 + n4 * 4 < N) v = ld4(Bm + (int64_t)(kbase + k) * a.ldb + n0 + n4 * 4);
+            }
+            breg[j] = v;
+        }
+    };
+    auto store_B = [&]() {
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int idx = tid + j * 256;
+            if (a.b_mode == 0) {
+                ldsB[idx] = breg[j];               // idx = r*BN + n already
+            } else if (a.b_mode == 1) {
+                const int n = idx >> 3, r = idx & 7;
+                ldsB[r * BN + n] = breg[j];
+            } else {
+                const int k = idx / (BN / 4), n4 = idx % (BN / 4);
+                float *dst = ldsBf + (((k >> 2) * BN + n4 * 4) * 4 + (k & 3));
+                dst[0] = breg[j][0];
+                dst[4] = breg[j][1];
+                dst[8] = breg[j][2];
+                dst[12] = breg[j][3];
+            }
+        }
+    };
+
+    // ---- A halo tile: global -> (affine, SiLU, resample) -> LDS --------------------------------
+    auto stage_A = [&](int chunk) {
+        const int kbase = chunk * KC;
+        const float *src;
+        int ld, koff;
+        if (kbase < a.c0) { src = A0; ld = a.a0_ld; koff = kbase; }
+        else              { src = A1; ld = a.a1_ld; koff = kbase - a.c0; }
+        const int c4 = tid & 7;
+        const int k = kbase + c4 * 4;
+        const bool kvalid = k < K;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        const bool affine = (gsc != nullptr);
+        if (affine && kvalid) { sc = ld4(gsc + k); sh = ld4(gsh + k); }
+        const bool act = a.act != 0;
+        auto xform = [&](f32x4 v) {
+            if (affine) v = v * sc + sh;
+            if (act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+            return v;
+        };
+        src += koff + c4 * 4;
+        for (int p = tid >> 3; p < npix; p += 32) {
+            const int hy = p / HP, hx = p - hy * HP;
+            const int gy = y0 + hy - pad, gx = x0 + hx - pad;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (kvalid && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                if (a.a_mode == 0) {
+                    v = xform(ld4(src + ((int64_t)gy * W + gx) * ld));
+                } else if (a.a_mode == 1) {        // source is (H/2, W/2): nearest x2
+                    v = xform(ld4(src + ((int64_t)(gy >> 1) * (W >> 1) + (gx >> 1)) * ld));
+                } else {                           // source is (2H, 2W): 2x2 mean of transformed values
+                    const int64_t w2 = (int64_t)W * 2;
+                    const float *q = src + ((int64_t)(2 * gy) * w2 + 2 * gx) * ld;
+                    const f32x4 v00 = xform(ld4(q)), v01 = xform(ld4(q + ld));
+                    const f32x4 v10 = xform(ld4(q + w2 * ld)), v11 = xform(ld4(q + (w2 + 1) * ld));
+                    v = (((v00 + v01) + v10) + v11) * 0.25f;
+                }
+            }
+            ldsA[p * 8 + (c4 ^ ((p >> 1) & 7))] = v;
+        }
+    };
+
+    // ---- main loop -----------------------------------------------------------------------------
+    if (nsteps > 0) load_B(0);
+    for (int step = 0; step < nsteps; ++step) {
+        const int tap = step % taps;
+        __syncthreads();                            // previous step's LDS reads are done
+        store_B();
+        if (tap == 0) stage_A(c_begin + step / taps);
+        __syncthreads();
+        if (step + 1 < nsteps) load_B(step + 1);    // in flight during the MFMAs below
+
+        const int tapoff = (KS == 3) ? (tap / 3) * HP + (tap % 3) : 0;
+        int pA[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) pA[mt] = pixbase[mt] + tapoff;
+#pragma unroll
+        for (int k8 = 0; k8 < KC / 8; ++k8) {
+            const int c4 = k8 * 2 + h;
+            f32x4 av[MT], bv[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = ldsA[pA[mt] * 8 + (c4 ^ ((pA[mt] >> 1) & 7))];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = ldsB[c4 * BN + ncol[nt]];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][kk], bv[nt][kk], acc[mt][nt], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------
+    const int P = H * W;
+    const int Z = a.B * a.heads;
+    float *O = a.out + (int64_t)b * a.o_bs + (int64_t)hd * a.o_hs;
+    const float *R = a.res ? a.res + (int64_t)b * a.r_bs + (int64_t)hd * a.r_hs : nullptr;
+    const float *TE = a.temb ? a.temb + (int64_t)b * a.temb_ld : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + ncol[nt];
+            if (n >= N) continue;
+            float add = 0.f;
+            if (ksplit == 1) {
+                if (a.bias) add += a.bias[n];
+                if (TE) add += TE[n];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int m = (wm * MT + mt) * 32 + row;
+                const int oy = y0 + (m >> log2TW), ox = x0 + (m & (TW - 1));
+                if (oy >= H || ox >= W) continue;              // partial tile on tiny feature maps
+                const int64_t pix = (int64_t)oy * W + ox;
+                float v = acc[mt][nt][r];
+                if (ksplit > 1) {
+                    a.ws[(((int64_t)ksi * Z + z) * P + pix) * N + n] = v;
+                } else {
+                    v = a.alpha * v + add;
+                    if (R) v += R[pix * a.res_ld + n];
+                    O[pix * a.out_ld + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// Split-K tail: out = alpha * sum_ks ws[ks] + bias + temb + res   (fixed summation order)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const anoddpm_igemm_args a)
+{
+    const int P = a.H * a.W;
+    const int N4 = a.N >> 2;
+    const int Z = a.B * a.heads;
+    const int64_t total = (int64_t)Z * P * N4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int n4 = (int)(i % N4);
+        const int64_t zp = i / N4;
+        const int64_t pix = zp % P;
+        const int z = (int)(zp / P);
+        const int b = z / a.heads, hd = z % a.heads;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < a.ksplit; ++ks)
+            s += ld4(a.ws + ((((int64_t)ks * Z + z) * P + pix) * a.N) + n4 * 4);
+        s *= a.alpha;
+        if (a.bias) s += ld4(a.bias + n4 * 4);
+        if (a.temb) s += ld4(a.temb + (int64_t)b * a.temb_ld + n4 * 4);
+        if (a.res) s += ld4(a.res + (int64_t)b * a.r_bs + (int64_t)hd * a.r_hs + pix * a.res_ld + n4 * 4);
+        *reinterpret_cast<f32x4 *>(a.out + (int64_t)b * a.o_bs + (int64_t)hd * a.o_hs + pix * a.out_ld + n4 * 4) = s;
+    }
+}
+
+inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream)
+{
+    ANODDPM_REQUIRE(a && a->a0 && a->bmat && a->out, "igemm: null pointer");
+    ANODDPM_REQUIRE(a->ks == 1 || a->ks == 3, "igemm: ks must be 1 or 3");
+    ANODDPM_REQUIRE(a->cfg == 0 || a->cfg == 1, "igemm: cfg must be 0 or 1");
+    const int BM = a->cfg == 0 ? 128 : 64, BN = BM;
+    ANODDPM_REQUIRE(a->c0 > 0 && a->c0 % 4 == 0 && a->c1 >= 0 && a->c1 % 4 == 0, "igemm: channel counts must be multiples of 4");
+    ANODDPM_REQUIRE(a->c1 == 0 || (a->a1 && a->c0 % KC == 0), "igemm: dual source needs a1 and c0 %% 32 == 0");
+    ANODDPM_REQUIRE(a->N >= 1 && a->B >= 1 && a->heads >= 1 && a->ksplit >= 1, "igemm: bad sizes");
+    ANODDPM_REQUIRE(a->a_mode >= 0 && a->a_mode <= 2 && a->b_mode >= 0 && a->b_mode <= 2, "igemm: bad mode");
+    ANODDPM_REQUIRE(a->a_mode == 0 || a->ks == 3, "igemm: resampling is only fused into 3x3 loads");
+    ANODDPM_REQUIRE(a->b_mode == 0 || a->ks == 1, "igemm: activation B operands need ks == 1");
+    ANODDPM_REQUIRE(a->b_mode != 2 || a->N % 4 == 0, "igemm: b_mode 2 needs N %% 4 == 0");
+    ANODDPM_REQUIRE(a->b_mode == 0 || a->ldb % 4 == 0, "igemm: ldb must be a multiple of 4");
+    ANODDPM_REQUIRE(a->a0_ld % 4 == 0 && (a->c1 == 0 || a->a1_ld % 4 == 0), "igemm: pixel strides must be multiples of 4 floats");
+    ANODDPM_REQUIRE(al16(a->a0) && al16(a->bmat) && (!a->a1 || al16(a->a1)), "igemm: operands must be 16-byte aligned");
+    ANODDPM_REQUIRE((a->a0_bs | a->a0_hs | a->a1_bs | a->a1_hs | a->b_bs | a->b_hs) % 4 == 0, "igemm: strides must be multiples of 4 floats");
+    ANODDPM_REQUIRE(!a->gn_scale || (a->gn_shift && a->gn_ld % 4 == 0 && al16(a->gn_scale) && al16(a->gn_shift)), "igemm: bad GroupNorm affine");
+    ANODDPM_REQUIRE(a->ksplit == 1 || (a->ws && a->N % 4 == 0 && al16(a->ws) && a->out_ld % 4 == 0 && al16(a->out) &&
+                                       (!a->res || (a->res_ld % 4 == 0 && al16(a->res))) && (!a->bias || al16(a->bias)) &&
+                                       (!a->temb || (a->temb_ld % 4 == 0 && al16(a->temb)))),
+                    "igemm: split-K needs a workspace and 16-byte aligned epilogue operands");
+    int H = a->H, W = a->W, log2TW, TH;
+    ANODDPM_REQUIRE(H >= 1 && W >= 1, "igemm: bad image size");
+    const int64_t P = (int64_t)H * W;
+    anoddpm_igemm_args k = *a;
+    int tiles_x, tiles_y;
+    if (a->ks == 1) {                 // treat the image as one row of P pixels
+        k.H = 1; k.W = (int)P; H = 1; W = (int)P;
+        TH = 1;
+        log2TW = (BM == 128) ? 7 : 6;
+        tiles_x = (int)((P + BM - 1) / BM);
+        tiles_y = 1;
+    } else {
+        ANODDPM_REQUIRE((W & (W - 1)) == 0 && W >= 2, "igemm: 3x3 path needs power-of-two width >= 2");
+        const int TW = W < 32 ? W : 32;
+        log2TW = 0;
+        while ((1 << log2TW) < TW) ++log2TW;
+        TH = BM / TW;
+        tiles_x = W / TW;
+        tiles_y = (H + TH - 1) / TH;
+        ANODDPM_REQUIRE((TH + 2) * (TW + 2) <= (BM == 128 ? 204 : 136), "igemm: halo tile exceeds LDS budget for this shape");
+    }
+    const int64_t Z = (int64_t)a->B * a->heads;
+    dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((a->N + BN - 1) / BN), (unsigned)(Z * a->ksplit));
+    ANODDPM_REQUIRE(grid.y <= 65535 && Z * a->ksplit <= 65535, "igemm: grid too large");
+    hipStream_t s = anoddpm::as_stream(stream);
+    if (BM == 128) hipLaunchKernelGGL((igemm_kernel<128, 128>), grid, dim3(256), 0, s, k, log2TW, TH, tiles_x);
+    else           hipLaunchKernelGGL((igemm_kernel<64, 64>), grid, dim3(256), 0, s, k, log2TW, TH, tiles_x);
+    if (a->ksplit > 1) {
+        const int64_t total = Z * P * (a->N / 4);
+        const int64_t blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, *a);
+    }
+    return anoddpm::check_launch("igemm");
+}

@@ -1,0 +1,285 @@
+// OpenSimplex-v1 3-D multi-octave noise on gfx950 -- replaces simplex.py:166-192 (_init, host),
+// :202-208 (_extrapolate3), :321-830 (_noise3), :833-840 (_noise3a) and the octave loops of
+// :37-54 / :75-93.  Bit-exact with the reference's fp64 arithmetic: this translation unit is
+// compiled with -ffp-contract=off (no FMA contraction), divisions are IEEE, and every lattice
+// vertex is displaced in the reference's operation order.
+//
+// Kernel shape: one thread per output pixel, 256-thread blocks covering 64x4 pixel tiles; the
+// permutation / gradient-index tables (512 B) and the 24 gradient vectors live in LDS; the octave
+// loop runs in registers and the field is written once (8 B or 4 B per pixel).  The work is fp64
+// ALU + LDS bound (~200 fp64 ops per octave-evaluation), not HBM bound.
+//
+// A vertex is an integer lattice offset (i,j,k); its displacement component along an axis is
+//     ((d0 - A) - n*SQUISH) - C          n = i+j+k
+// with (A,C) = (offset, 0) normally.  Two reference branches build one component as
+// "(d0 - 1 - 3*SQUISH) - 1" (simplex.py:503,506) or "(d0 - 2*SQUISH) - 2" (:737-743); they map
+// to (A,C) = (offset-1, 1) and (0, 2).  Subtracting +0.0 is exact, so one formula serves all.
+#include "common.h"
+
+namespace {
+
+constexpr double STRETCH3 = -1.0 / 6;
+constexpr double SQUISH3 = 1.0 / 3;
+constexpr double NORM3 = 103.0;
+
+__constant__ signed char kGrad3[72] = {
+    -11, 4, 4,  -4, 11, 4,  -4, 4, 11,   11, 4, 4,   4, 11, 4,   4, 4, 11,
+    -11,-4, 4,  -4,-11, 4,  -4,-4, 11,   11,-4, 4,   4,-11, 4,   4,-4, 11,
+    -11, 4,-4,  -4, 11,-4,  -4, 4,-11,   11, 4,-4,   4, 11,-4,   4, 4,-11,
+    -11,-4,-4,  -4,-11,-4,  -4,-4,-11,   11,-4,-4,   4,-11,-4,   4,-4,-11,
+};
+
+struct Tables {
+    unsigned char perm[256];
+    unsigned char pgi3[256];
+    double grad[72];
+};
+
+struct Vtx {
+    int i, j, k;        // lattice offset
+    int lx, ly, lz;     // 0 std, 1 "late -1", 2 "late -2" per component
+};
+
+__device__ __forceinline__ Vtx mk(int i, int j, int k) { return Vtx{i, j, k, 0, 0, 0}; }
+
+__device__ __forceinline__ double component(double d0, int off, double sq, int late)
+{
+    const double A = (late == 2) ? 0.0 : (double)(off - (late == 1 ? 1 : 0));
+    const double C = (late == 2) ? 2.0 : (late == 1 ? 1.0 : 0.0);
+    return ((d0 - A) - sq) - C;
+}
+
+__device__ __forceinline__ double vertex_term(const Tables &T, long long xsb, long long ysb, long long zsb,
+                                              double dx0, double dy0, double dz0, Vtx v, bool on)
+{
+    const int n = v.i + v.j + v.k;
+    const double sq = (double)n * SQUISH3;          // n*SQUISH formed as one rounded constant
+    const double dx = component(dx0, v.i, sq, v.lx);
+    const double dy = component(dy0, v.j, sq, v.ly);
+    const double dz = component(dz0, v.k, sq, v.lz);
+    double attn = 2 - dx * dx - dy * dy - dz * dz;
+    double r = 0.0;
+    if (on && attn > 0) {
+        const int h0 = T.perm[(int)((xsb + v.i) & 0xFF)];
+        const int h1 = T.perm[(int)((h0 + ysb + v.j) & 0xFF)];
+        const int gi = T.pgi3[(int)((h1 + zsb + v.k) & 0xFF)];
+        attn *= attn;
+        r = attn * attn * (T.grad[gi] * dx + T.grad[gi + 1] * dy + T.grad[gi + 2] * dz);
+    }
+    return r;
+}
+
+__device__ double noise3(const Tables &T, double x, double y, double z)
+{
+    const double stretch = (x + y + z) * STRETCH3;
+    const double xs = x + stretch, ys = y + stretch, zs = z + stretch;
+    const double fx = floor(xs), fy = floor(ys), fz = floor(zs);
+    const long long xsb = (long long)fx, ysb = (long long)fy, zsb = (long long)fz;
+    const double squish = (double)(xsb + ysb + zsb) * SQUISH3;
+    const double xb = (double)xsb + squish, yb = (double)ysb + squish, zb = (double)zsb + squish;
+    const double xins = xs - (double)xsb, yins = ys - (double)ysb, zins = zs - (double)zsb;
+    const double in_sum = xins + yins + zins;
+    const double dx0 = x - xb, dy0 = y - yb, dz0 = z - zb;
+
+    Vtx e0 = mk(0, 0, 0), e1 = mk(0, 0, 0);
+    int body;       // six 3-bit vertex codes (bit0 = +x, bit1 = +y, bit2 = +z), slot s at bits [3s,3s+3)
+    int nbody;
+
+    if (in_sum <= 1) {                       // tetrahedron at (0,0,0): simplex.py:354-468
+        int ap = 1, bp = 2;
+        double as = xins, bs = yins;
+        if (as >= bs && zins > bs) { bs = zins; bp = 4; }
+        else if (as < bs && zins > as) { as = zins; ap = 4; }
+        const double wins = 1 - in_sum;
+        if (wins > as || wins > bs) {
+            const int c = (bs > as) ? bp : ap;
+            if (c & 1) { e0.i = 1; e1.i = 1; } else { e0.i = -1; e1.i = 0; }
+            if (c & 2) { e0.j = 1; e1.j = 1; } else if (c & 1) { e0.j = -1; } else { e1.j = -1; }
+            if (c & 4) { e0.k = 1; e1.k = 1; } else { e1.k = -1; }
+        } else {
+            const int c = ap | bp;
+            e0 = mk(c & 1, (c >> 1) & 1, (c >> 2) & 1);
+            e1 = mk((c & 1) ? 1 : -1, (c & 2) ? 1 : -1, (c & 4) ? 1 : -1);
+        }
+        body = 0 | (1 << 3) | (2 << 6) | (4 << 9);
+        nbody = 4;
+    } else if (in_sum >= 2) {                // tetrahedron at (1,1,1): simplex.py:469-586
+        int ap = 6, bp = 5;
+        double as = xins, bs = yins;
+        if (as <= bs && zins < bs) { bs = zins; bp = 3; }
+        else if (as > bs && zins < as) { as = zins; ap = 3; }
+        const double wins = 3 - in_sum;
+        if (wins < as || wins < bs) {
+            const int c = (bs < as) ? bp : ap;
+            if (c & 1) { e0.i = 2; e1.i = 1; }
+            if (c & 2) {
+                e0.j = 1; e1.j = 1;
+                if (c & 1) { e1.j = 2; e1.ly = 1; } else { e0.j = 2; e0.ly = 1; }
+            }
+            if (c & 4) { e0.k = 1; e1.k = 2; }
+        } else {
+            const int c = ap & bp;
+            e0 = mk(c & 1, (c >> 1) & 1, (c >> 2) & 1);
+            e1 = mk(2 * (c & 1), 2 * ((c >> 1) & 1), 2 * ((c >> 2) & 1));
+        }
+        body = 3 | (5 << 3) | (6 << 6) | (7 << 9);
+        nbody = 4;
+    } else {                                 // octahedron: simplex.py:587-798
+        double as, bs;
+        int ap, bp;
+        bool af, bf;
+        const double p1 = xins + yins, p2 = xins + zins, p3 = yins + zins;
+        if (p1 > 1) { as = p1 - 1; ap = 3; af = true; } else { as = 1 - p1; ap = 4; af = false; }
+        if (p2 > 1) { bs = p2 - 1; bp = 5; bf = true; } else { bs = 1 - p2; bp = 2; bf = false; }
+        if (p3 > 1) {
+            const double sc = p3 - 1;
+            if (as <= bs && as < sc) { ap = 6; af = true; }
+            else if (as > bs && bs < sc) { bp = 6; bf = true; }
+        } else {
+            const double sc = 1 - p3;
+            if (as <= bs && as < sc) { ap = 1; af = false; }
+            else if (as > bs && bs < sc) { bp = 1; bf = false; }
+        }
+        if (af == bf) {
+            if (af) {
+                const int c = ap & bp;
+                e0 = mk(1, 1, 1);
+                e1 = (c & 1) ? mk(2, 0, 0) : (c & 2) ? mk(0, 2, 0) : mk(0, 0, 2);
+            } else {
+                const int c = ap | bp;
+                e1 = !(c & 1) ? mk(-1, 1, 1) : !(c & 2) ? mk(1, -1, 1) : mk(1, 1, -1);
+            }
+        } else {
+            const int c1 = af ? ap : bp;
+            const int c2 = af ? bp : ap;
+            e0 = !(c1 & 1) ? mk(-1, 1, 1) : !(c1 & 2) ? mk(1, -1, 1) : mk(1, 1, -1);
+            if (c2 & 1)      { e1 = mk(2, 0, 0); e1.lx = 2; }
+            else if (c2 & 2) { e1 = mk(0, 2, 0); e1.ly = 2; }
+            else             { e1 = mk(0, 0, 2); e1.lz = 2; }
+        }
+        body = 1 | (2 << 3) | (4 << 6) | (3 << 9) | (5 << 12) | (6 << 15);
+        nbody = 6;
+    }
+
+    double value = 0.0;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int code = (body >> (3 * s)) & 7;
+        value += vertex_term(T, xsb, ysb, zsb, dx0, dy0, dz0,
+                             mk(code & 1, (code >> 1) & 1, (code >> 2) & 1), s < nbody);
+    }
+    value += vertex_term(T, xsb, ysb, zsb, dx0, dy0, dz0, e0, true);
+    value += vertex_term(T, xsb, ysb, zsb, dx0, dy0, dz0, e1, true);
+    return value / NORM3;
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void simplex3_octaves_kernel(anoddpm_simplex_args a)
+{
+    __shared__ Tables T;
+    const int s = blockIdx.z;
+    long long tab = (a.table_sel ? (long long)(*a.table_sel) * a.table_sel_scale : 0) +
+                    (long long)s * a.table_slice_stride;
+    const int16_t *src = a.tables + tab * 512;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        T.perm[i] = (unsigned char)src[i];
+        T.pgi3[i] = (unsigned char)src[256 + i];
+    }
+    if (threadIdx.x < 72) T.grad[threadIdx.x] = (double)kGrad3[threadIdx.x];
+    __syncthreads();
+
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.W || y >= a.H) return;
+    const long long zi = a.zvals ? a.zvals[s] : a.z0 + s;
+
+    double acc = 0.0, amp = 1.0, f = a.frequency;
+    for (int o = 0; o < a.octaves; ++o) {
+        const double n = noise3(T, (double)x / f, (double)y / f, (double)zi / f);
+        acc = acc + amp * n;            // noise += amplitude * field, octave 0 first (simplex.py:90)
+        f = f / 2;
+        amp = amp * a.persistence;
+    }
+    OutT *out = reinterpret_cast<OutT *>(a.out) + (long long)s * a.out_slice_stride + (long long)y * a.W + x;
+    *out = (OutT)acc;
+}
+
+// simplex.py:833-840 (_noise3a): arbitrary coordinate vectors, out[z][y][x] = noise3(X[x], Y[y], Z[z]).
+__global__ __launch_bounds__(256) void simplex3_grid_kernel(double *out, const double *X, int nx, const double *Y, int ny,
+                                                            const double *Z, int nz, const int16_t *tables)
+{
+    __shared__ Tables T;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        T.perm[i] = (unsigned char)tables[i];
+        T.pgi3[i] = (unsigned char)tables[256 + i];
+    }
+    if (threadIdx.x < 72) T.grad[threadIdx.x] = (double)kGrad3[threadIdx.x];
+    __syncthreads();
+    const long long total = (long long)nx * ny * nz;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ix = (int)(i % nx);
+        const int iy = (int)((i / nx) % ny);
+        const int iz = (int)(i / ((long long)nx * ny));
+        out[i] = noise3(T, X[ix], Y[iy], Z[iz]);
+    }
+}
+
+}  // namespace
+
+extern "C" int anoddpm_simplex3_grid_f64(double *out, const double *X, int32_t nx, const double *Y, int32_t ny,
+                                         const double *Z, int32_t nz, const int16_t *tables, void *stream)
+{
+    ANODDPM_REQUIRE(nx >= 0 && ny >= 0 && nz >= 0, "simplex3_grid: negative size");
+    const long long total = (long long)nx * ny * nz;
+    if (total == 0) return ANODDPM_OK;
+    ANODDPM_REQUIRE(out && X && Y && Z && tables, "simplex3_grid: null pointer");
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(simplex3_grid_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0,
+                       anoddpm::as_stream(stream), out, X, nx, Y, ny, Z, nz, tables);
+    return anoddpm::check_launch("simplex3_grid");
+}
+
+extern "C" int anoddpm_simplex_perm_init(int64_t seed, int16_t *perm, int16_t *pgi3)
+{
+    ANODDPM_REQUIRE(perm && pgi3, "simplex_perm_init: null table pointer");
+    int16_t source[256];
+    for (int i = 0; i < 256; ++i) source[i] = (int16_t)i;
+    uint64_t s = (uint64_t)seed;
+    const uint64_t MUL = 6364136223846793005ULL, INC = 1442695040888963407ULL;
+    for (int w = 0; w < 3; ++w) s = s * MUL + INC;            // three warm-up rounds (simplex.py:181-183)
+    for (int i = 255; i >= 0; --i) {
+        s = s * MUL + INC;                                    // int64 wrap-around
+        __int128 wide = (__int128)(int64_t)s + 31;            // "+31" does NOT wrap (Python int)
+        __int128 m = wide % (i + 1);
+        if (m < 0) m += i + 1;                                // floor-mod
+        const int r = (int)m;
+        perm[i] = source[r];
+        pgi3[i] = (int16_t)((perm[i] % 24) * 3);
+        source[r] = source[i];
+    }
+    return ANODDPM_OK;
+}
+
+template <typename OutT>
+static int launch_simplex(const anoddpm_simplex_args *a, void *stream)
+{
+    ANODDPM_REQUIRE(a && a->out && a->tables, "simplex3_octaves: null pointer");
+    ANODDPM_REQUIRE(a->nslices >= 0 && a->H >= 0 && a->W >= 0 && a->octaves >= 0, "simplex3_octaves: negative size");
+    ANODDPM_REQUIRE(a->nslices <= 65535, "simplex3_octaves: nslices > 65535 (split the launch)");
+    ANODDPM_REQUIRE(a->out_slice_stride >= (int64_t)a->H * a->W, "simplex3_octaves: slice stride < H*W");
+    if (a->nslices == 0 || a->H == 0 || a->W == 0) return ANODDPM_OK;
+    dim3 grid((a->W + 63) / 64, (a->H + 3) / 4, a->nslices);
+    ANODDPM_REQUIRE(grid.y <= 65535, "simplex3_octaves: H too large");
+    hipLaunchKernelGGL(simplex3_octaves_kernel<OutT>, grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
+    return anoddpm::check_launch("simplex3_octaves");
+}
+
+extern "C" int anoddpm_simplex3_octaves_f64(const anoddpm_simplex_args *a, void *stream)
+{
+    return launch_simplex<double>(a, stream);
+}
+
+extern "C" int anoddpm_simplex3_octaves_f32(const anoddpm_simplex_args *a, void *stream)
+{
+    return launch_simplex<float>(a, stream);
+}

@@ -1,0 +1,336 @@
+// Memory-bound UNet helper kernels for gfx950 (everything that is not the MFMA implicit GEMM):
+// GroupNorm statistics -> per-channel affine, row softmax, 2x resampling, small-batch linear
+// layers, sinusoidal timestep features, the Cin<=4 stem convolution and the NHWC->NCHW edge copy.
+// All of them stream NHWC fp32 with 16-byte lanes; roofline = HBM.
+#include "common.h"
+
+using anoddpm::silu_f;
+
+namespace {
+
+// ---------------------------------------------------------------- GroupNorm statistics --------
+// Stage 1: grid (nslab, B).  Threads are laid out (row, channel-quad); every thread keeps fp64
+// sums for its 4 channels over its pixel rows, rows are combined through LDS in a fixed order
+// (deterministic, no atomics), groups are reduced by 32 threads.  Stage 2 folds the slabs and
+// emits scale/shift.  Two sources = torch.cat([h, skip], 1) read in place (UNet.py:402).
+__global__ __launch_bounds__(256) void gn_partial_kernel(anoddpm_gn_args a)
+{
+    __shared__ double lds_s[256 * 4];
+    __shared__ double lds_q[256 * 4];
+    const int C = a.c0 + a.c1;
+    const int C4 = C >> 2;
+    const int TQ = C4 < 256 ? C4 : 256;
+    const int R = 256 / TQ;
+    const int npass = (C4 + TQ - 1) / TQ;
+    const int cpg = C / a.groups;
+    const int tid = threadIdx.x;
+    const int tq = tid % TQ, tr = tid / TQ;
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int sp = (a.P + a.nslab - 1) / a.nslab;
+    const int p0 = slab * sp;
+    const int p1 = (p0 + sp < a.P) ? p0 + sp : a.P;
+    double gs = 0.0, gq = 0.0;                       // group totals (threads 0..groups-1)
+
+    for (int pass = 0; pass < npass; ++pass) {
+        const int quad = pass * TQ + tq;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        if (tr < R && quad < C4) {
+            const int c = quad * 4;
+            const float *src;
+            int ld;
+            if (c < a.c0) { src = a.a0 + (int64_t)b * a.a0_bs + c; ld = a.a0_ld; }
+            else          { src = a.a1 + (int64_t)b * a.a1_bs + (c - a.c0); ld = a.a1_ld; }
+            for (int p = p0 + tr; p < p1; p += R) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + (int64_t)p * ld);
+                const double d0 = v.x, d1 = v.y, d2 = v.z, d3 = v.w;
+                s0 += d0; s1 += d1; s2 += d2; s3 += d3;
+                q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
+            }
+        }
+        if (tr < R) {
+            const int o = (tr * TQ + tq) * 4;
+            lds_s[o] = s0; lds_s[o + 1] = s1; lds_s[o + 2] = s2; lds_s[o + 3] = s3;
+            lds_q[o] = q0; lds_q[o + 1] = q1; lds_q[o + 2] = q2; lds_q[o + 3] = q3;
+        }
+        __syncthreads();
+        if (tid < a.groups) {
+            const int clo = pass * TQ * 4, chi = clo + TQ * 4;
+            int g0 = tid * cpg, g1 = g0 + cpg;
+            g0 = g0 > clo ? g0 : clo;
+            g1 = g1 < chi ? g1 : chi;
+            for (int c = g0; c < g1; ++c)
+                for (int r = 0; r < R; ++r) {
+                    gs += lds_s[r * TQ * 4 + (c - clo)];
+                    gq += lds_q[r * TQ * 4 + (c - clo)];
+                }
+        }
+        __syncthreads();
+    }
+    if (tid < a.groups) {
+        double *dst = a.partial + ((int64_t)(b * a.nslab + slab) * a.groups + tid) * 2;
+        dst[0] = gs;
+        dst[1] = gq;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(anoddpm_gn_args a)
+{
+    __shared__ double mean_s[64];
+    __shared__ double rstd_s[64];
+    const int C = a.c0 + a.c1;
+    const int cpg = C / a.groups;
+    const int b = blockIdx.x;
+    if ((int)threadIdx.x < a.groups) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < a.nslab; ++k) {
+            const double *src = a.partial + ((int64_t)(b * a.nslab + k) * a.groups + threadIdx.x) * 2;
+            s += src[0];
+            q += src[1];
+        }
+        const double n = (double)a.P * cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        mean_s[threadIdx.x] = mean;
+        rstd_s[threadIdx.x] = 1.0 / sqrt(var + (double)a.eps);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const double sc = rstd_s[g] * (double)a.gamma[c];
+        a.scale[(int64_t)b * C + c] = (float)sc;
+        a.shift[(int64_t)b * C + c] = (float)((double)a.beta[c] - mean_s[g] * sc);
+    }
+}
+
+// ---------------------------------------------------------------- softmax ---------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float *x, int64_t rows, int L)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float *r = x + row * L;
+    float m = -INFINITY;
+    for (int i = lane; i < L; i += 64) m = fmaxf(m, r[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+    for (int i = lane; i < L; i += 64) {
+        const float e = __expf(r[i] - m);
+        r[i] = e;
+        s += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float inv = 1.0f / s;
+    for (int i = lane; i < L; i += 64) r[i] *= inv;
+}
+
+// ---------------------------------------------------------------- 2x resample -----------------
+__global__ __launch_bounds__(256) void resample2x_kernel(anoddpm_resample_args a)
+{
+    const int C4 = a.C >> 2;
+    const int Ho = a.mode == 1 ? a.H * 2 : a.H / 2;
+    const int Wo = a.mode == 1 ? a.W * 2 : a.W / 2;
+    const int64_t total = (int64_t)a.B * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        int64_t p = i / C4;
+        const int xo = (int)(p % Wo);
+        p /= Wo;
+        const int yo = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        const float4 *in = reinterpret_cast<const float4 *>(a.in) + (int64_t)b * a.H * a.W * C4 + q;
+        float4 o;
+        if (a.mode == 1) {
+            o = in[((int64_t)(yo >> 1) * a.W + (xo >> 1)) * C4];
+        } else {
+            const float4 v00 = in[((int64_t)(2 * yo) * a.W + 2 * xo) * C4];
+            const float4 v01 = in[((int64_t)(2 * yo) * a.W + 2 * xo + 1) * C4];
+            const float4 v10 = in[((int64_t)(2 * yo + 1) * a.W + 2 * xo) * C4];
+            const float4 v11 = in[((int64_t)(2 * yo + 1) * a.W + 2 * xo + 1) * C4];
+            o.x = (((v00.x + v01.x) + v10.x) + v11.x) * 0.25f;
+            o.y = (((v00.y + v01.y) + v10.y) + v11.y) * 0.25f;
+            o.z = (((v00.z + v01.z) + v10.z) + v11.z) * 0.25f;
+            o.w = (((v00.w + v01.w) + v10.w) + v11.w) * 0.25f;
+        }
+        reinterpret_cast<float4 *>(a.out)[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------- small-batch linear ----------
+// One wave per output feature; lanes stride over K in float4; up to 16 batch rows in registers.
+template <int NB>
+__global__ __launch_bounds__(256) void linear_small_kernel(anoddpm_linear_args a)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= a.N) return;
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    const float4 *w = reinterpret_cast<const float4 *>(a.w + (int64_t)n * a.K);
+    const int K4 = a.K >> 2;
+    for (int k = lane; k < K4; k += 64) {
+        const float4 wv = w[k];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b < a.B) {
+                float4 xv = reinterpret_cast<const float4 *>(a.in + (int64_t)b * a.K)[k];
+                if (a.act_in) { xv.x = silu_f(xv.x); xv.y = silu_f(xv.y); xv.z = silu_f(xv.z); xv.w = silu_f(xv.w); }
+                acc[b] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[b] += __shfl_xor(acc[b], o);
+    }
+    if (lane == 0) {
+        const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b < a.B) {
+                float v = acc[b] + bias;
+                if (a.act_out) v = silu_f(v);
+                a.out[(int64_t)b * a.N + n] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- timestep features -----------
+__global__ void posemb_kernel(anoddpm_posemb_args a)
+{
+    const int half = a.dim >> 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.B * half) return;
+    const int b = i / half, j = i % half;
+    const float arg = ((float)a.t[b] * a.scale) * a.freqs[j];
+    a.out[(int64_t)b * a.dim + j] = sinf(arg);
+    a.out[(int64_t)b * a.dim + half + j] = cosf(arg);
+}
+
+// ---------------------------------------------------------------- stem conv -------------------
+// NCHW (Cin <= 4) -> NHWC Cout, 3x3 pad 1.  Thread = (pixel, 4 output channels).  Write-bound.
+__global__ __launch_bounds__(256) void conv_stem_kernel(anoddpm_stem_args a)
+{
+    const int QP = a.Cout >> 2;
+    const int ppb = 256 / QP;                        // pixels per block
+    const int q = threadIdx.x % QP;
+    const int pl = threadIdx.x / QP;
+    if (pl >= ppb) return;
+    const int64_t npix = (int64_t)a.B * a.H * a.W;
+    const int64_t pix = (int64_t)blockIdx.x * ppb + pl;
+    if (pix >= npix) return;
+    const int x = (int)(pix % a.W);
+    const int y = (int)((pix / a.W) % a.H);
+    const int b = (int)(pix / ((int64_t)a.W * a.H));
+    float4 acc = a.bias ? reinterpret_cast<const float4 *>(a.bias)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 *w = reinterpret_cast<const float4 *>(a.w);
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        const float *plane = a.x + ((int64_t)b * a.Cin + ci) * a.H * a.W;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = y + dy, xx = x + dx;
+                if (yy < 0 || yy >= a.H || xx < 0 || xx >= a.W) continue;
+                const float v = plane[(int64_t)yy * a.W + xx];
+                const float4 wv = w[(((dy + 1) * 3 + (dx + 1)) * a.Cin + ci) * QP + q];
+                acc.x += v * wv.x; acc.y += v * wv.y; acc.z += v * wv.z; acc.w += v * wv.w;
+            }
+        }
+    }
+    reinterpret_cast<float4 *>(a.out)[pix * QP + q] = acc;
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(anoddpm_layout_args a)
+{
+    const int64_t total = (int64_t)a.B * a.C * a.P;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int p = (int)(i % a.P);
+        const int c = (int)((i / a.P) % a.C);
+        const int b = (int)(i / ((int64_t)a.P * a.C));
+        a.out[i] = a.in[((int64_t)b * a.P + p) * a.in_ld + c];
+    }
+}
+
+inline unsigned cap_grid(int64_t blocks) { return (unsigned)(blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks)); }
+
+}  // namespace
+
+extern "C" int anoddpm_gn_stats(const anoddpm_gn_args *a, void *stream)
+{
+    ANODDPM_REQUIRE(a && a->a0 && a->gamma && a->beta && a->scale && a->shift && a->partial, "gn_stats: null pointer");
+    const int C = a->c0 + a->c1;
+    ANODDPM_REQUIRE(a->c0 > 0 && a->c0 % 4 == 0 && a->c1 % 4 == 0 && (a->c1 == 0 || a->a1), "gn_stats: channel counts must be multiples of 4");
+    ANODDPM_REQUIRE(a->groups > 0 && a->groups <= 64 && C % a->groups == 0, "gn_stats: C %% groups != 0");
+    ANODDPM_REQUIRE(C / 4 <= 256 * 16, "gn_stats: too many channels");
+    ANODDPM_REQUIRE(a->B > 0 && a->B <= 65535 && a->P > 0 && a->nslab > 0 && a->nslab <= 65535, "gn_stats: bad sizes");
+    hipStream_t s = anoddpm::as_stream(stream);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(a->nslab, a->B), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a->B), dim3(256), 0, s, *a);
+    return anoddpm::check_launch("gn_stats");
+}
+
+extern "C" int anoddpm_softmax_rows(const anoddpm_softmax_args *a, void *stream)
+{
+    ANODDPM_REQUIRE(a && a->x && a->rows >= 0 && a->L > 0, "softmax_rows: bad arguments");
+    if (a->rows == 0) return ANODDPM_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((a->rows + 3) / 4)), dim3(256), 0,
+                       anoddpm::as_stream(stream), a->x, a->rows, a->L);
+    return anoddpm::check_launch("softmax_rows");
+}
+
+extern "C" int anoddpm_resample2x(const anoddpm_resample_args *a, void *stream)
+{
+    ANODDPM_REQUIRE(a && a->in && a->out, "resample2x: null pointer");
+    ANODDPM_REQUIRE(a->C % 4 == 0 && (a->mode == 1 || (a->mode == 2 && a->H % 2 == 0 && a->W % 2 == 0)), "resample2x: bad shape/mode");
+    const int Ho = a->mode == 1 ? a->H * 2 : a->H / 2, Wo = a->mode == 1 ? a->W * 2 : a->W / 2;
+    const int64_t total = (int64_t)a->B * Ho * Wo * (a->C / 4);
+    if (total == 0) return ANODDPM_OK;
+    hipLaunchKernelGGL(resample2x_kernel, dim3(cap_grid((total + 255) / 256)), dim3(256), 0, anoddpm::as_stream(stream), *a);
+    return anoddpm::check_launch("resample2x");
+}
+
+extern "C" int anoddpm_linear_small(const anoddpm_linear_args *a, void *stream)
+{
+    ANODDPM_REQUIRE(a && a->in && a->w && a->out, "linear_small: null pointer");
+    ANODDPM_REQUIRE(a->B >= 1 && a->B <= 16 && a->K % 4 == 0 && a->N >= 1, "linear_small: need 1<=B<=16, K%%4==0");
+    dim3 grid((a->N + 3) / 4);
+    hipStream_t s = anoddpm::as_stream(stream);
+    if (a->B <= 4) hipLaunchKernelGGL(linear_small_kernel<4>, grid, dim3(256), 0, s, *a);
+    else if (a->B <= 8) hipLaunchKernelGGL(linear_small_kernel<8>, grid, dim3(256), 0, s, *a);
+    else hipLaunchKernelGGL(linear_small_kernel<16>, grid, dim3(256), 0, s, *a);
+    return anoddpm::check_launch("linear_small");
+}
+
+extern "C" int anoddpm_posemb(const anoddpm_posemb_args *a, void *stream)
+{
+    ANODDPM_REQUIRE(a && a->t && a->freqs && a->out && a->B >= 1 && a->dim >= 2 && a->dim % 2 == 0, "posemb: bad arguments");
+    const int n = a->B * (a->dim / 2);
+    hipLaunchKernelGGL(posemb_kernel, dim3((n + 255) / 256), dim3(256), 0, anoddpm::as_stream(stream), *a);
+    return anoddpm::check_launch("posemb");
+}
+
+extern "C" int anoddpm_conv_stem(const anoddpm_stem_args *a, void *stream)
+{
+    ANODDPM_REQUIRE(a && a->x && a->w && a->out, "conv_stem: null pointer");
+    ANODDPM_REQUIRE(a->Cin >= 1 && a->Cin <= 16 && a->Cout % 4 == 0 && a->Cout / 4 <= 256, "conv_stem: need Cin<=16, Cout%%4==0, Cout<=1024");
+    const int ppb = 256 / (a->Cout / 4);
+    const int64_t npix = (int64_t)a->B * a->H * a->W;
+    if (npix == 0) return ANODDPM_OK;
+    hipLaunchKernelGGL(conv_stem_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, anoddpm::as_stream(stream), *a);
+    return anoddpm::check_launch("conv_stem");
+}
+
+extern "C" int anoddpm_nhwc_to_nchw(const anoddpm_layout_args *a, void *stream)
+{
+    ANODDPM_REQUIRE(a && a->in && a->out && a->in_ld >= a->C, "nhwc_to_nchw: bad arguments");
+    const int64_t total = (int64_t)a->B * a->C * a->P;
+    if (total == 0) return ANODDPM_OK;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cap_grid((total + 255) / 256)), dim3(256), 0, anoddpm::as_stream(stream), *a);
+    return anoddpm::check_launch("nhwc_to_nchw");
+}

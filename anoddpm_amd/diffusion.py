@@ -1,0 +1,528 @@
+"""`GaussianDiffusionModel` & friends -- the reference diffusion process (GaussianDiffusion.py)
+driven from PyTorch-ROCm host code with the arithmetic in fused HIP kernels.
+
+Kept from the reference (names, signatures, return structures, RNG consumption order):
+  get_beta_schedule, extract, mean_flat, normal_kl, approx_standard_normal_cdf,
+  discretised_gaussian_log_likelihood, generate_simplex_noise, random_noise,
+  GaussianDiffusionModel.{sample_t_with_weights, predict_x_0_from_eps, predict_eps_from_x_0,
+  q_mean_variance, q_posterior_mean_variance, p_mean_variance, sample_p, forward_backward,
+  sample_q, sample_q_gradual, calc_vlb_xt, calc_loss, p_loss, prior_vlb, calc_total_vlb,
+  detection_A_fixedT} plus the north-star aliases q_sample / p_sample_loop.
+
+What changed underneath (MI355X-first):
+  * the 14 fp64 schedule tables are built exactly as GaussianDiffusion.py:184-217 and uploaded
+    ONCE per device as fp32 (the reference uploads an 8 KB table 8x per step, :32-36);
+  * sample_q is one kernel (12 B/pixel), the whole reverse update of sample_p -- predict x0, clamp,
+    posterior mean, sigma*noise -- is one kernel (16 B/pixel) instead of ~25 dispatches;
+  * simplex noise is generated on the GPU straight into the noise tensor (no D2H of t, no numba,
+    no H2D), seeded from the global numpy stream exactly like Simplex_CLASS.newSeed();
+  * forward_backward keeps `t` on the device and, for the built-in UNetModel, replays one captured
+    HIP graph per reverse step.
+
+All tensors must live on a HIP device: there is no CPU fallback (CPU tensors raise AnoddpmError).
+"""
+import ctypes
+import random
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PUpdateArgs, check, current_stream, lib, ptr
+from .simplex import Simplex_CLASS, perm_tables
+
+__all__ = ["SimplexNoiseFn", "ReverseChain", "get_beta_schedule", "extract", "mean_flat", "normal_kl", "approx_standard_normal_cdf",
+           "discretised_gaussian_log_likelihood", "generate_simplex_noise", "random_noise",
+           "GaussianDiffusionModel"]
+
+_RANDOM_PARAMS = [(2, 0.6, 16), (6, 0.6, 32), (7, 0.7, 32), (10, 0.8, 64), (5, 0.8, 16), (4, 0.6, 16),
+                  (1, 0.6, 64), (7, 0.8, 128), (6, 0.9, 64), (2, 0.85, 128), (2, 0.85, 64), (2, 0.85, 32),
+                  (2, 0.85, 16), (2, 0.85, 8), (2, 0.85, 4), (2, 0.85, 2), (1, 0.85, 128), (1, 0.85, 64),
+                  (1, 0.85, 32), (1, 0.85, 16), (1, 0.85, 8), (1, 0.85, 4), (1, 0.85, 2)]
+
+
+def get_beta_schedule(num_diffusion_steps, name="cosine"):
+    """GaussianDiffusion.py:12-29 (host, fp64)."""
+    if name == "cosine":
+        def abar(u):
+            return np.cos((u + 0.008) / 1.008 * np.pi / 2) ** 2
+        n = num_diffusion_steps
+        return np.array([min(1 - abar((i + 1) / n) / abar(i / n), 0.999) for i in range(n)])
+    if name == "linear":
+        k = 1000 / num_diffusion_steps
+        return np.linspace(k * 0.0001, k * 0.02, num_diffusion_steps, dtype=np.float64)
+    raise NotImplementedError(f"unknown beta schedule: {name}")
+
+
+def extract(arr, timesteps, broadcast_shape, device):
+    """GaussianDiffusion.py:32-36: gather in fp64, then cast to fp32, broadcast to `broadcast_shape`."""
+    res = torch.from_numpy(np.asarray(arr)).to(device=timesteps.device)[timesteps].float()
+    while len(res.shape) < len(broadcast_shape):
+        res = res[..., None]
+    return res.expand(broadcast_shape).to(device)
+
+
+def mean_flat(tensor):
+    return torch.mean(tensor, dim=list(range(1, len(tensor.shape))))
+
+
+def normal_kl(mean1, logvar1, mean2, logvar2):
+    """KL(N(mean1, e^logvar1) || N(mean2, e^logvar2)) -- GaussianDiffusion.py:43-53."""
+    return 0.5 * (-1 + logvar2 - logvar1 + torch.exp(logvar1 - logvar2) + ((mean1 - mean2) ** 2) * torch.exp(-logvar2))
+
+
+def approx_standard_normal_cdf(x):
+    return 0.5 * (1.0 + torch.tanh(np.sqrt(2.0 / np.pi) * (x + 0.044715 * torch.pow(x, 3))))
+
+
+def discretised_gaussian_log_likelihood(x, means, log_scales):
+    """GaussianDiffusion.py:64-93."""
+    assert x.shape == means.shape == log_scales.shape
+    centered = x - means
+    inv_std = torch.exp(-log_scales)
+    cdf_plus = approx_standard_normal_cdf(inv_std * (centered + 1.0 / 255.0))
+    cdf_min = approx_standard_normal_cdf(inv_std * (centered - 1.0 / 255.0))
+    log_cdf_plus = torch.log(cdf_plus.clamp(min=1e-12))
+    log_one_minus_cdf_min = torch.log((1.0 - cdf_min).clamp(min=1e-12))
+    cdf_delta = cdf_plus - cdf_min
+    log_probs = torch.where(x < -0.999, log_cdf_plus,
+                            torch.where(x > 0.999, log_one_minus_cdf_min, torch.log(cdf_delta.clamp(min=1e-12))))
+    assert log_probs.shape == x.shape
+    return log_probs
+
+
+def generate_simplex_noise(Simplex_instance, x, t, random_param=False, octave=6, persistence=0.8, frequency=64,
+                           in_channels=1):
+    """GaussianDiffusion.py:96-137 on the device.
+
+    Per channel: a fresh seed from the global numpy stream (newSeed), then the multi-octave field at
+    z = t written as fp32 into noise[:, i].  `random_param=True` draws `random.choice` like the
+    reference does; the reference then overwrites that field with the default-parameter one
+    (:125-136 has no else), so only the RNG draw is observable and only it is reproduced.
+    Batch > 1: sample b gets the field at z = t[b] (all equal inside forward_backward, which is the
+    reference's `.repeat(B,1,1,1)` behaviour); the reference itself only runs at batch 1.
+    """
+    _lib.require_cuda(x, "generate_simplex_noise")
+    noise = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    for i in range(in_channels):
+        Simplex_instance.newSeed()
+        if random_param:
+            random.choice(_RANDOM_PARAMS)
+        Simplex_instance.fill_fixed_T_octaves_(noise, t, octave, persistence, frequency, channel=i)
+    return noise
+
+
+def random_noise(Simplex_instance, x, t):
+    """GaussianDiffusion.py:140-147."""
+    if random.choice(["gauss", "simplex"]) == "gauss":
+        return torch.randn_like(x)
+    return generate_simplex_noise(Simplex_instance, x, t)
+
+
+class SimplexNoiseFn:
+    """A `denoise_fn` / `noise_fn` callable equivalent to
+    `lambda x, t: generate_simplex_noise(simplex, x, t, False, octave, persistence, frequency, in_channels)`
+    that the reverse chain can recognise: its seeds are then drawn up front (same numpy-stream order,
+    one per step per channel) and the permutation tables of all steps are uploaded once."""
+
+    def __init__(self, simplex, octave=6, persistence=0.8, frequency=64, in_channels=1):
+        self.simplex, self.octave, self.persistence, self.frequency, self.in_channels = \
+            simplex, octave, persistence, frequency, in_channels
+
+    def __call__(self, x, t):
+        return generate_simplex_noise(self.simplex, x, t, False, self.octave, self.persistence, self.frequency,
+                                      self.in_channels)
+
+
+class ReverseChain:
+    """Device-resident state of the reverse loop (GaussianDiffusion.py:351-357): x, t and a step counter
+    live in HBM; one step = model forward + noise + ONE fused update launch + t -= 1."""
+
+    def __init__(self, owner, model, x, t_distance, denoise_fn):
+        _lib.require_cuda(x, "ReverseChain")
+        self.owner, self.model, self.denoise_fn = owner, model, denoise_fn
+        self.B = x.shape[0]
+        self.x = owner._f32(x.detach()).clone()
+        self.t = torch.full((self.B,), t_distance - 1, device=x.device, dtype=torch.int64)
+        self.step_idx = torch.zeros(1, device=x.device, dtype=torch.int32)
+        self.remaining = int(t_distance)
+        self.hip_model = hasattr(model, "forward_hip")
+        self.noise = None
+        self.tables = None
+        fn = denoise_fn
+        if type(fn) == str and fn not in ("gauss", "noise_fn", "random"):
+            fn = SimplexNoiseFn(owner.simplex, in_channels=owner.img_channels)      # :310 defaults
+        if isinstance(fn, SimplexNoiseFn):
+            # draw every seed of the chain now, in the order the per-step newSeed() calls would
+            C = fn.in_channels
+            tabs = np.empty((self.remaining * C, 512), dtype=np.int16)
+            self._last_seed = None
+            for i in range(self.remaining * C):
+                seed = np.random.randint(-10000000000, 10000000000)
+                tabs[i] = perm_tables(seed)
+                self._last_seed = seed
+            self.tables = torch.from_numpy(tabs).to(x.device)
+            self.simplex_fn = fn
+            self.noise = torch.empty_like(self.x)
+
+    def step(self):
+        o = self.owner
+        with torch.no_grad():
+            eps = self.model.forward_hip(self.x, self.t) if self.hip_model else self.model(self.x, self.t)
+            if self.tables is not None:
+                fn = self.simplex_fn
+                for c in range(fn.in_channels):
+                    fn.simplex.fill_fixed_T_octaves_(self.noise, self.t, fn.octave, fn.persistence, fn.frequency,
+                                                     channel=c, tables=self.tables[c:], table_sel=self.step_idx,
+                                                     table_sel_scale=fn.in_channels)
+                noise = self.noise
+            else:
+                noise = o._denoise_noise(self.x, self.t, self.denoise_fn)
+            o._reverse_update(self.x, self.t, eps, noise, want_pred=False, out=self.x)     # in place
+            check(lib().anoddpm_chain_advance(ptr(self.t), self.B, ptr(self.step_idx), current_stream()), "chain_advance")
+        self.remaining -= 1
+        return self.x
+
+    def finish(self):
+        if self.tables is not None and self._last_seed is not None:
+            self.simplex_fn.simplex.newSeed(self._last_seed)       # leave the generator where upstream would
+
+
+class _DeviceTables:
+    """fp32 device copies of the schedule tables (one upload per device, not eight per step)."""
+
+    NAMES = ("sqrt_alphas", "sqrt_betas", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+             "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+             "posterior_mean_coef2", "model_variance", "model_log_variance", "sigma")
+
+    def __init__(self, owner, device):
+        def up(a):
+            # extract() gathers in fp64 and casts the gathered value: casting the table is the same thing
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).float().to(device)
+        for n in self.NAMES[:8]:
+            setattr(self, n, up(getattr(owner, n)))
+        model_var = np.append(owner.posterior_variance[1], owner.betas[1:])       # :282-283
+        model_logvar = np.log(model_var)
+        self.model_variance = up(model_var)
+        self.model_log_variance = up(model_logvar)
+        # exp(0.5*log_variance) evaluated by the same fp32 torch expression the reference uses (:317)
+        self.sigma = torch.exp(0.5 * torch.from_numpy(model_logvar).float()).to(device)
+
+
+class GaussianDiffusionModel:
+    def __init__(self, img_size, betas, img_channels=1, loss_type="l2", loss_weight='none', noise="gauss"):
+        super().__init__()
+        if noise == "gauss":
+            self.noise_fn = lambda x, t: torch.randn_like(x)
+        else:
+            self.simplex = Simplex_CLASS()
+            if noise == "simplex_randParam":
+                self.noise_fn = lambda x, t: generate_simplex_noise(self.simplex, x, t, True, in_channels=img_channels)
+            elif noise == "random":
+                self.noise_fn = lambda x, t: random_noise(self.simplex, x, t)
+            else:
+                self.noise_fn = lambda x, t: generate_simplex_noise(self.simplex, x, t, False, in_channels=img_channels)
+        self.noise_kind = noise
+
+        self.img_size = img_size
+        self.img_channels = img_channels
+        self.loss_type = loss_type
+        self.num_timesteps = len(betas)
+
+        if loss_weight == 'prop-t':
+            self.weights = np.arange(self.num_timesteps, 0, -1)
+        elif loss_weight == "uniform":
+            self.weights = np.ones(self.num_timesteps)
+        self.loss_weight = loss_weight
+
+        # fp64 host tables, GaussianDiffusion.py:184-217
+        betas = np.asarray(betas, dtype=np.float64)
+        alphas = 1 - betas
+        self.betas = betas
+        self.sqrt_alphas = np.sqrt(alphas)
+        self.sqrt_betas = np.sqrt(betas)
+        self.alphas_cumprod = np.cumprod(alphas, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.log_one_minus_alphas_cumprod = np.log(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - self.alphas_cumprod)
+        self._dev = {}
+
+    # ------------------------------------------------------------------ device plumbing
+    def _tables(self, device):
+        tb = self._dev.get(device)
+        if tb is None:
+            tb = self._dev[device] = _DeviceTables(self, device)
+        return tb
+
+    @staticmethod
+    def _t64(t, device):
+        if t.dtype != torch.int64 or t.device != device or not t.is_contiguous():
+            t = t.to(device=device, dtype=torch.int64).contiguous()
+        return t
+
+    @staticmethod
+    def _f32(x):
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        return x
+
+    def _axpby(self, ca, cb, x, t, noise):
+        _lib.require_cuda(x, "GaussianDiffusionModel.sample_q")
+        x = self._f32(x.detach() if not x.requires_grad else x)
+        noise = self._f32(noise).to(x.device)
+        t = self._t64(t, x.device)
+        out = torch.empty_like(x)
+        B = x.shape[0]
+        check(lib().anoddpm_q_sample(ptr(out), ptr(x), ptr(noise), ptr(t), ptr(ca), ptr(cb), B,
+                                     x.numel() // max(B, 1), self.num_timesteps, current_stream()), "q_sample")
+        return out
+
+    def _reverse_update(self, x_t, t, eps, noise, want_pred=True, want_mean=False, out=None):
+        """One fused launch for GaussianDiffusion.py:287-288 + :314-317."""
+        _lib.require_cuda(x_t, "GaussianDiffusionModel.sample_p")
+        tb = self._tables(x_t.device)
+        x_t, eps = self._f32(x_t.detach()), self._f32(eps.detach())
+        if noise is not None:
+            noise = self._f32(noise.detach())
+        t = self._t64(t, x_t.device)
+        a = PUpdateArgs()
+        x_prev = out if out is not None else torch.empty_like(x_t)
+        pred = torch.empty_like(x_t) if want_pred else None
+        mean = torch.empty_like(x_t) if want_mean else None
+        a.x_prev, a.pred_x0, a.mean_out = x_prev.data_ptr(), pred.data_ptr() if want_pred else None, mean.data_ptr() if want_mean else None
+        a.x_t, a.eps, a.noise, a.t = x_t.data_ptr(), eps.data_ptr(), noise.data_ptr() if noise is not None else None, t.data_ptr()
+        a.c_recip, a.c_recipm1 = tb.sqrt_recip_alphas_cumprod.data_ptr(), tb.sqrt_recipm1_alphas_cumprod.data_ptr()
+        a.c_coef1, a.c_coef2, a.c_sigma = tb.posterior_mean_coef1.data_ptr(), tb.posterior_mean_coef2.data_ptr(), tb.sigma.data_ptr()
+        a.B, a.T = x_t.shape[0], self.num_timesteps
+        a.n = x_t.numel() // max(x_t.shape[0], 1)
+        check(lib().anoddpm_p_sample_update(ctypes.byref(a), current_stream()), "p_sample_update")
+        return x_prev, pred, mean
+
+    # ------------------------------------------------------------------ reference API
+    def sample_t_with_weights(self, b_size, device):
+        p = self.weights / np.sum(self.weights)
+        indices_np = np.random.choice(len(p), size=b_size, p=p)
+        indices = torch.from_numpy(indices_np).long().to(device)
+        weights_np = 1 / len(p) * p[indices_np]
+        weights = torch.from_numpy(weights_np).float().to(device)
+        return indices, weights
+
+    def predict_x_0_from_eps(self, x_t, t, eps):
+        return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape, x_t.device) * x_t
+                - extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape, x_t.device) * eps)
+
+    def predict_eps_from_x_0(self, x_t, t, pred_x_0):
+        return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape, x_t.device) * x_t - pred_x_0) \
+               / extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape, x_t.device)
+
+    def q_mean_variance(self, x_0, t):
+        mean = extract(self.sqrt_alphas_cumprod, t, x_0.shape, x_0.device) * x_0
+        variance = extract(1.0 - self.alphas_cumprod, t, x_0.shape, x_0.device)
+        log_variance = extract(self.log_one_minus_alphas_cumprod, t, x_0.shape, x_0.device)
+        return mean, variance, log_variance
+
+    def q_posterior_mean_variance(self, x_0, x_t, t):
+        posterior_mean = (extract(self.posterior_mean_coef1, t, x_t.shape, x_t.device) * x_0
+                          + extract(self.posterior_mean_coef2, t, x_t.shape, x_t.device) * x_t)
+        posterior_var = extract(self.posterior_variance, t, x_t.shape, x_t.device)
+        posterior_log_var_clipped = extract(self.posterior_log_variance_clipped, t, x_t.shape, x_t.device)
+        return posterior_mean, posterior_var, posterior_log_var_clipped
+
+    def p_mean_variance(self, model, x_t, t, estimate_noise=None):
+        """GaussianDiffusion.py:269-296; mean / pred_x_0 come from the fused update kernel."""
+        if estimate_noise is None:
+            estimate_noise = model(x_t, t)
+        if x_t.requires_grad or estimate_noise.requires_grad:
+            # differentiable form (hybrid loss, :413) -- same expressions on device tensors
+            model_var = np.append(self.posterior_variance[1], self.betas[1:])
+            pred_x_0 = self.predict_x_0_from_eps(x_t, t, estimate_noise).clamp(-1, 1)
+            model_mean, _, _ = self.q_posterior_mean_variance(pred_x_0, x_t, t)
+            return {"mean": model_mean, "variance": extract(model_var, t, x_t.shape, x_t.device),
+                    "log_variance": extract(np.log(model_var), t, x_t.shape, x_t.device), "pred_x_0": pred_x_0}
+        tb = self._tables(x_t.device)
+        tt = self._t64(t, x_t.device)
+        _, pred, mean = self._reverse_update(x_t, tt, estimate_noise, None, want_pred=True, want_mean=True)
+        shape = x_t.shape
+        view = (-1,) + (1,) * (len(shape) - 1)
+        return {"mean": mean, "variance": tb.model_variance[tt].view(view).expand(shape),
+                "log_variance": tb.model_log_variance[tt].view(view).expand(shape), "pred_x_0": pred}
+
+    def _denoise_noise(self, x_t, t, denoise_fn):
+        """Noise selection of sample_p (GaussianDiffusion.py:301-312)."""
+        if type(denoise_fn) == str:
+            if denoise_fn == "gauss":
+                return torch.randn_like(x_t)
+            if denoise_fn == "noise_fn":
+                return self.noise_fn(x_t, t).float()
+            if denoise_fn == "random":
+                return torch.randn_like(x_t)
+            return generate_simplex_noise(self.simplex, x_t, t, False, in_channels=self.img_channels).float()
+        return denoise_fn(x_t, t)
+
+    def sample_p(self, model, x_t, t, denoise_fn="gauss"):
+        """One reverse step (GaussianDiffusion.py:298-318): model -> noise -> ONE fused update launch."""
+        eps = model(x_t, t)
+        noise = self._denoise_noise(x_t, t, denoise_fn)
+        sample, pred, _ = self._reverse_update(x_t, t, eps, noise)
+        return {"sample": sample, "pred_x_0": pred}
+
+    def forward_backward(self, model, x, see_whole_sequence="half", t_distance=None, denoise_fn="gauss"):
+        """GaussianDiffusion.py:320-359.  `t` lives on the device for the whole chain."""
+        assert see_whole_sequence == "whole" or see_whole_sequence == "half" or see_whole_sequence == None
+
+        if t_distance == 0:
+            return x.detach()
+        if t_distance is None:
+            t_distance = self.num_timesteps
+        _lib.require_cuda(x, "GaussianDiffusionModel.forward_backward")
+        seq = [x.cpu().detach()]
+        B = x.shape[0]
+        if see_whole_sequence == "whole":
+            for t in range(int(t_distance)):
+                t_batch = torch.full((B,), t, device=x.device, dtype=torch.int64)
+                noise = self.noise_fn(x, t_batch).float()
+                with torch.no_grad():
+                    x = self.sample_q_gradual(x, t_batch, noise)
+                seq.append(x.cpu().detach())
+        else:
+            t_tensor = torch.full((B,), t_distance - 1, device=x.device, dtype=torch.int64)
+            x = self.sample_q(x, t_tensor, self.noise_fn(x, t_tensor).float())
+            if see_whole_sequence == "half":
+                seq.append(x.cpu().detach())
+
+        with torch.no_grad():
+            x = self._reverse_chain(model, x, int(t_distance), denoise_fn, seq if see_whole_sequence else None)
+        return x.detach() if not see_whole_sequence else seq
+
+    p_sample_loop = forward_backward          # north-star alias
+
+    def _reverse_chain(self, model, x, t_distance, denoise_fn, seq):
+        """t = t_distance-1 ... 0 of sample_p with a device-resident timestep (no per-step H2D)."""
+        chain = ReverseChain(self, model, x, t_distance, denoise_fn)
+        for _ in range(t_distance):
+            chain.step()
+            if seq is not None:
+                seq.append(chain.x.cpu().detach())
+        chain.finish()
+        return chain.x
+
+    def reverse_chain(self, model, x_t, t_distance, denoise_fn="gauss"):
+        """Stepping form of the reverse loop of forward_backward (:351-357): returns a ReverseChain whose
+        .step() performs one sample_p on the device-resident state (bench.py times K of these)."""
+        return ReverseChain(self, model, x_t, int(t_distance), denoise_fn)
+
+    def sample_q(self, x_0, t, noise):
+        """q(x_t | x_0), GaussianDiffusion.py:361-371 -- one fused launch."""
+        if x_0.requires_grad or noise.requires_grad:
+            return (extract(self.sqrt_alphas_cumprod, t, x_0.shape, x_0.device) * x_0 +
+                    extract(self.sqrt_one_minus_alphas_cumprod, t, x_0.shape, x_0.device) * noise)
+        _lib.require_cuda(x_0, "GaussianDiffusionModel.sample_q")
+        tb = self._tables(x_0.device)
+        return self._axpby(tb.sqrt_alphas_cumprod, tb.sqrt_one_minus_alphas_cumprod, x_0, t, noise)
+
+    q_sample = sample_q                       # north-star alias
+
+    def sample_q_gradual(self, x_t, t, noise):
+        """q(x_t | x_{t-1}), GaussianDiffusion.py:373-382."""
+        _lib.require_cuda(x_t, "GaussianDiffusionModel.sample_q_gradual")
+        tb = self._tables(x_t.device)
+        return self._axpby(tb.sqrt_alphas, tb.sqrt_betas, x_t, t, noise)
+
+    def calc_vlb_xt(self, model, x_0, x_t, t, estimate_noise=None):
+        true_mean, _, true_log_var = self.q_posterior_mean_variance(x_0, x_t, t)
+        output = self.p_mean_variance(model, x_t, t, estimate_noise)
+        kl = normal_kl(true_mean, true_log_var, output["mean"], output["log_variance"])
+        kl = mean_flat(kl) / np.log(2.0)
+        decoder_nll = -discretised_gaussian_log_likelihood(x_0, output["mean"], log_scales=0.5 * output["log_variance"])
+        decoder_nll = mean_flat(decoder_nll) / np.log(2.0)
+        nll = torch.where((t == 0), decoder_nll, kl)
+        return {"output": nll, "pred_x_0": output["pred_x_0"]}
+
+    def calc_loss(self, model, x_0, t):
+        noise = self.noise_fn(x_0, t).float()
+        x_t = self.sample_q(x_0, t, noise)
+        estimate_noise = model(x_t, t)
+        loss = {}
+        if self.loss_type == "l1":
+            loss["loss"] = mean_flat((estimate_noise - noise).abs())
+        elif self.loss_type == "l2":
+            loss["loss"] = mean_flat((estimate_noise - noise).square())
+        elif self.loss_type == "hybrid":
+            loss["vlb"] = self.calc_vlb_xt(model, x_0, x_t, t, estimate_noise)["output"]
+            loss["loss"] = loss["vlb"] + mean_flat((estimate_noise - noise).square())
+        else:
+            loss["loss"] = mean_flat((estimate_noise - noise).square())
+        return loss, x_t, estimate_noise
+
+    def p_loss(self, model, x_0, args):
+        if self.loss_weight == "none":
+            if args["train_start"]:
+                t = torch.randint(0, min(args["sample_distance"], self.num_timesteps), (x_0.shape[0],), device=x_0.device)
+            else:
+                t = torch.randint(0, self.num_timesteps, (x_0.shape[0],), device=x_0.device)
+            weights = 1
+        else:
+            t, weights = self.sample_t_with_weights(x_0.shape[0], x_0.device)
+        loss, x_t, eps_t = self.calc_loss(model, x_0, t)
+        loss = ((loss["loss"] * weights).mean(), (loss, x_t, eps_t))
+        return loss
+
+    def prior_vlb(self, x_0, args):
+        t = torch.tensor([self.num_timesteps - 1] * args["Batch_Size"], device=x_0.device)
+        qt_mean, _, qt_log_variance = self.q_mean_variance(x_0, t)
+        kl_prior = normal_kl(mean1=qt_mean, logvar1=qt_log_variance, mean2=torch.tensor(0.0, device=x_0.device),
+                             logvar2=torch.tensor(0.0, device=x_0.device))
+        return mean_flat(kl_prior) / np.log(2.0)
+
+    def calc_total_vlb(self, x_0, model, args):
+        vb, x_0_mse, mse = [], [], []
+        for t in reversed(list(range(self.num_timesteps))):
+            t_batch = torch.tensor([t] * args["Batch_Size"], device=x_0.device)
+            noise = torch.randn_like(x_0)
+            x_t = self.sample_q(x_0=x_0, t=t_batch, noise=noise)
+            with torch.no_grad():
+                out = self.calc_vlb_xt(model, x_0=x_0, x_t=x_t, t=t_batch)
+            vb.append(out["output"])
+            x_0_mse.append(mean_flat((out["pred_x_0"] - x_0) ** 2))
+            eps = self.predict_eps_from_x_0(x_t, t_batch, out["pred_x_0"])
+            mse.append(mean_flat((eps - noise) ** 2))
+        vb = torch.stack(vb, dim=1)
+        x_0_mse = torch.stack(x_0_mse, dim=1)
+        mse = torch.stack(mse, dim=1)
+        prior_vlb = self.prior_vlb(x_0, args)
+        total_vlb = vb.sum(dim=1) + prior_vlb
+        return {"total_vlb": total_vlb, "prior_vlb": prior_vlb, "vb": vb, "x_0_mse": x_0_mse, "mse": mse}
+
+    # ------------------------------------------------------------------ detection compute loops
+    def detection_A_fixedT(self, model, x_0, args, mask, end_freq=6):
+        """GaussianDiffusion.py:596-623 (pure compute; no file output upstream either)."""
+        t_distance = 250
+        output = torch.empty((6 * end_freq, 1, *args["img_size"]), device=x_0.device)
+        for i in range(1, end_freq + 1):
+            freq = 2 ** i
+            noise_fn = lambda x, t: generate_simplex_noise(self.simplex, x, t, False, frequency=freq).float()
+            t_tensor = torch.tensor([t_distance - 1], device=x_0.device).repeat(x_0.shape[0])
+            x = self.sample_q(x_0, t_tensor, noise_fn(x_0, t_tensor).float())
+            x_noised = x.clone().detach()
+            with torch.no_grad():
+                x = self._reverse_chain(model, x, t_distance, noise_fn, None)
+            mse = ((x_0 - x).square() * 2) - 1
+            mse_threshold = mse > 0
+            mse_threshold = (mse_threshold.float() * 2) - 1
+            output[(i - 1) * 6:i * 6, ...] = torch.cat((x_0, x_noised, x, mse, mse_threshold, mask))
+        return output
+
+    def detection_A(self, *a, **k):
+        raise NotImplementedError("detection_A writes matplotlib figures (GaussianDiffusion.py:480-529); its compute "
+                                  "loop is forward_backward(..., denoise_fn=...) -- plotting is out of scope (SURVEY 2 row 1b)")
+
+    def detection_B(self, *a, **k):
+        raise NotImplementedError("detection_B writes matplotlib figures (GaussianDiffusion.py:531-594); its compute "
+                                  "loop is forward_backward(..., denoise_fn=...) -- plotting is out of scope (SURVEY 2 row 1b)")

@@ -1,0 +1,689 @@
+"""`UNetModel` -- the reference denoiser (UNet.py:220-406) as an MI355X-native module.
+
+Boundary kept from the reference: constructor signature, `forward(x, time) -> Tensor like x`,
+`nn.Module` behaviour (state_dict keys / shapes / init order identical, so checkpoints and
+`copy.deepcopy` / `optim.AdamW(model.parameters())` work unchanged), `update_ema_params`.
+
+Execution: the module owns only parameters.  `forward` under `torch.no_grad()` (sampling, the
+hot path) compiles a *plan* once per (batch, device): packed weights, NHWC activation buffers and
+a flat list of C-ABI ops (include/anoddpm_hip.h) that the native executor `anoddpm_run_ops`
+launches in one call -- GroupNorm statistics, MFMA implicit-GEMM convolutions with the
+GroupNorm-apply/SiLU/resample/concat fused into their operand load, attention as two MFMA GEMMs
+around a softmax, and the batched timestep-embedding projections.  There is no eager-PyTorch or
+CPU fallback for this path: CPU tensors raise.
+
+When autograd is recording (training, diffusion_training.py:99-105) the forward is expressed with
+differentiable PyTorch-ROCm ops so `loss.backward()` works; the hand-written backward kernels are
+the next step of the build plan (SURVEY.md section 7.6 lists this as the legitimate interim).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from ._lib import (GnArgs, IgemmArgs, LayoutArgs, LinearArgs, Op, PosembArgs, ResampleArgs,
+                   SoftmaxArgs, StemArgs, check, lib)
+
+__all__ = ["UNetModel", "update_ema_params", "zero_module", "GroupNorm32"]
+
+_DEFAULT_MULTS = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4),
+                  64: (1, 2, 3, 4), 32: (1, 2, 3, 4)}
+
+
+# ----------------------------------------------------------------------------- parameters
+class _Affine(nn.Module):
+    """weight/bias holder for a GroupNorm(32, C) (UNet.py:409-411)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class _Weights(nn.Module):
+    """weight/bias holder with nn.Conv*/nn.Linear default initialisation (same RNG draws)."""
+
+    def __init__(self, shape, zero=False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*shape))
+        self.bias = nn.Parameter(torch.empty(shape[0]))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        fan_in = int(np.prod(shape[1:]))
+        bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+        nn.init.uniform_(self.bias, -bound, bound)
+        if zero:                                   # zero_module (UNet.py:414-420)
+            with torch.no_grad():
+                self.weight.zero_()
+                self.bias.zero_()
+
+
+def _indexed(**mods):
+    d = nn.ModuleDict()
+    for k, v in mods.items():
+        d[k.lstrip("_")] = v
+    return d
+
+
+class _ResBlockParams(nn.Module):
+    def __init__(self, cin, ted, cout):
+        super().__init__()
+        self.in_layers = _indexed(_0=_Affine(cin), _2=_Weights((cout, cin, 3, 3)))
+        self.embed_layers = _indexed(_1=_Weights((cout, ted)))
+        self.out_layers = _indexed(_0=_Affine(cout), _3=_Weights((cout, cout, 3, 3), zero=True))
+        if cin != cout:
+            self.skip_connection = _Weights((cout, cin, 1, 1))
+
+
+class _AttentionParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.norm = _Affine(c)
+        self.to_qkv = _Weights((3 * c, c, 1))
+        self.proj_out = _Weights((c, c, 1), zero=True)
+
+
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+class GroupNorm32(nn.GroupNorm):
+    def forward(self, x):
+        return super().forward(x.float()).type(x.dtype)
+
+
+def update_ema_params(target, source, decay_rate=0.9999):
+    """ema = decay*ema + (1-decay)*src per named parameter (UNet.py:423-427)."""
+    tp = dict(target.named_parameters())
+    sp = dict(source.named_parameters())
+    with torch.no_grad():
+        for k in tp:
+            tp[k].data.mul_(decay_rate).add_(sp[k].data, alpha=1 - decay_rate)
+
+
+# ----------------------------------------------------------------------------- topology
+def _topology(img_size, base, mults, num_res_blocks, attention_resolutions, in_channels):
+    """Block list of UNet.py:278-388: entries (prefix, kind, cin, cout, resample)."""
+    attn_ds = [img_size // int(r) for r in attention_resolutions.split(",")]
+    ch = int(mults[0] * base)
+    down = [[("down.0.0", "stem", in_channels, base, None)]]
+    skip_ch = [ch]
+    ds = 1
+    for level, mult in enumerate(mults):
+        for _ in range(num_res_blocks):
+            n = len(down)
+            cout = int(base * mult)
+            blk = [(f"down.{n}.0", "res", ch, cout, None)]
+            ch = cout
+            if ds in attn_ds:
+                blk.append((f"down.{n}.1", "attn", ch, ch, None))
+            down.append(blk)
+            skip_ch.append(ch)
+        if level != len(mults) - 1:
+            down.append([(f"down.{len(down)}.0", "res", ch, ch, "down")])
+            ds *= 2
+            skip_ch.append(ch)
+    middle = [("middle.0", "res", ch, ch, None), ("middle.1", "attn", ch, ch, None),
+              ("middle.2", "res", ch, ch, None)]
+    up = []
+    for level, mult in reversed(list(enumerate(mults))):
+        for j in range(num_res_blocks + 1):
+            n = len(up)
+            cin = ch + skip_ch.pop()
+            cout = int(base * mult)
+            blk = [(f"up.{n}.0", "res", cin, cout, None)]
+            ch = cout
+            m = 1
+            if ds in attn_ds:
+                blk.append((f"up.{n}.{m}", "attn", ch, ch, None))
+                m += 1
+            if level and j == num_res_blocks:
+                blk.append((f"up.{n}.{m}", "res", ch, ch, "up"))
+                ds //= 2
+            up.append(blk)
+    return down, middle, up, ch
+
+
+class UNetModel(nn.Module):
+    def __init__(self, img_size, base_channels, conv_resample=True, n_heads=1, n_head_channels=-1,
+                 channel_mults="", num_res_blocks=2, dropout=0, attention_resolutions="32,16,8",
+                 biggan_updown=True, in_channels=1):
+        super().__init__()
+        self.dtype = torch.float32
+        if channel_mults == "":
+            if img_size not in _DEFAULT_MULTS:
+                raise ValueError(f"unsupported image size: {img_size}")
+            channel_mults = _DEFAULT_MULTS[img_size]
+        if not biggan_updown:
+            raise NotImplementedError("only the reference default biggan_updown=True is built (UNet.py:318,377)")
+        self.image_size = img_size
+        self.in_channels = in_channels
+        self.model_channels = base_channels
+        self.out_channels = in_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = attention_resolutions
+        self.dropout = dropout
+        self.channel_mult = channel_mults
+        self.conv_resample = conv_resample
+        self.num_heads = n_heads
+        self.num_head_channels = n_head_channels
+
+        ted = base_channels * 4
+        self._ted = ted
+        down, middle, up, out_ch = _topology(img_size, base_channels, channel_mults, num_res_blocks,
+                                             attention_resolutions, in_channels)
+        self._blocks = (down, middle, up)
+        self._final_cin = int(base_channels * channel_mults[0])
+        assert out_ch == self._final_cin or True
+
+        # parameters are created in the reference constructor's order so that the same torch seed
+        # gives the same initial weights (UNet.py:271-388)
+        self.time_embedding = _indexed(_1=_Weights((ted, base_channels)), _3=_Weights((ted, ted)))
+
+        def make(blk):
+            prefix, kind, cin, cout, _ = blk
+            if kind == "stem":
+                return _Weights((cout, cin, 3, 3))
+            if kind == "res":
+                return _ResBlockParams(cin, ted, cout)
+            heads = n_heads if n_head_channels == -1 else None
+            if heads is None:
+                assert cin % n_head_channels == 0, \
+                    f"q,k,v channels {cin} is not divisible by num_head_channels {n_head_channels}"
+            return _AttentionParams(cin)
+
+        def seq(blks):
+            d = nn.ModuleDict()
+            for b in blks:
+                d[b[0].split(".")[-1]] = make(b)
+            return d
+
+        self.down = nn.ModuleList([seq(b) for b in down])
+        self.middle = seq(middle)
+        self.up = nn.ModuleList([seq(b) for b in up])
+        self.out = _indexed(_0=_Affine(out_ch), _2=_Weights((in_channels, self._final_cin, 3, 3), zero=True))
+        self._plans = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _heads_for(self, c):
+        return self.num_heads if self.num_head_channels == -1 else c // self.num_head_channels
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "_plans":
+                new.__dict__[k] = {}
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_plans"] = {}
+        return d
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, time):
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad:
+            return self._forward_autograd(x, time)
+        return self.forward_hip(x, time)
+
+    def forward_hip(self, x, time, out=None):
+        """Inference forward on the HIP plan (no autograd).  Returns a fresh tensor like x."""
+        _lib.require_cuda(x, "UNetModel.forward")
+        B, C, H, W = x.shape
+        if C != self.in_channels or H != W:
+            raise ValueError(f"expected [B,{self.in_channels},S,S] input, got {tuple(x.shape)}")
+        plan = self._plan_for(B, H, x.device)
+        xin = x.detach()
+        if xin.dtype != torch.float32 or not xin.is_contiguous():
+            xin = xin.float().contiguous()
+        t = time.detach()
+        if t.dtype != torch.int64 or t.device != x.device or not t.is_contiguous():
+            t = t.to(device=x.device, dtype=torch.int64).contiguous()
+        y = plan.run(xin, t)
+        if out is not None:
+            out.copy_(y.view_as(out))
+            return out
+        return y.clone().to(x.dtype)
+
+    def _plan_for(self, B, S, device):
+        key = (B, S, device)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _Plan(self, B, S, device)
+            self._plans[key] = plan
+        plan.refresh_weights()
+        return plan
+
+    # ------------------------------------------------------------------ differentiable forward (training)
+    def _forward_autograd(self, x, time):
+        _lib.require_cuda(x, "UNetModel.forward (training)")
+        sd = dict(self.named_parameters())
+
+        def P(k):
+            return sd[k]
+
+        def gn(p, h):
+            return F.group_norm(h.float(), 32, P(p + ".weight"), P(p + ".bias"), eps=1e-5)
+
+        half = self.model_channels // 2
+        freqs = _posemb_freqs(half).to(x.device)
+        arg = torch.outer(time * 1, freqs)
+        temb = torch.cat((arg.sin(), arg.cos()), dim=-1)
+        temb = F.linear(temb, P("time_embedding.1.weight"), P("time_embedding.1.bias"))
+        temb = F.linear(F.silu(temb), P("time_embedding.3.weight"), P("time_embedding.3.bias"))
+
+        def res(p, h, resample):
+            xs = h
+            h = F.silu(gn(p + ".in_layers.0", h))
+            if resample == "down":
+                h, xs = F.avg_pool2d(h, 2, 2), F.avg_pool2d(xs, 2, 2)
+            elif resample == "up":
+                h = F.interpolate(h, scale_factor=2, mode="nearest")
+                xs = F.interpolate(xs, scale_factor=2, mode="nearest")
+            h = F.conv2d(h, P(p + ".in_layers.2.weight"), P(p + ".in_layers.2.bias"), padding=1)
+            e = F.linear(F.silu(temb), P(p + ".embed_layers.1.weight"), P(p + ".embed_layers.1.bias"))
+            h = h + e[:, :, None, None]
+            h = F.silu(gn(p + ".out_layers.0", h))
+            h = F.dropout(h, self.dropout, self.training)
+            h = F.conv2d(h, P(p + ".out_layers.3.weight"), P(p + ".out_layers.3.bias"), padding=1)
+            if (p + ".skip_connection.weight") in sd:
+                xs = F.conv2d(xs, P(p + ".skip_connection.weight"), P(p + ".skip_connection.bias"))
+            return xs + h
+
+        def attn(p, h):
+            b, c, hh, ww = h.shape
+            heads = self._heads_for(c)
+            xf = h.reshape(b, c, -1)
+            qkv = F.conv1d(gn(p + ".norm", xf), P(p + ".to_qkv.weight"), P(p + ".to_qkv.bias"))
+            ch = c // heads
+            q, k, v = qkv.reshape(b * heads, 3 * ch, -1).split(ch, dim=1)
+            s = 1.0 / math.sqrt(math.sqrt(ch))
+            w = torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s).float(), dim=-1)
+            a = torch.einsum("bts,bcs->bct", w, v).reshape(b, c, -1)
+            a = F.conv1d(a, P(p + ".proj_out.weight"), P(p + ".proj_out.bias"))
+            return (xf + a).reshape(b, c, hh, ww)
+
+        def run(blks, h):
+            for (p, kind, cin, cout, resample) in blks:
+                if kind == "stem":
+                    h = F.conv2d(h, P(p + ".weight"), P(p + ".bias"), padding=1)
+                elif kind == "res":
+                    h = res(p, h, resample)
+                else:
+                    h = attn(p, h)
+            return h
+
+        down, middle, up = self._blocks
+        h = x.float()
+        skips = []
+        for blk in down:
+            h = run(blk, h)
+            skips.append(h)
+        h = run(middle, h)
+        for blk in up:
+            h = run(blk, torch.cat([h, skips.pop()], dim=1))
+        h = F.silu(gn("out.0", h))
+        return F.conv2d(h, P("out.2.weight"), P("out.2.bias"), padding=1).type(x.dtype)
+
+
+def _posemb_freqs(half):
+    """exp(arange(half) * -(ln 1e4 / half)) in fp32 exactly as UNet.py:53-54 computes it (host)."""
+    step = np.log(10000) / half
+    return torch.exp(torch.arange(half) * -step)
+
+
+# ----------------------------------------------------------------------------- plan
+def _pack_conv(w):
+    """OIHW / OI1 -> [taps][I/4][O][4] fp32 (B operand layout of the implicit GEMM)."""
+    if w.dim() == 3:
+        w = w.unsqueeze(-1)
+    o, i, kh, kw = w.shape
+    return (w.detach().float().permute(2, 3, 1, 0).reshape(kh * kw, i // 4, 4, o)
+            .permute(0, 1, 3, 2).contiguous())
+
+
+class _Plan:
+    """Compiled forward for one (batch, size, device): buffers + packed weights + flat op list."""
+
+    def __init__(self, model, B, S, device):
+        self.model = model
+        self.B, self.S, self.device = B, S, device
+        self.keep = []          # tensors / ctypes structs that must outlive the op list
+        self.ops = []           # (code, struct)
+        self.packers = []       # callables that (re)pack weights into their fixed buffers
+        self.token = None
+        self.flops = {"conv3": 0.0, "conv1": 0.0, "attn": 0.0, "qkvproj": 0.0}
+        self.igemm_flops = 0.0
+        self._ws_need = 0
+        with torch.no_grad():
+            self._build()
+        n = len(self.ops)
+        self.op_array = (Op * n)()
+        for i, (code, st) in enumerate(self.ops):
+            self.op_array[i].code = code
+            self.op_array[i].flags = 0
+            self.op_array[i].args = ctypes.addressof(st)
+
+    # -- small helpers ------------------------------------------------------------------
+    def buf(self, *shape, dtype=torch.float32):
+        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def packed(self, key, fn):
+        """Fixed device buffer holding fn(param) -- refreshed in place when parameters change."""
+        params = dict(self.model.named_parameters())
+        src = params[key]
+        dst = fn(src.to(self.device)).contiguous()
+        self.keep.append(dst)
+        self.packers.append((key, fn, dst))
+        return dst
+
+    def add(self, code, st):
+        self.keep.append(st)
+        self.ops.append((code, st))
+        return st
+
+    def refresh_weights(self):
+        params = list(self.model.parameters())
+        token = tuple((p.data_ptr(), p._version) for p in params)
+        if token == self.token:
+            return
+        named = dict(self.model.named_parameters())
+        with torch.no_grad():
+            for key, fn, dst in self.packers:
+                src = named[key]
+                if src.device != self.device:
+                    raise _lib.AnoddpmError(f"parameter {key} is on {src.device}, plan is on {self.device}")
+                dst.copy_(fn(src))
+            for fn in self.post_pack:
+                fn()
+        self.token = token
+
+    # -- op emitters ----------------------------------------------------------------------
+    def gn(self, srcs, P, gamma_key, beta_key):
+        """srcs: [(tensor[B,P,C], C)] one or two sources.  Returns (scale, shift) [B][Ctot]."""
+        B = self.B
+        c0 = srcs[0][1]
+        c1 = srcs[1][1] if len(srcs) > 1 else 0
+        C = c0 + c1
+        nslab = max(1, min(256, (P * (C // 4)) // 4096))
+        st = GnArgs()
+        st.a0 = srcs[0][0].data_ptr()
+        st.a1 = srcs[1][0].data_ptr() if c1 else None
+        st.gamma = self.packed(gamma_key, lambda w: w.detach().float()).data_ptr()
+        st.beta = self.packed(beta_key, lambda w: w.detach().float()).data_ptr()
+        scale, shift = self.buf(B, C), self.buf(B, C)
+        st.scale, st.shift = scale.data_ptr(), shift.data_ptr()
+        st.partial = self.buf(B * nslab * 64, dtype=torch.float64).data_ptr()
+        st.a0_bs, st.a1_bs = P * c0, P * c1
+        st.c0, st.c1, st.a0_ld, st.a1_ld = c0, c1, c0, max(c1, 4)
+        st.P, st.B, st.groups, st.nslab, st.eps = P, B, 32, nslab, 1e-5
+        self.add(_lib.OP_GN_STATS, st)
+        return scale, shift
+
+    def igemm(self, *, srcs, H, W, ks, N, bmat, out, out_ld=None, gn=None, act=0, a_mode=0, bias=None,
+              temb=None, temb_ld=0, res=None, res_ld=0, b_mode=0, ldb=0, heads=1, alpha=1.0,
+              a_strides=None, b_strides=(0, 0), o_strides=None, r_strides=None, kind="conv3"):
+        B = self.B
+        P = H * W
+        c0 = srcs[0][1]
+        c1 = srcs[1][1] if len(srcs) > 1 else 0
+        K = c0 + c1
+        st = IgemmArgs()
+        st.a0 = srcs[0][0] if isinstance(srcs[0][0], int) else srcs[0][0].data_ptr()
+        st.a1 = (srcs[1][0].data_ptr() if c1 else None)
+        a0_ld = srcs[0][2] if len(srcs[0]) > 2 else c0
+        a1_ld = (srcs[1][2] if len(srcs[1]) > 2 else c1) if c1 else 4
+        st.a0_ld, st.a1_ld = a0_ld, a1_ld
+        if a_strides is None:
+            Pin = P if a_mode == 0 else (P // 4 if a_mode == 1 else P * 4)
+            st.a0_bs, st.a0_hs, st.a1_bs, st.a1_hs = Pin * a0_ld, 0, Pin * a1_ld if c1 else 0, 0
+        else:
+            st.a0_bs, st.a0_hs = a_strides
+            st.a1_bs = st.a1_hs = 0
+        st.gn_scale = gn[0].data_ptr() if gn else None
+        st.gn_shift = gn[1].data_ptr() if gn else None
+        st.gn_ld = K
+        st.bmat = bmat if isinstance(bmat, int) else bmat.data_ptr()
+        st.b_bs, st.b_hs = b_strides
+        st.bias = bias.data_ptr() if bias is not None else None
+        st.temb = temb if temb else None
+        st.temb_ld = temb_ld
+        st.res = (res if isinstance(res, int) else res.data_ptr()) if res is not None else None
+        out_ld = out_ld or N
+        st.out = out if isinstance(out, int) else out.data_ptr()
+        st.out_ld, st.res_ld = out_ld, (res_ld or N)
+        if o_strides is None:
+            st.o_bs, st.o_hs = P * out_ld, 0
+        else:
+            st.o_bs, st.o_hs = o_strides
+        if r_strides is None:
+            st.r_bs, st.r_hs = P * (res_ld or N), 0
+        else:
+            st.r_bs, st.r_hs = r_strides
+        st.c0, st.c1 = c0, c1
+        st.H, st.W, st.ks, st.a_mode, st.act = H, W, ks, a_mode, act
+        st.b_mode, st.ldb, st.N = b_mode, ldb, N
+        st.B, st.heads, st.alpha = B, heads, alpha
+        # tile configuration + split-K: fill the 256 CUs (>= 512 workgroups when K allows it)
+        Z = B * heads
+
+        def ok128():
+            if P % 128:
+                return False
+            if ks == 1:
+                return True
+            tw = min(W, 32)
+            th = 128 // tw
+            return th <= H and H % th == 0
+        blocks128 = (P // 128) * ((N + 127) // 128) * Z if ok128() else 0
+        cfg = 0 if (blocks128 >= 256 and N >= 96) else 1
+        bm = 128 if cfg == 0 else 64
+        blocks = -(-P // bm) * ((N + bm - 1) // bm) * Z
+        nchunks = (K + 31) // 32
+        ksplit = 1
+        if blocks < 512 and nchunks > 1 and N % 4 == 0:
+            ksplit = int(min(nchunks, 16, max(1, -(-512 // blocks))))
+        st.cfg, st.ksplit = cfg, ksplit
+        st.ws = None                      # patched after the build (one shared workspace)
+        if ksplit > 1:
+            self._ws_need = max(self._ws_need, ksplit * Z * P * N)
+        self.add(_lib.OP_IGEMM, st)
+        fl = 2.0 * K * N * ks * ks * P * Z
+        self.flops[kind] = self.flops.get(kind, 0.0) + fl
+        self.igemm_flops += fl
+        return st
+
+    # -- network ------------------------------------------------------------------------------
+    def _build(self):
+        m = self.model
+        B, S, dev = self.B, self.S, self.device
+        base, ted = m.model_channels, m._ted
+        down, middle, up = m._blocks
+        self.post_pack = []
+
+        # --- timestep path: features -> MLP -> all per-block projections in one launch (UNet.py:271-276,185-188)
+        half = base // 2
+        freqs = _posemb_freqs(half).to(dev)
+        self.keep.append(freqs)
+        pe = self.buf(B, base)
+        self.posemb = PosembArgs()
+        self.posemb.t, self.posemb.freqs, self.posemb.out = None, freqs.data_ptr(), pe.data_ptr()
+        self.posemb.B, self.posemb.dim, self.posemb.scale = B, base, 1.0
+        self.add(_lib.OP_POSEMB, self.posemb)
+
+        def linear(inp, wkey, bkey, K, N, act_in, act_out, w=None, b=None):
+            st = LinearArgs()
+            st.inp = inp.data_ptr()
+            wt = w if w is not None else self.packed(wkey, lambda t: t.detach().float())
+            bt = b if b is not None else self.packed(bkey, lambda t: t.detach().float())
+            st.w, st.bias = wt.data_ptr(), bt.data_ptr()
+            o = self.buf(B, N)
+            st.out = o.data_ptr()
+            st.B, st.K, st.N, st.act_in, st.act_out = B, K, N, act_in, act_out
+            self.add(_lib.OP_LINEAR, st)
+            return o
+        h1 = linear(pe, "time_embedding.1.weight", "time_embedding.1.bias", base, ted, 0, 1)
+        temb = linear(h1, "time_embedding.3.weight", "time_embedding.3.bias", ted, ted, 0, 0)
+        self.temb = temb
+
+        res_blocks = [b for grp in (down, [middle], up) for blk in grp for b in blk if b[1] == "res"]
+        offs, tot = {}, 0
+        for b in res_blocks:
+            offs[b[0]] = tot
+            tot += b[3]
+        w_all = self.buf(tot, ted)
+        b_all = self.buf(tot)
+        named = dict(m.named_parameters())
+
+        def pack_emb():
+            for b in res_blocks:
+                o = offs[b[0]]
+                w_all[o:o + b[3]].copy_(named[b[0] + ".embed_layers.1.weight"].detach().to(dev))
+                b_all[o:o + b[3]].copy_(named[b[0] + ".embed_layers.1.bias"].detach().to(dev))
+        pack_emb()
+        self.post_pack.append(pack_emb)
+        emb_all = linear(temb, None, None, ted, tot, 1, 0, w=w_all, b=b_all)
+        self.emb_tot = tot
+
+        # --- blocks ---------------------------------------------------------------------------
+        def res_block(prefix, srcs, Hin, cout, resample):
+            cin = sum(s[1] for s in srcs)
+            Hout = Hin * 2 if resample == "up" else (Hin // 2 if resample == "down" else Hin)
+            Pin, Pout = Hin * Hin, Hout * Hout
+            g1 = self.gn(srcs, Pin, prefix + ".in_layers.0.weight", prefix + ".in_layers.0.bias")
+            h1 = self.buf(B, Pout, cout)
+            self.igemm(srcs=srcs, H=Hout, W=Hout, ks=3, N=cout, gn=g1, act=1,
+                       a_mode={None: 0, "up": 1, "down": 2}[resample],
+                       bmat=self.packed(prefix + ".in_layers.2.weight", _pack_conv),
+                       bias=self.packed(prefix + ".in_layers.2.bias", lambda t: t.detach().float()),
+                       temb=emb_all.data_ptr() + 4 * offs[prefix], temb_ld=tot, out=h1)
+            g2 = self.gn([(h1, cout)], Pout, prefix + ".out_layers.0.weight", prefix + ".out_layers.0.bias")
+            if cin != cout:
+                sk = self.buf(B, Pout, cout)
+                assert resample is None
+                self.igemm(srcs=srcs, H=Hout, W=Hout, ks=1, N=cout, kind="conv1",
+                           bmat=self.packed(prefix + ".skip_connection.weight", _pack_conv),
+                           bias=self.packed(prefix + ".skip_connection.bias", lambda t: t.detach().float()), out=sk)
+            elif resample is not None:
+                assert len(srcs) == 1
+                sk = self.buf(B, Pout, cout)
+                st = ResampleArgs()
+                st.inp, st.out = srcs[0][0].data_ptr(), sk.data_ptr()
+                st.B, st.H, st.W, st.C, st.mode = B, Hin, Hin, cin, 1 if resample == "up" else 2
+                self.add(_lib.OP_RESAMPLE, st)
+            else:
+                if len(srcs) != 1:
+                    raise NotImplementedError("identity skip over a concatenated input (cin == cout) is not built")
+                sk = srcs[0][0]
+            h2 = self.buf(B, Pout, cout)
+            self.igemm(srcs=[(h1, cout)], H=Hout, W=Hout, ks=3, N=cout, gn=g2, act=1,
+                       bmat=self.packed(prefix + ".out_layers.3.weight", _pack_conv),
+                       bias=self.packed(prefix + ".out_layers.3.bias", lambda t: t.detach().float()),
+                       res=sk, out=h2)
+            return h2, Hout
+
+        def attn_block(prefix, x, Hc, C):
+            L = Hc * Hc
+            heads = m._heads_for(C)
+            ch = C // heads
+            if ch % 4:
+                raise NotImplementedError(f"attention head width {ch} must be a multiple of 4")
+            g = self.gn([(x, C)], L, prefix + ".norm.weight", prefix + ".norm.bias")
+            qkv = self.buf(B, L, 3 * C)
+            self.igemm(srcs=[(x, C)], H=Hc, W=Hc, ks=1, N=3 * C, gn=g, act=0, kind="qkvproj",
+                       bmat=self.packed(prefix + ".to_qkv.weight", _pack_conv),
+                       bias=self.packed(prefix + ".to_qkv.bias", lambda t: t.detach().float()), out=qkv)
+            S_ = self.buf(B * heads, L, L)
+            qp = qkv.data_ptr()
+            # scores = (q*s)^T (k*s), s = ch^-1/4  ->  alpha = ch^-1/2 on the product (UNet.py:147-150)
+            self.igemm(srcs=[(qp, ch, 3 * C)], H=1, W=L, ks=1, N=L, b_mode=1, ldb=3 * C, heads=heads,
+                       bmat=qp + 4 * ch, alpha=1.0 / math.sqrt(ch), kind="attn",
+                       a_strides=(L * 3 * C, 3 * ch), b_strides=(L * 3 * C, 3 * ch),
+                       out=S_, out_ld=L, o_strides=(heads * L * L, L * L))
+            sm = SoftmaxArgs()
+            sm.x, sm.rows, sm.L = S_.data_ptr(), B * heads * L, L
+            self.add(_lib.OP_SOFTMAX, sm)
+            att = self.buf(B, L, C)
+            self.igemm(srcs=[(S_.data_ptr(), L, L)], H=1, W=L, ks=1, N=ch, b_mode=2, ldb=3 * C, heads=heads,
+                       bmat=qp + 4 * 2 * ch, kind="attn",
+                       a_strides=(heads * L * L, L * L), b_strides=(L * 3 * C, 3 * ch),
+                       out=att, out_ld=C, o_strides=(L * C, ch))
+            y = self.buf(B, L, C)
+            self.igemm(srcs=[(att, C)], H=Hc, W=Hc, ks=1, N=C, kind="qkvproj",
+                       bmat=self.packed(prefix + ".proj_out.weight", _pack_conv),
+                       bias=self.packed(prefix + ".proj_out.bias", lambda t: t.detach().float()),
+                       res=x, out=y)
+            return y
+
+        def run(blks, srcs, Hc):
+            for (prefix, kind, cin, cout, resample) in blks:
+                if kind == "stem":
+                    h0 = self.buf(B, S * S, cout)
+                    self.stem = StemArgs()
+                    self.stem.x = None
+                    self.stem.w = self.packed(prefix + ".weight", lambda w: w.detach().float().permute(2, 3, 1, 0).reshape(-1, w.shape[0])).data_ptr()
+                    self.stem.bias = self.packed(prefix + ".bias", lambda t: t.detach().float()).data_ptr()
+                    self.stem.out = h0.data_ptr()
+                    self.stem.B, self.stem.H, self.stem.W, self.stem.Cin, self.stem.Cout = B, S, S, cin, cout
+                    self.add(_lib.OP_STEM, self.stem)
+                    self.flops["conv3"] += 2.0 * cin * cout * 9 * S * S * B
+                    srcs = [(h0, cout)]
+                elif kind == "res":
+                    h, Hc = res_block(prefix, srcs, Hc, cout, resample)
+                    srcs = [(h, cout)]
+                else:
+                    h = attn_block(prefix, srcs[0][0], Hc, cin)
+                    srcs = [(h, cin)]
+            return srcs, Hc
+
+        Hc = S
+        srcs = None
+        skips = []
+        for blk in down:
+            srcs, Hc = run(blk, srcs, Hc)
+            skips.append(srcs[0])
+        srcs, Hc = run(middle, srcs, Hc)
+        for blk in up:
+            srcs, Hc = run(blk, [srcs[0], skips.pop()], Hc)
+
+        # --- head: GN + SiLU + 3x3 conv to in_channels (UNet.py:384-388,405)
+        hfin, cfin = srcs[0]
+        g = self.gn([(hfin, cfin)], S * S, "out.0.weight", "out.0.bias")
+        nout = m.in_channels
+        y_nhwc = self.buf(B, S * S, nout)
+        self.igemm(srcs=[(hfin, cfin)], H=S, W=S, ks=3, N=nout, gn=g, act=1,
+                   bmat=self.packed("out.2.weight", _pack_conv),
+                   bias=self.packed("out.2.bias", lambda t: t.detach().float()), out=y_nhwc)
+        if nout == 1:
+            self.y = y_nhwc.view(B, 1, S, S)
+        else:
+            self.y = self.buf(B, nout, S, S)
+            st = LayoutArgs()
+            st.inp, st.out, st.B, st.P, st.C, st.in_ld = y_nhwc.data_ptr(), self.y.data_ptr(), B, S * S, nout, nout
+            self.add(_lib.OP_LAYOUT, st)
+        # one split-K workspace shared by every op (ops run in stream order)
+        if self._ws_need:
+            ws = self.buf(self._ws_need)
+            for code, st in self.ops:
+                if code == _lib.OP_IGEMM and st.ksplit > 1:
+                    st.ws = ws.data_ptr()
+
+    def run(self, x, t):
+        """x: contiguous fp32 [B,C,S,S] on self.device; t: int64 [B].  Returns the plan-owned output."""
+        self.stem.x = x.data_ptr()
+        self.posemb.t = t.data_ptr()
+        check(lib().anoddpm_run_ops(self.op_array, len(self.ops), _lib.current_stream()), "UNet forward")
+        return self.y

@@ -1,0 +1,301 @@
+/*
+ * anoddpm_hip.h -- C ABI of libanoddpm_hip.so, the MI355X (gfx950) implementation of the
+ * AnoDDPM hot path.  Plain pointers and sizes only: no torch / C++ types cross this boundary.
+ *
+ * The upstream reference (Julian-Wyatt/AnoDDPM) is pure Python and has no FFI of its own; the
+ * drop-in boundary its callers see is the Python module surface (GaussianDiffusion / UNet /
+ * simplex).  This header is the layer directly below that surface: each entry point replaces
+ * the reference code cited next to it.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every function returns ANODDPM_OK (0) or a negative ANODDPM_E* code; nothing throws,
+ *     nothing allocates device memory, nothing synchronises (safe under hipGraph capture)
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream)
+ *   - device pointers are marked [dev]; host pointers [host]
+ *   - activations are NHWC fp32 ("pixels x channels"); an image is H*W pixels
+ */
+#ifndef ANODDPM_HIP_H
+#define ANODDPM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANODDPM_OK 0
+#define ANODDPM_EINVAL (-1)   /* bad argument (shape/alignment/range)          */
+#define ANODDPM_ELAUNCH (-2)  /* HIP reported a launch / runtime error          */
+#define ANODDPM_ENODEV (-3)   /* no HIP device visible                          */
+
+int anoddpm_abi_version(void);          /* bumps whenever a struct below changes */
+const char *anoddpm_last_error(void);   /* [host] text of the last failure on this thread */
+int anoddpm_device_count(void);
+int anoddpm_struct_size(int32_t which); /* sizeof of the n-th *_args struct, in declaration order */
+
+/* ------------------------------------------------------------------ simplex ------------ */
+
+/* simplex.py:166-192 (_init): seed -> permutation + gradient-index tables.  HOST function.
+ * `seed` is the already int64-wrapped seed.  perm / pgi3: [host] int16[256] each. */
+int anoddpm_simplex_perm_init(int64_t seed, int16_t *perm, int16_t *pgi3);
+
+/* simplex.py:75-93 (rand_3d_fixed_T_octaves), :37-54 (rand_3d_octaves), :833-840 (_noise3a),
+ * :321-830 (_noise3), :202-208 (_extrapolate3): multi-octave OpenSimplex-3D field.
+ *   out[s][y][x] = sum_o persistence^o * noise3(x/f_o, y/f_o, z_s/f_o),  f_o = frequency/2^o
+ * evaluated in fp64 in the reference's exact operation order (bit-exact), octave 0 first.
+ * One launch fills `nslices` slices of H x W.
+ *   zvals   [dev] int64[nslices] integer z index of each slice (timesteps, or 0..D-1);
+ *           NULL means z_s = z0 + s
+ *   tables  [dev] int16: table set n at tables + n*512 = {perm[256], pgi3[256]}
+ *   table_sel [dev] int32* or NULL: *table_sel = index of the table set for this launch
+ *           (lets a captured graph walk through pre-generated per-step tables)
+ *   table_slice_stride: table set used by slice s = base + s*table_slice_stride (0 = shared)
+ *   out_slice_stride: elements between consecutive slices in `out` (>= H*W)
+ * _f64 stores doubles (Simplex_CLASS API); _f32 stores the fp64 result rounded to fp32
+ * (what generate_simplex_noise's assignment into a float tensor does, GaussianDiffusion.py:125). */
+typedef struct {
+    void *out;                 /* [dev] double* or float* */
+    const int64_t *zvals;      /* [dev] or NULL */
+    const int16_t *tables;     /* [dev] */
+    const int32_t *table_sel;  /* [dev] or NULL */
+    int64_t z0;
+    int64_t out_slice_stride;
+    int32_t nslices, H, W;
+    int32_t table_slice_stride;
+    int32_t table_sel_scale;   /* table index = (*table_sel) * table_sel_scale + ... */
+    int32_t octaves;
+    double persistence;
+    double frequency;
+} anoddpm_simplex_args;
+
+int anoddpm_simplex3_octaves_f64(const anoddpm_simplex_args *a, void *stream);
+int anoddpm_simplex3_octaves_f32(const anoddpm_simplex_args *a, void *stream);
+
+/* simplex.py:833-840 (_noise3a) / :31-35 (noise3, noise3array): one octave on arbitrary fp64
+ * coordinate vectors, out[z][y][x] = noise3(X[x], Y[y], Z[z]); all pointers [dev]; tables = one
+ * 512-entry set. */
+int anoddpm_simplex3_grid_f64(double *out, const double *X, int32_t nx, const double *Y, int32_t ny,
+                              const double *Z, int32_t nz, const int16_t *tables, void *stream);
+
+/* ------------------------------------------------------------------ diffusion ---------- */
+
+/* GaussianDiffusion.py:361-371 (sample_q) and :373-382 (sample_q_gradual):
+ *   out = ca[t[b]] * x + cb[t[b]] * noise        (separate mul, mul, add: no FMA)
+ * x, noise, out: [dev] fp32 [B][n]; t: [dev] int64[B]; ca, cb: [dev] fp32[T] (the reference's
+ * fp64 tables rounded to fp32, which is what extract() does after its gather, :32-36). */
+int anoddpm_q_sample(float *out, const float *x, const float *noise, const int64_t *t,
+                     const float *ca, const float *cb, int32_t B, int64_t n, int32_t T,
+                     void *stream);
+
+/* GaussianDiffusion.py:269-318 (p_mean_variance + sample_p) with the model output given:
+ *   pred_x0 = clamp(c_recip[t]*x_t - c_recipm1[t]*eps, -1, 1)
+ *   mean    = c_coef1[t]*pred_x0 + c_coef2[t]*x_t
+ *   x_prev  = mean + (t != 0) * sigma[t] * noise ,  sigma = exp(0.5*model_log_variance)
+ * all fp32 with the reference's operation order (bit-exact vs. its CPU path).
+ * x_prev may alias x_t.  pred_x0 and mean_out may be NULL.  noise may be NULL (treated as 0). */
+typedef struct {
+    float *x_prev;
+    float *pred_x0;
+    float *mean_out;
+    const float *x_t;
+    const float *eps;
+    const float *noise;
+    const int64_t *t;          /* [dev] int64[B] */
+    const float *c_recip;      /* sqrt_recip_alphas_cumprod      fp32[T] */
+    const float *c_recipm1;    /* sqrt_recipm1_alphas_cumprod    fp32[T] */
+    const float *c_coef1;      /* posterior_mean_coef1           fp32[T] */
+    const float *c_coef2;      /* posterior_mean_coef2           fp32[T] */
+    const float *c_sigma;      /* exp(0.5*log(model_var))        fp32[T] */
+    int64_t n;                 /* elements per sample */
+    int32_t B, T;
+} anoddpm_p_update_args;
+
+int anoddpm_p_sample_update(const anoddpm_p_update_args *a, void *stream);
+
+/* Advance a device-resident chain state after a reverse step: t[b] -= 1 for all b, *step += 1.
+ * (The reference rebuilds t on the host every step, GaussianDiffusion.py:351-352.) */
+int anoddpm_chain_advance(int64_t *t, int32_t B, int32_t *step, void *stream);
+
+/* ------------------------------------------------------------------ UNet ops ----------- */
+
+/* Operation codes for anoddpm_run_ops: one UNet forward is a flat list of these. */
+enum {
+    ANODDPM_OP_IGEMM = 1,        /* anoddpm_igemm_args       */
+    ANODDPM_OP_GN_STATS = 2,     /* anoddpm_gn_args          */
+    ANODDPM_OP_SOFTMAX = 3,      /* anoddpm_softmax_args     */
+    ANODDPM_OP_RESAMPLE = 4,     /* anoddpm_resample_args    */
+    ANODDPM_OP_LINEAR = 5,       /* anoddpm_linear_args      */
+    ANODDPM_OP_POSEMB = 6,       /* anoddpm_posemb_args      */
+    ANODDPM_OP_STEM = 7,         /* anoddpm_stem_args        */
+    ANODDPM_OP_LAYOUT = 8        /* anoddpm_layout_args      */
+};
+
+/* Implicit-GEMM convolution / GEMM on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact fp32).
+ *   out[z][p][n] = alpha * sum_{tap,k} A(z, p shifted by tap, k) * Bmat(tap, k, n)
+ *                  + bias[n] + temb[b][n] + res[z][p][n]
+ * Replaces: nn.Conv2d 3x3 / 1x1 (UNet.py:172,193,200,280,387), nn.Conv1d k=1 (UNet.py:115,117),
+ * the two einsums of QKVAttention (UNet.py:148-152), and -- fused into the A load -- GroupNorm32
+ * apply + SiLU (UNet.py:170-171,190-191,386,409-411), AvgPool2d / nearest x2 (UNet.py:70,89)
+ * and torch.cat([h, skip]) (UNet.py:402: the two sources are read in place).
+ * z = blockIdx.z decomposes as b = z / heads, head = z % heads. */
+typedef struct {
+    /* A operand: up to two NHWC sources concatenated along channels */
+    const float *a0, *a1;           /* a1 NULL when single source */
+    const float *gn_scale, *gn_shift; /* [B][K] per-sample per-channel affine or NULL */
+    /* B operand */
+    const float *bmat;              /* packed weights, or activations for b_mode 1/2 */
+    /* epilogue */
+    const float *bias;              /* [N] or NULL */
+    const float *temb;              /* [B][temb_ld] or NULL */
+    const float *res;               /* residual, same layout as out, or NULL */
+    float *out;
+    float *ws;                      /* split-K workspace [ksplit][Z][P][N] or NULL */
+    int64_t a0_bs, a0_hs, a1_bs, a1_hs;   /* batch / head strides (floats) */
+    int64_t b_bs, b_hs;
+    int64_t o_bs, o_hs, r_bs, r_hs;
+    int32_t c0, c1;                 /* channels taken from a0 / a1 (K = c0 + c1) */
+    int32_t a0_ld, a1_ld;           /* floats between consecutive pixels */
+    int32_t H, W;                   /* OUTPUT image dims; P = H*W                */
+    int32_t ks;                     /* 1 or 3 (square, stride 1, pad ks/2)       */
+    int32_t a_mode;                 /* 0 same-res, 1 source is half-res (nearest x2), 2 source is double-res (avg 2x2) */
+    int32_t act;                    /* 1: SiLU on the A operand (after the affine) */
+    int32_t b_mode;                 /* 0 packed [taps][K/4][N][4]; 1 rows [N][K] (ldb); 2 rows [K][N] (ldb) */
+    int32_t ldb;
+    int32_t N;
+    int32_t temb_ld;
+    int32_t out_ld, res_ld;
+    int32_t B, heads;               /* Z = B*heads */
+    int32_t ksplit;                 /* >= 1 */
+    int32_t cfg;                    /* 0: 128x128 tile, 1: 64x64 tile */
+    float alpha;
+    int32_t gn_ld;                  /* row length of gn_scale/gn_shift (= K) */
+} anoddpm_igemm_args;
+
+int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream);
+
+/* GroupNorm statistics -> per-sample per-channel affine (UNet.py:409-411 / nn.GroupNorm(32,C),
+ * eps 1e-5, biased variance), over up to two concatenated NHWC sources:
+ *   scale[b][c] = rstd[b,g(c)] * gamma[c];  shift[b][c] = beta[c] - mean[b,g(c)] * scale[b][c]
+ * `partial` is scratch: double[B][nslab][64]. */
+typedef struct {
+    const float *a0, *a1;
+    const float *gamma, *beta;      /* [C] */
+    float *scale, *shift;           /* [B][C] */
+    double *partial;
+    int64_t a0_bs, a1_bs;
+    int32_t c0, c1, a0_ld, a1_ld;
+    int32_t P;                      /* pixels per image */
+    int32_t B, groups, nslab;
+    float eps;
+} anoddpm_gn_args;
+
+int anoddpm_gn_stats(const anoddpm_gn_args *a, void *stream);
+
+/* Row softmax in place (UNet.py:151): x[r][0..L) <- softmax(x[r][:]); rows = B*heads*L. */
+typedef struct {
+    float *x;
+    int64_t rows;
+    int32_t L;
+} anoddpm_softmax_args;
+
+int anoddpm_softmax_rows(const anoddpm_softmax_args *a, void *stream);
+
+/* 2x resampling of an NHWC tensor (the x_upd path of ResBlock, UNet.py:177-181,207):
+ * mode 1: nearest x2 up (in H x W -> out 2H x 2W); mode 2: 2x2 average pool (in -> H/2 x W/2). */
+typedef struct {
+    const float *in;
+    float *out;
+    int32_t B, H, W, C;             /* INPUT dims */
+    int32_t mode;
+} anoddpm_resample_args;
+
+int anoddpm_resample2x(const anoddpm_resample_args *a, void *stream);
+
+/* Small-batch linear layer (UNet.py:273-275 time MLP; :185-188 per-block embedding projections,
+ * all blocks batched into one launch by concatenating their weight rows):
+ *   out[b][n] = act_out( sum_k act_in(in[b][k]) * w[n][k] + bias[n] ),  B <= 16. */
+typedef struct {
+    const float *in;                /* [B][K] */
+    const float *w;                 /* [N][K] (nn.Linear layout) */
+    const float *bias;              /* [N] or NULL */
+    float *out;                     /* [B][N] */
+    int32_t B, K, N;
+    int32_t act_in, act_out;        /* 1 = SiLU */
+} anoddpm_linear_args;
+
+int anoddpm_linear_small(const anoddpm_linear_args *a, void *stream);
+
+/* Sinusoidal timestep features (UNet.py:50-57): out[b][i] = sin(t_b*f_i), out[b][half+i] = cos(t_b*f_i),
+ * f_i = exp(-i * ln(1e4)/half) in fp32 (table supplied by the caller so that it is bit-identical
+ * to the host-computed one; t_b*f_i is one fp32 multiply as in torch.outer). */
+typedef struct {
+    const int64_t *t;               /* [dev] int64[B] */
+    const float *freqs;             /* [dev] fp32[dim/2]: f_i, precomputed once on the host */
+    float *out;                     /* [B][dim] */
+    int32_t B, dim;
+    float scale;
+} anoddpm_posemb_args;
+
+int anoddpm_posemb(const anoddpm_posemb_args *a, void *stream);
+
+/* Stem convolution (UNet.py:280): 3x3, pad 1, Cin <= 4 NCHW input -> Cout NHWC output.
+ * w: [9][Cin][Cout] fp32. */
+typedef struct {
+    const float *x;                 /* [B][Cin][H][W] (NCHW, as the caller hands it over) */
+    const float *w;
+    const float *bias;
+    float *out;                     /* [B][H][W][Cout] */
+    int32_t B, H, W, Cin, Cout;
+} anoddpm_stem_args;
+
+int anoddpm_conv_stem(const anoddpm_stem_args *a, void *stream);
+
+/* Layout change at the API edge: NHWC [B][P][C] -> NCHW [B][C][P] (C small, UNet output). */
+typedef struct {
+    const float *in;
+    float *out;
+    int32_t B, P, C;
+    int32_t in_ld;
+} anoddpm_layout_args;
+
+int anoddpm_nhwc_to_nchw(const anoddpm_layout_args *a, void *stream);
+
+/* Flat op list: the native executor behind UNetModel.forward (UNet.py:390-406). */
+typedef struct {
+    int32_t code;                   /* ANODDPM_OP_* */
+    int32_t flags;
+    const void *args;               /* [host] pointer to the matching *_args struct */
+} anoddpm_op;
+
+int anoddpm_run_ops(const anoddpm_op *ops, int32_t n, void *stream);
+
+/* Per-class kernel timing with HIP events on the launch stream (bench.py roofline leg).
+ * enable=1 starts recording one event pair per launched op; collect() synchronises the events
+ * and returns accumulated milliseconds and launch counts per op code (arrays of 16). */
+int anoddpm_prof_enable(int32_t enable);
+int anoddpm_prof_collect(double *ms_per_code, int64_t *launches_per_code);
+
+/* ------------------------------------------------------------------ training ----------- */
+
+/* Fused AdamW + EMA over a flat fp32 parameter buffer (diffusion_training.py:75,105,107 and
+ * UNet.py:423-427): decoupled weight decay, bias-corrected moments, then
+ * ema = decay*ema + (1-decay)*p.  grad_scale multiplies g first (global-norm clip factor). */
+typedef struct {
+    float *p, *m, *v, *ema;
+    const float *g;
+    const float *grad_scale;        /* [dev] fp32 scalar or NULL */
+    int64_t n;
+    float lr, beta1, beta2, eps, weight_decay, ema_decay;
+    int32_t step;                   /* 1-based */
+} anoddpm_adamw_args;
+
+int anoddpm_adamw_ema(const anoddpm_adamw_args *a, void *stream);
+
+/* Sum of squares of a flat fp32 buffer -> *out (fp32, [dev]); out must be zeroed by the caller.
+ * (clip_grad_norm_, diffusion_training.py:104) */
+int anoddpm_sumsq(const float *g, int64_t n, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANODDPM_HIP_H */

@@ -1,0 +1,149 @@
+"""Thin test-side wrappers that call single C-ABI ops (include/anoddpm_hip.h) on torch CUDA tensors."""
+import ctypes
+import math
+
+import torch
+
+from anoddpm_amd import _lib
+from anoddpm_amd._lib import (GnArgs, IgemmArgs, LinearArgs, PosembArgs, ResampleArgs, SoftmaxArgs, StemArgs,
+                              check, current_stream, lib)
+from anoddpm_amd.unet import _pack_conv
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def gn_affine(srcs, gamma, beta, nslab=None, eps=1e-5):
+    """srcs: list of NHWC [B,H,W,C] cuda tensors (1 or 2).  Returns scale, shift [B, Ctot]."""
+    B, H, W, c0 = srcs[0].shape
+    c1 = srcs[1].shape[3] if len(srcs) > 1 else 0
+    C, P = c0 + c1, H * W
+    nslab = nslab or max(1, min(256, (P * (C // 4)) // 4096))
+    st = GnArgs()
+    st.a0 = srcs[0].data_ptr()
+    st.a1 = srcs[1].data_ptr() if c1 else None
+    scale = torch.empty(B, C, device=srcs[0].device)
+    shift = torch.empty(B, C, device=srcs[0].device)
+    part = torch.empty(B * nslab * 64, dtype=torch.float64, device=srcs[0].device)
+    st.gamma, st.beta, st.scale, st.shift, st.partial = gamma.data_ptr(), beta.data_ptr(), scale.data_ptr(), shift.data_ptr(), part.data_ptr()
+    st.a0_bs, st.a1_bs, st.c0, st.c1, st.a0_ld, st.a1_ld = P * c0, P * c1, c0, c1, c0, max(c1, 4)
+    st.P, st.B, st.groups, st.nslab, st.eps = P, B, 32, nslab, eps
+    check(lib().anoddpm_gn_stats(ctypes.byref(st), current_stream()), "gn_stats")
+    return scale, shift
+
+
+def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=None, res=None, cfg=0, ksplit=1):
+    """srcs: NHWC sources; w: OIHW weights.  Returns NHWC [B,Hout,Hout,N]."""
+    dev = srcs[0].device
+    B = srcs[0].shape[0]
+    c0 = srcs[0].shape[3]
+    c1 = srcs[1].shape[3] if len(srcs) > 1 else 0
+    N = w.shape[0]
+    P = Hout * Hout
+    Pin = srcs[0].shape[1] * srcs[0].shape[2]
+    st = IgemmArgs()
+    wp = _pack_conv(w)
+    out = torch.full((B, Hout, Hout, N), float("nan"), device=dev)
+    st.a0, st.a1 = srcs[0].data_ptr(), srcs[1].data_ptr() if c1 else None
+    st.a0_ld, st.a1_ld, st.c0, st.c1 = c0, max(c1, 4), c0, c1
+    st.a0_bs, st.a1_bs = Pin * c0, Pin * c1
+    st.gn_scale = gn[0].data_ptr() if gn else None
+    st.gn_shift = gn[1].data_ptr() if gn else None
+    st.gn_ld = c0 + c1
+    st.bmat = wp.data_ptr()
+    st.bias = bias.data_ptr() if bias is not None else None
+    st.temb = temb.data_ptr() if temb is not None else None
+    st.temb_ld = N
+    st.res = res.data_ptr() if res is not None else None
+    st.out, st.out_ld, st.res_ld = out.data_ptr(), N, N
+    st.o_bs = st.r_bs = P * N
+    st.H, st.W, st.ks, st.a_mode, st.act = Hout, Hout, ks, a_mode, act
+    st.b_mode, st.ldb, st.N, st.B, st.heads, st.alpha = 0, 0, N, B, 1, 1.0
+    st.cfg, st.ksplit = cfg, ksplit
+    ws = torch.empty(max(1, ksplit * B * P * N), device=dev) if ksplit > 1 else None
+    st.ws = ws.data_ptr() if ws is not None else None
+    check(lib().anoddpm_igemm(ctypes.byref(st), current_stream()), "igemm")
+    torch.cuda.synchronize()
+    return out
+
+
+def attention(qkv, heads, cfg=1):
+    """qkv: [B, L, 3C] (legacy per-head q|k|v channel order).  Returns [B, L, C]."""
+    dev = qkv.device
+    B, L, C3 = qkv.shape
+    C = C3 // 3
+    ch = C // heads
+    S = torch.full((B * heads, L, L), float("nan"), device=dev)
+    st = IgemmArgs()
+    st.a0, st.a0_ld, st.c0, st.c1 = qkv.data_ptr(), C3, ch, 0
+    st.a0_bs, st.a0_hs = L * C3, 3 * ch
+    st.bmat, st.b_mode, st.ldb, st.b_bs, st.b_hs = qkv.data_ptr() + 4 * ch, 1, C3, L * C3, 3 * ch
+    st.out, st.out_ld, st.o_bs, st.o_hs = S.data_ptr(), L, heads * L * L, L * L
+    st.H, st.W, st.ks, st.N, st.B, st.heads, st.alpha = 1, L, 1, L, B, heads, 1.0 / math.sqrt(ch)
+    st.cfg, st.ksplit, st.a1_ld, st.res_ld, st.temb_ld, st.gn_ld = cfg, 1, 4, L, 0, ch
+    check(lib().anoddpm_igemm(ctypes.byref(st), current_stream()), "igemm qk")
+    sm = SoftmaxArgs()
+    sm.x, sm.rows, sm.L = S.data_ptr(), B * heads * L, L
+    check(lib().anoddpm_softmax_rows(ctypes.byref(sm), current_stream()), "softmax")
+    out = torch.full((B, L, C), float("nan"), device=dev)
+    st2 = IgemmArgs()
+    st2.a0, st2.a0_ld, st2.c0, st2.c1 = S.data_ptr(), L, L, 0
+    st2.a0_bs, st2.a0_hs = heads * L * L, L * L
+    st2.bmat, st2.b_mode, st2.ldb, st2.b_bs, st2.b_hs = qkv.data_ptr() + 8 * ch, 2, C3, L * C3, 3 * ch
+    st2.out, st2.out_ld, st2.o_bs, st2.o_hs = out.data_ptr(), C, L * C, ch
+    st2.H, st2.W, st2.ks, st2.N, st2.B, st2.heads, st2.alpha = 1, L, 1, ch, B, heads, 1.0
+    st2.cfg, st2.ksplit, st2.a1_ld, st2.res_ld, st2.temb_ld, st2.gn_ld = cfg, 1, 4, C, 0, L
+    check(lib().anoddpm_igemm(ctypes.byref(st2), current_stream()), "igemm pv")
+    torch.cuda.synchronize()
+    return out, S
+
+
+def resample(x, mode):
+    B, H, W, C = x.shape
+    Ho = H * 2 if mode == 1 else H // 2
+    out = torch.full((B, Ho, Ho, C), float("nan"), device=x.device)
+    st = ResampleArgs()
+    st.inp, st.out, st.B, st.H, st.W, st.C, st.mode = x.data_ptr(), out.data_ptr(), B, H, W, C, mode
+    check(lib().anoddpm_resample2x(ctypes.byref(st), current_stream()), "resample")
+    torch.cuda.synchronize()
+    return out
+
+
+def linear(x, w, b, act_in=0, act_out=0):
+    B, K = x.shape
+    N = w.shape[0]
+    out = torch.full((B, N), float("nan"), device=x.device)
+    st = LinearArgs()
+    st.inp, st.w, st.bias, st.out = x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, out.data_ptr()
+    st.B, st.K, st.N, st.act_in, st.act_out = B, K, N, act_in, act_out
+    check(lib().anoddpm_linear_small(ctypes.byref(st), current_stream()), "linear")
+    torch.cuda.synchronize()
+    return out
+
+
+def posemb(t, freqs, dim):
+    B = t.numel()
+    out = torch.full((B, dim), float("nan"), device=t.device)
+    st = PosembArgs()
+    st.t, st.freqs, st.out, st.B, st.dim, st.scale = t.data_ptr(), freqs.data_ptr(), out.data_ptr(), B, dim, 1.0
+    check(lib().anoddpm_posemb(ctypes.byref(st), current_stream()), "posemb")
+    torch.cuda.synchronize()
+    return out
+
+
+def stem(x, w, b):
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    wp = w.permute(2, 3, 1, 0).reshape(-1, Cout).contiguous()
+    out = torch.full((B, H, W, Cout), float("nan"), device=x.device)
+    st = StemArgs()
+    st.x, st.w, st.bias, st.out = x.data_ptr(), wp.data_ptr(), b.data_ptr(), out.data_ptr()
+    st.B, st.H, st.W, st.Cin, st.Cout = B, H, W, Cin, Cout
+    check(lib().anoddpm_conv_stem(ctypes.byref(st), current_stream()), "stem")
+    torch.cuda.synchronize()
+    return out

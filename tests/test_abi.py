@@ -1,0 +1,60 @@
+"""The C-ABI shared library loads and exports every symbol include/anoddpm_hip.h declares; argument
+validation and the host-side permutation routine work without a GPU.  CPU only."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from anoddpm_amd import _lib
+
+from conftest import GOLDEN, ROOT
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "anoddpm_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(anoddpm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in the header but not exported"
+    assert sorted(_lib.SYMBOLS) == syms
+
+
+def test_abi_version_and_struct_sizes():
+    L = _lib.lib()
+    assert L.anoddpm_abi_version() == _lib.ABI_VERSION
+    for i, st in enumerate(_lib._STRUCTS):
+        assert L.anoddpm_struct_size(i) == ctypes.sizeof(st), st.__name__
+    assert L.anoddpm_struct_size(99) == -1
+
+
+def test_argument_validation_without_gpu():
+    L = _lib.lib()
+    a = _lib.IgemmArgs()
+    assert L.anoddpm_igemm(ctypes.byref(a), None) == -1
+    assert b"null pointer" in L.anoddpm_last_error()
+    g = _lib.GnArgs()
+    assert L.anoddpm_gn_stats(ctypes.byref(g), None) == -1
+    with pytest.raises(_lib.AnoddpmError):
+        _lib.check(-1, "x")
+    op = (_lib.Op * 1)()
+    op[0].code, op[0].args = 77, ctypes.addressof(a)
+    assert L.anoddpm_run_ops(op, 1, None) == -1
+    assert b"unknown op code" in L.anoddpm_last_error()
+
+
+def test_perm_init_matches_reference_tables():
+    from anoddpm_amd.simplex import perm_tables
+    kat = np.load(os.path.join(GOLDEN, "simplex_kat.npz"))
+    for s, p, g in zip(kat["init_seeds"], kat["init_perm"], kat["init_pgi3"]):
+        tab = perm_tables(int(s))
+        assert (tab[:256] == p).all() and (tab[256:] == g).all()
+    # python ints outside int64 wrap like c_int64 (simplex.py:166-171)
+    assert (perm_tables(2 ** 64 + 3) == perm_tables(3)).all()

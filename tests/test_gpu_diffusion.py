@@ -1,0 +1,126 @@
+"""-m gpu: fused diffusion kernels + GaussianDiffusionModel semantics against reference-generated
+fixtures (bit-exact fp32) and the numpy/torch oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import GOLDEN
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def kat():
+    return np.load(os.path.join(GOLDEN, "diffusion_kat.npz"))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("name", ["linear", "cosine"])
+def test_sample_q_and_sample_p_bit_exact(kat, name):
+    import GaussianDiffusion as GD
+    d = GD.GaussianDiffusionModel([16, 16], GD.get_beta_schedule(1000, name))
+    x, eps, noise, t = T(kat["x"]), T(kat["eps"]), T(kat["noise"]), T(kat["t"])
+    assert torch.equal(d.sample_q(x, t, noise).cpu(), torch.from_numpy(kat[f"{name}_sample_q"]))
+    assert torch.equal(d.q_sample(x, t, noise).cpu(), torch.from_numpy(kat[f"{name}_sample_q"]))
+    assert torch.equal(d.sample_q_gradual(x, t, noise).cpu(), torch.from_numpy(kat[f"{name}_sample_q_gradual"]))
+    pmv = d.p_mean_variance(None, x, t, estimate_noise=eps)
+    for k in ("mean", "variance", "log_variance", "pred_x_0"):
+        assert pmv[k].shape == x.shape
+        assert torch.equal(pmv[k].contiguous().cpu(), torch.from_numpy(kat[f"{name}_pmv_{k}"])), k
+    sp = d.sample_p(lambda a, b: eps, x, t, denoise_fn=lambda a, b: noise)
+    assert torch.equal(sp["sample"].cpu(), torch.from_numpy(kat[f"{name}_sample_p_sample"]))
+    assert torch.equal(sp["pred_x_0"].cpu(), torch.from_numpy(kat[f"{name}_sample_p_pred_x_0"]))
+    pe = d.predict_eps_from_x_0(x, t, pmv["pred_x_0"])
+    np.testing.assert_allclose(pe.cpu().numpy(), kat[f"{name}_predict_eps_from_x_0"], rtol=1e-5, atol=1e-5)
+
+
+def test_ragged_and_empty_shapes_vs_oracle():
+    import GaussianDiffusion as GD
+    from oracle import diffusion_oracle as do
+    betas = GD.get_beta_schedule(1000, "linear")
+    d = GD.GaussianDiffusionModel([7, 5], betas)
+    tb = do.tables(betas)
+    g = torch.Generator().manual_seed(3)
+    for shape in ((3, 1, 7, 5), (2, 3, 9, 9), (1, 1, 256, 256)):      # n % 4 != 0 -> scalar path
+        x = torch.rand(shape, generator=g) * 2 - 1
+        e, n = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+        t = torch.randint(0, 1000, (shape[0],), generator=g)
+        assert torch.equal(d.sample_q(x.to(DEV), t.to(DEV), n.to(DEV)).cpu(), do.q_sample(tb, x, t, n))
+        s, p0 = do.p_sample_update(tb, x, t, e, n)
+        sp = d.sample_p(lambda a, b: e.to(DEV), x.to(DEV), t.to(DEV), denoise_fn=lambda a, b: n.to(DEV))
+        assert torch.equal(sp["sample"].cpu(), s) and torch.equal(sp["pred_x_0"].cpu(), p0)
+    empty = torch.zeros(0, 1, 4, 4, device=DEV)
+    assert d.sample_q(empty, torch.zeros(0, dtype=torch.int64, device=DEV), empty).shape == (0, 1, 4, 4)
+
+
+def test_forward_backward_sequences(kat):
+    import GaussianDiffusion as GD
+    d = GD.GaussianDiffusionModel([16, 16], GD.get_beta_schedule(1000, "linear"))
+    x1 = T(kat["x"][:1])
+    fixed = T(kat["noise"][:1])
+    d.noise_fn = lambda a, b: fixed
+    model = lambda a, b: 0.3 * a - 0.1
+    half = d.forward_backward(model, x1, "half", 5, denoise_fn=lambda a, b: 0.5 * fixed)
+    whole = d.forward_backward(model, x1, "whole", 4, denoise_fn=lambda a, b: 0.5 * fixed)
+    final = d.forward_backward(model, x1, None, 5, denoise_fn=lambda a, b: 0.5 * fixed)
+    assert len(half) == int(kat["fb_half_len"]) == 7 and len(whole) == int(kat["fb_whole_len"]) == 9
+    assert all(not s.is_cuda for s in half)                       # sequences are CPU tensors upstream
+    np.testing.assert_allclose(torch.stack(half).numpy(), kat["fb_half_seq"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(torch.stack(whole).numpy(), kat["fb_whole_seq"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(final.cpu().numpy(), kat["fb_final"], rtol=0, atol=2e-6)
+    assert final.is_cuda and torch.equal(d.forward_backward(model, x1, None, 0), x1)
+    assert torch.equal(d.p_sample_loop(model, x1, None, 0), x1)
+
+
+def test_losses_with_injected_noise(kat):
+    import GaussianDiffusion as GD
+    x, noise, t = T(kat["x"]), T(kat["noise"]), T(kat["t"])
+    model = lambda a, b: 0.3 * a - 0.1
+    for lt in ("l1", "l2", "hybrid"):
+        d = GD.GaussianDiffusionModel([16, 16], GD.get_beta_schedule(1000, "linear"), loss_type=lt)
+        d.noise_fn = lambda a, b: noise
+        loss, x_t, est = d.calc_loss(model, x, t)
+        np.testing.assert_allclose(loss["loss"].cpu().numpy(), kat[f"loss_{lt}"], rtol=2e-5, atol=1e-6)
+        if lt == "hybrid":
+            np.testing.assert_allclose(loss["vlb"].cpu().numpy(), kat["loss_hybrid_vlb"], rtol=2e-5, atol=1e-6)
+    args = {"train_start": True, "sample_distance": 800}
+    total, (ld, x_t, eps_t) = d.p_loss(model, x, args)
+    assert total.dim() == 0 and x_t.shape == x.shape and eps_t.shape == x.shape
+
+
+def test_simplex_noise_path_matches_oracle_and_rng_order():
+    import GaussianDiffusion as GD
+    from oracle.simplex_oracle import OracleSimplex
+    d = GD.GaussianDiffusionModel([48, 40], GD.get_beta_schedule(1000, "linear"), noise="simplex", img_channels=2)
+    x = torch.zeros(1, 2, 48, 40, device=DEV)
+    t = torch.tensor([249], device=DEV)
+    np.random.seed(99)
+    got = d.noise_fn(x, t)
+    np.random.seed(99)
+    o = OracleSimplex(None)
+    for c in range(2):
+        o.newSeed()                                               # one fresh seed per channel (:101-102)
+        ref = o.rand_3d_fixed_T_octaves((48, 40), np.array([249]), 6, 0.8, 64)[0].astype(np.float32)
+        assert (got[0, c].cpu().numpy().view(np.uint32) == ref.view(np.uint32)).all()
+    # sample_p with a simplex string: default 6 octaves / 0.8 / 64 (GaussianDiffusion.py:97,310)
+    np.random.seed(5)
+    eps = torch.zeros_like(x)
+    out = d.sample_p(lambda a, b: eps, x, t, denoise_fn="simplex")
+    np.random.seed(5)
+    o2 = OracleSimplex(None)
+    o2.newSeed()
+    n0 = o2.rand_3d_fixed_T_octaves((48, 40), np.array([249]), 6, 0.8, 64)[0].astype(np.float32)
+    from oracle import diffusion_oracle as do
+    tb = do.tables(GD.get_beta_schedule(1000, "linear"))
+    o2.newSeed()
+    n1 = o2.rand_3d_fixed_T_octaves((48, 40), np.array([249]), 6, 0.8, 64)[0].astype(np.float32)
+    nz = torch.from_numpy(np.stack([n0, n1])[None])
+    ref, _ = do.p_sample_update(tb, x.cpu(), t.cpu(), eps.cpu(), nz)
+    assert torch.equal(out["sample"].cpu(), ref)

@@ -1,0 +1,171 @@
+"""-m gpu: every C-ABI UNet op against the stock-PyTorch CPU statement of the same op (the oracle's
+building blocks, oracle/unet_oracle.py).  Tolerance: 1e-3 relative to the tensor's max magnitude is the
+north-star bar; these ops are plain fp32 so the tests ask for 2e-5."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def relerr(got, ref):
+    ref = ref.float().cpu()
+    got = got.float().cpu()
+    assert torch.isfinite(got).all(), "non-finite output (unwritten region?)"
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 0), (1, 8, 8, 1024, 0), (2, 32, 32, 96, 0), (1, 64, 64, 128, 0),
+                                   (2, 16, 16, 256, 128), (1, 8, 8, 64, 32), (3, 4, 4, 96, 0), (1, 16, 16, 1536, 0)])
+def test_gn_affine(shape):
+    import hipops
+    B, H, W, c0, c1 = shape
+    C = c0 + c1
+    x = rnd(B, C, H, W, seed=1) * 2 + 0.7
+    gamma, beta = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    ref = F.group_norm(x, 32, gamma, beta, eps=1e-5)
+    xs = hipops.nhwc(x.to(dev()))
+    srcs = [xs[..., :c0].contiguous()] + ([xs[..., c0:].contiguous()] if c1 else [])
+    for nslab in (None, 1, 3):
+        sc, sh = hipops.gn_affine(srcs, gamma.to(dev()), beta.to(dev()), nslab=nslab)
+        got = xs * sc[:, None, None, :] + sh[:, None, None, :]
+        assert relerr(hipops.nchw(got), ref) < TOL
+
+
+CONV_CASES = [
+    # B, Cin(c0,c1), Cout, Hout, ks, a_mode, gn, act, temb, res, cfg, ksplit
+    (1, (64, 0), 128, 32, 3, 0, True, 1, True, True, 0, 1),
+    (2, (32, 0), 64, 16, 3, 0, True, 1, False, False, 1, 1),
+    (1, (128, 0), 128, 64, 3, 0, False, 0, False, False, 0, 1),
+    (2, (64, 64), 128, 16, 3, 0, True, 1, True, True, 0, 1),       # virtual concat
+    (2, (96, 32), 96, 8, 3, 0, True, 1, False, True, 1, 4),        # concat + split-K + N tail
+    (1, (64, 0), 64, 32, 3, 1, True, 1, False, False, 0, 1),       # fused nearest x2
+    (1, (64, 0), 64, 16, 3, 2, True, 1, True, False, 1, 2),        # fused 2x2 avg pool
+    (2, (256, 0), 256, 8, 3, 0, True, 1, True, True, 1, 8),        # 8x8 level, split-K
+    (3, (64, 0), 32, 4, 3, 0, True, 1, False, True, 1, 2),         # 4x4 level (partial tile)
+    (1, (128, 0), 1, 32, 3, 0, True, 1, False, False, 1, 1),       # head conv, N = 1
+    (1, (128, 0), 3, 16, 3, 0, True, 1, False, False, 1, 1),       # head conv, N = 3
+    (2, (64, 32), 128, 16, 1, 0, False, 0, False, False, 0, 1),    # 1x1 skip over concat
+    (1, (128, 0), 384, 16, 1, 0, True, 0, False, False, 1, 2),     # qkv projection (GN, no SiLU)
+    (2, (64, 0), 64, 8, 1, 0, False, 0, False, True, 1, 1),        # proj_out + residual
+    (1, (32, 0), 32, 128, 3, 0, True, 1, True, True, 1, 1),        # wide image, narrow channels
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_igemm_conv(case):
+    import hipops
+    B, (c0, c1), N, Hout, ks, a_mode, use_gn, act, use_temb, use_res, cfg, ksplit = case
+    C = c0 + c1
+    Hin = Hout if a_mode == 0 else (Hout // 2 if a_mode == 1 else Hout * 2)
+    x = rnd(B, C, Hin, Hin, seed=11)
+    w = rnd(N, C, ks, ks, seed=12, scale=1.0 / math.sqrt(C * ks * ks))
+    b = rnd(N, seed=13, scale=0.1)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=14), 0.1 * rnd(C, seed=15)
+    temb = rnd(B, N, seed=16) if use_temb else None
+    res = rnd(B, N, Hout, Hout, seed=17) if use_res else None
+    h = x
+    if use_gn:
+        h = F.group_norm(h, 32, gamma, beta, eps=1e-5)
+    if act:
+        h = F.silu(h)
+    if a_mode == 1:
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+    elif a_mode == 2:
+        h = F.avg_pool2d(h, 2, 2)
+    ref = F.conv2d(h, w, b, padding=ks // 2)
+    if temb is not None:
+        ref = ref + temb[:, :, None, None]
+    if res is not None:
+        ref = ref + res
+    xs = hipops.nhwc(x.to(dev()))
+    srcs = [xs[..., :c0].contiguous()] + ([xs[..., c0:].contiguous()] if c1 else [])
+    gn = hipops.gn_affine(srcs, gamma.to(dev()), beta.to(dev())) if use_gn else None
+    got = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), Hout=Hout, ks=ks, gn=gn, act=act, a_mode=a_mode,
+                            temb=temb.to(dev()) if temb is not None else None,
+                            res=hipops.nhwc(res.to(dev())) if res is not None else None, cfg=cfg, ksplit=ksplit)
+    assert relerr(hipops.nchw(got), ref) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 2), (1, 256, 512, 2), (2, 16, 96, 2), (1, 1024, 64, 1), (1, 64, 128, 4), (1, 256, 512, 1)])
+def test_attention_legacy_order(case):
+    import hipops
+    B, L, C, heads = case
+    qkv = rnd(B, 3 * C, L, seed=21)
+    ch = C // heads
+    q, k, v = qkv.reshape(B * heads, 3 * ch, L).split(ch, dim=1)          # UNet.py:146
+    s = 1 / math.sqrt(math.sqrt(ch))
+    wgt = torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s).float(), dim=-1)
+    ref = torch.einsum("bts,bcs->bct", wgt, v).reshape(B, C, L)
+    for cfg in ((1, 0) if L >= 128 else (1,)):
+        got, S = hipops.attention(qkv.permute(0, 2, 1).contiguous().to(dev()), heads, cfg=cfg)
+        assert relerr(S, wgt) < TOL
+        assert relerr(got.permute(0, 2, 1), ref) < TOL
+
+
+def test_softmax_spike_rows():
+    import hipops, ctypes
+    from anoddpm_amd._lib import SoftmaxArgs, check, lib, current_stream
+    x = rnd(37, 200, seed=5) * 30
+    x[3, 7] = 500.0
+    d = x.to(dev()).clone()
+    sm = SoftmaxArgs()
+    sm.x, sm.rows, sm.L = d.data_ptr(), 37, 200
+    check(lib().anoddpm_softmax_rows(ctypes.byref(sm), current_stream()))
+    torch.cuda.synchronize()
+    assert relerr(d, torch.softmax(x, -1)) < TOL
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_resample(mode):
+    import hipops
+    x = rnd(2, 64, 16, 16, seed=31)
+    ref = F.interpolate(x, scale_factor=2, mode="nearest") if mode == 1 else F.avg_pool2d(x, 2, 2)
+    got = hipops.resample(hipops.nhwc(x.to(dev())), mode)
+    assert torch.equal(hipops.nchw(got).cpu(), ref)
+
+
+@pytest.mark.parametrize("case", [(1, 128, 512, 0, 1), (4, 512, 512, 0, 0), (4, 512, 1000, 1, 0), (13, 64, 36, 1, 1)])
+def test_linear_small(case):
+    import hipops
+    B, K, N, ai, ao = case
+    x, w, b = rnd(B, K, seed=41), rnd(N, K, seed=42, scale=1 / math.sqrt(K)), rnd(N, seed=43)
+    ref = F.linear(F.silu(x) if ai else x, w, b)
+    ref = F.silu(ref) if ao else ref
+    assert relerr(hipops.linear(x.to(dev()), w.to(dev()), b.to(dev()), ai, ao), ref) < TOL
+
+
+def test_posemb_matches_reference_expression():
+    import hipops
+    from anoddpm_amd.unet import _posemb_freqs
+    t = torch.tensor([0, 1, 17, 500, 999])
+    for dim in (32, 128):
+        fr = _posemb_freqs(dim // 2)
+        arg = torch.outer(t * 1, fr)
+        ref = torch.cat((arg.sin(), arg.cos()), -1)
+        got = hipops.posemb(t.to(dev()), fr.to(dev()), dim).cpu()
+        assert (got - ref).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("case", [(2, 1, 32, 64), (1, 3, 64, 128), (1, 1, 16, 32)])
+def test_stem(case):
+    import hipops
+    B, Cin, H, Cout = case
+    x, w, b = rnd(B, Cin, H, H, seed=51), rnd(Cout, Cin, 3, 3, seed=52, scale=0.3), rnd(Cout, seed=53)
+    ref = F.conv2d(x, w, b, padding=1)
+    got = hipops.stem(x.to(dev()), w.to(dev()), b.to(dev()))
+    assert relerr(hipops.nchw(got), ref) < TOL
