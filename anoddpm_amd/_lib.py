@@ -114,6 +114,22 @@ class AnoddpmError(RuntimeError):
     pass
 
 
+def _preload_torch_hip_runtime():
+    """libanoddpm_hip.so must share ONE HIP runtime with PyTorch (streams, device pointers).  The torch
+    wheel bundles its own libamdhip64 (SONAME libamdhip64.so.7, the same as /opt/rocm's); whichever copy is
+    mapped first satisfies later DT_NEEDED lookups, so torch's copy is mapped before our library."""
+    import glob
+    import torch  # noqa: F401  (maps libtorch_hip and its bundled runtime)
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        for path in glob.glob(os.path.join(tl, name + "*")):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+            break
+
+
 def lib():
     """Load the HIP library (once).  Fails loudly: this package has no other compute path."""
     global _lib
@@ -123,6 +139,7 @@ def lib():
         raise AnoddpmError(
             f"{SO_PATH} is missing: build it with `python -m anoddpm_amd.build` "
             "(hipcc --offload-arch=gfx950).  anoddpm_amd has no CPU / eager fallback.")
+    _preload_torch_hip_runtime()
     L = ctypes.CDLL(SO_PATH)
     L.anoddpm_last_error.restype = ctypes.c_char_p
     L.anoddpm_struct_size.argtypes = [c_int32]

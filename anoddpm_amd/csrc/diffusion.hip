@@ -103,9 +103,9 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 extern "C" int anoddpm_q_sample(float *out, const float *x, const float *noise, const int64_t *t,
                                 const float *ca, const float *cb, int32_t B, int64_t n, int32_t T, void *stream)
 {
-    ANODDPM_REQUIRE(out && x && noise && t && ca && cb, "q_sample: null pointer");
     ANODDPM_REQUIRE(B >= 0 && n >= 0 && T > 0, "q_sample: bad sizes");
-    if (B == 0 || n == 0) return ANODDPM_OK;
+    if (B == 0 || n == 0) return ANODDPM_OK;            // empty batch: nothing to do (pointers may be null)
+    ANODDPM_REQUIRE(out && x && noise && t && ca && cb, "q_sample: null pointer");
     ANODDPM_REQUIRE(B <= 65535, "q_sample: B > 65535");
     const bool v4 = (n % 4 == 0) && aligned16(out) && aligned16(x) && aligned16(noise);
     const int64_t work = v4 ? n / 4 : n;
@@ -119,10 +119,11 @@ extern "C" int anoddpm_q_sample(float *out, const float *x, const float *noise, 
 
 extern "C" int anoddpm_p_sample_update(const anoddpm_p_update_args *a, void *stream)
 {
-    ANODDPM_REQUIRE(a && a->x_prev && a->x_t && a->eps && a->t, "p_sample_update: null pointer");
-    ANODDPM_REQUIRE(a->c_recip && a->c_recipm1 && a->c_coef1 && a->c_coef2 && a->c_sigma, "p_sample_update: null table");
+    ANODDPM_REQUIRE(a, "p_sample_update: null argument struct");
     ANODDPM_REQUIRE(a->B >= 0 && a->n >= 0 && a->T > 0, "p_sample_update: bad sizes");
     if (a->B == 0 || a->n == 0) return ANODDPM_OK;
+    ANODDPM_REQUIRE(a->x_prev && a->x_t && a->eps && a->t, "p_sample_update: null pointer");
+    ANODDPM_REQUIRE(a->c_recip && a->c_recipm1 && a->c_coef1 && a->c_coef2 && a->c_sigma, "p_sample_update: null table");
     ANODDPM_REQUIRE(a->B <= 65535, "p_sample_update: B > 65535");
     const bool v4 = (a->n % 4 == 0) && aligned16(a->x_prev) && aligned16(a->x_t) && aligned16(a->eps) &&
                     (!a->noise || aligned16(a->noise)) && (!a->pred_x0 || aligned16(a->pred_x0)) &&

@@ -103,8 +103,8 @@ def test_simplex_noise_path_matches_oracle_and_rng_order():
     t = torch.tensor([249], device=DEV)
     np.random.seed(99)
     got = d.noise_fn(x, t)
+    o = OracleSimplex(3)                                          # explicit seed: the constructor draws nothing
     np.random.seed(99)
-    o = OracleSimplex(None)
     for c in range(2):
         o.newSeed()                                               # one fresh seed per channel (:101-102)
         ref = o.rand_3d_fixed_T_octaves((48, 40), np.array([249]), 6, 0.8, 64)[0].astype(np.float32)
@@ -113,8 +113,8 @@ def test_simplex_noise_path_matches_oracle_and_rng_order():
     np.random.seed(5)
     eps = torch.zeros_like(x)
     out = d.sample_p(lambda a, b: eps, x, t, denoise_fn="simplex")
+    o2 = OracleSimplex(3)
     np.random.seed(5)
-    o2 = OracleSimplex(None)
     o2.newSeed()
     n0 = o2.rand_3d_fixed_T_octaves((48, 40), np.array([249]), 6, 0.8, 64)[0].astype(np.float32)
     from oracle import diffusion_oracle as do
