@@ -69,12 +69,18 @@ def fill_weights(model, seed=1234):
                 p.copy_(torch.randn(p.shape, generator=g) * max(0.02, 1.0 / np.sqrt(fan_in)))
 
 
-def cpu_baseline(cfg, steps=3):
+def cpu_baseline(cfg, steps=2):
     """The reference's CPU path restated (oracle/unet_oracle.py + simplex oracle + diffusion oracle), one
     image, timed on the host cores: warm-up 1, then `steps` full reverse steps."""
     from oracle import unet_oracle as uo, diffusion_oracle as do
     from oracle.simplex_oracle import OracleSimplex
-    cores = os.cpu_count() or 1
+    # host threads actually used: all cores the process may run on, capped at 64 (the stock ATen CPU
+    # kernels stop scaling -- and with SMT siblings regress badly -- beyond that on the 256-thread hosts)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 64))
     torch.set_num_threads(cores)
     kw = dict(img_size=cfg["img"], base_channels=cfg["base"], channel_mults=cfg["mults"],
               attention_resolutions=cfg["attn"], n_heads=cfg["heads"])
