@@ -14,8 +14,10 @@
 // halo tile ((TH+2) x (TW+2) pixels x 32 channels, staged once per 32-channel slice of K and
 // transformed -- affine, SiLU, resample -- exactly once on the way in).  The weight tile for
 // (tap, K-slice) is [8][BN][4] floats so that each lane's four consecutive k values are one
-// ds_read_b128; the next weight tile is prefetched into registers while the current one feeds the
-// MFMAs.  K order inside a 32-slice is permuted (lane half h takes k = 8j+4h..8j+4h+3) -- legal
+// ds_read_b128.  Pipeline: weight tiles are double-buffered in LDS and loaded two K-steps ahead
+// (registers for one step, LDS for the next) so a K-step costs ONE barrier; the raw halo tile of the
+// NEXT K-slice sits in registers for the nine taps of the current slice, so HBM/L2 latency of the
+// activation stream is never on the critical path.  K order inside a 32-slice is permuted (lane half h takes k = 8j+4h..8j+4h+3) -- legal
 // because A and B use the same permutation.
 //
 // LDS layout.  A: [pixel][8 quads] with the quad index XOR-ed by (pixel>>1)&7, which spreads the 16
@@ -35,16 +37,17 @@ constexpr int KC = 32;  // K slice held in LDS
 
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void igemm_kernel(const anoddpm_igemm_args a, const int log2TW, const int TH, const int tiles_x)
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const anoddpm_igemm_args a, const int log2TW, const int TH, const int tiles_x)
 {
     constexpr int MT = BM / 64, NT = BN / 64;          // 32x32 MFMA tiles per wave (2x2 waves)
     constexpr int APIX = (BM == 128) ? 204 : 136;      // largest halo tile in pixels
+    constexpr int AJ = (APIX + 31) / 32;               // A float4 slots per thread per K-slice
     constexpr int BJ = 8 * BN / 256;                   // B float4 slots per thread per step
-    __shared__ __attribute__((aligned(16))) float lds[APIX * KC + 8 * BN * 4];
+    constexpr int BTILE = 8 * BN * 4;                  // floats per weight tile
+    __shared__ __attribute__((aligned(16))) float lds[APIX * KC + 2 * BTILE];
     f32x4 *ldsA = reinterpret_cast<f32x4 *>(lds);
-    f32x4 *ldsB = reinterpret_cast<f32x4 *>(lds + APIX * KC);
-    float *ldsBf = lds + APIX * KC;
+    float *ldsBbase = lds + APIX * KC;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -73,6 +76,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const anoddpm_igemm_args a, 
     const float *Bm = a.b_mode ? a.bmat + (int64_t)b * a.b_bs + (int64_t)hd * a.b_hs : a.bmat;
     const float *gsc = a.gn_scale ? a.gn_scale + (int64_t)b * a.gn_ld : nullptr;
     const float *gsh = a.gn_shift ? a.gn_shift + (int64_t)b * a.gn_ld : nullptr;
+    const bool affine = (gsc != nullptr);
+    const bool act = a.act != 0;
+    const int a_mode = a.a_mode;
 
     const int nchunks = (K + KC - 1) / KC;
     const int cps = (nchunks + ksplit - 1) / ksplit;
@@ -99,38 +105,72 @@ __global__ __launch_bounds__(256) void igemm_kernel(const anoddpm_igemm_args a, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+    // ---- B tile: global -> registers -> LDS (double buffered) -------------------------------------
+    // All prefetch loads are UNCONDITIONAL (indices clamped in-bounds, result selected to zero
+    // afterwards): a predicated load makes hipcc branch around it and wait vmcnt(0) per element.
+    // CONV (packed weights, K % 32 == 0): the per-thread element offset is fixed, only a uniform
+    // (tap, K-slice) base moves -> one 32-bit add per load in the loop.
     f32x4 breg[BJ];
-
-    // ---- B tile: global -> registers ----------------------------------------------------------
-    auto load_B = [&](int step) {
-        const int chunk = c_begin + step / taps;
-        const int tap = step % taps;
-        const int kbase = chunk * KC;
+    int boff[BJ];            // CONV: element offset inside a [8][N][4] slab; else unused
+    unsigned bok = 0;
+    if (CONV) {
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int idx = tid + j * 256;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int r = idx / BN, n = idx % BN;
+            const int nc = n0 + n < N ? n0 + n : N - 1;
+            boff[j] = (r * N + nc) * 4;
+            bok |= (n0 + n < N ? 1u : 0u) << j;
+        }
+    }
+    auto load_B = [&](int chunk, int tap) {
+        const int kbase = chunk * KC;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (CONV) {
+            const float *base = Bm + ((int64_t)tap * K4 + (kbase >> 2)) * N * 4;     // uniform
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) {
+                const f32x4 v = ld4(base + boff[j]);
+                breg[j] = ((bok >> j) & 1) ? v : zero;
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int idx = tid + j * 256;
+            f32x4 v;
+            bool ok;
             if (a.b_mode == 0) {
                 const int r = idx / BN, n = idx % BN;
                 const int k4 = (kbase >> 2) + r;
-                if (k4 < K4 && n0 + n < N)
-                    v = ld4(Bm + (((int64_t)tap * K4 + k4) * N + n0 + n) * 4);
+                ok = (k4 < K4) && (n0 + n < N);
+                const int k4c = k4 < K4 ? k4 : K4 - 1;
+                const int nc = n0 + n < N ? n0 + n : N - 1;
+                v = ld4(Bm + (((int64_t)tap * K4 + k4c) * N + nc) * 4);
             } else if (a.b_mode == 1) {            // rows [N][K]: B[k][n] = src[n][k]
                 const int n = idx >> 3, r = idx & 7;
                 const int k = kbase + r * 4;
-                if (k < K && n0 + n < N) v = ld4(Bm + (int64_t)(n0 + n) * a.ldb + k);
+                ok = (k < K) && (n0 + n < N);
+                const int kc = k < K ? k : 0;
+                const int nc = n0 + n < N ? n0 + n : N - 1;
+                v = ld4(Bm + (int64_t)nc * a.ldb + kc);
             } else {                               // rows [K][N]
                 const int k = idx / (BN / 4), n4 = idx % (BN / 4);
-                if (kbase + k < K && n0 + n4 * 4 < N) v = ld4(Bm + (int64_t)(kbase + k) * a.ldb + n0 + n4 * 4);
+                ok = (kbase + k < K) && (n0 + n4 * 4 < N);
+                const int kc = kbase + k < K ? kbase + k : 0;
+                const int nc = n0 + n4 * 4 < N ? n0 + n4 * 4 : 0;
+                v = ld4(Bm + (int64_t)kc * a.ldb + nc);
             }
-            breg[j] = v;
+            breg[j] = ok ? v : zero;
         }
     };
-    auto store_B = [&]() {
+    auto store_B = [&](int buf) {
+        float *ldsBf = ldsBbase + buf * BTILE;
+        f32x4 *ldsB = reinterpret_cast<f32x4 *>(ldsBf);
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int idx = tid + j * 256;
-            if (a.b_mode == 0) {
+            if (CONV || a.b_mode == 0) {
                 ldsB[idx] = breg[j];               // idx = r*BN + n already
             } else if (a.b_mode == 1) {
                 const int n = idx >> 3, r = idx & 7;
@@ -146,69 +186,111 @@ __global__ __launch_bounds__(256) void igemm_kernel(const anoddpm_igemm_args a, 
         }
     };
 
-    // ---- A halo tile: global -> (affine, SiLU, resample) -> LDS --------------------------------
-    auto stage_A = [&](int chunk) {
+    // ---- A halo tile: global -> registers (one K-slice ahead) -> (affine, SiLU, resample) -> LDS ----
+    const int c4 = tid & 7;                 // this thread's channel quad inside the 32-channel slice
+    f32x4 areg[AJ];
+    f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
+    unsigned avalid = 0;
+    auto xform = [&](f32x4 v) {
+        if (affine) v = v * asc + ash;
+        if (act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+        return v;
+    };
+    // halo geometry is fixed for the block: source pixel index per slot (-1 = zero padding / unused)
+    int spix[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int p = (tid >> 3) + j * 32;
+        const int hy = p / HP, hx = p - hy * HP;
+        const int gy = y0 + hy - pad, gx = x0 + hx - pad;
+        int sp = -1;
+        if (p < npix && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            if (a_mode == 0)      sp = gy * W + gx;
+            else if (a_mode == 1) sp = (gy >> 1) * (W >> 1) + (gx >> 1);
+            else                  sp = (2 * gy) * (2 * W) + 2 * gx;
+        }
+        spix[j] = sp;
+    }
+    auto slice_src = [&](int chunk, const float *&src, int &ld, bool &kvalid) {
         const int kbase = chunk * KC;
-        const float *src;
-        int ld, koff;
+        int koff;
         if (kbase < a.c0) { src = A0; ld = a.a0_ld; koff = kbase; }
         else              { src = A1; ld = a.a1_ld; koff = kbase - a.c0; }
-        const int c4 = tid & 7;
         const int k = kbase + c4 * 4;
-        const bool kvalid = k < K;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        const bool affine = (gsc != nullptr);
-        if (affine && kvalid) { sc = ld4(gsc + k); sh = ld4(gsh + k); }
-        const bool act = a.act != 0;
-        auto xform = [&](f32x4 v) {
-            if (affine) v = v * sc + sh;
-            if (act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
-            return v;
-        };
-        src += koff + c4 * 4;
-        for (int p = tid >> 3; p < npix; p += 32) {
-            const int hy = p / HP, hx = p - hy * HP;
-            const int gy = y0 + hy - pad, gx = x0 + hx - pad;
+        kvalid = k < K;
+        src += kvalid ? koff + c4 * 4 : 0;                   // K tail: stay in-bounds, value is discarded
+        if (affine) { const int kc = kvalid ? k : 0; asc = ld4(gsc + kc); ash = ld4(gsh + kc); }
+    };
+    auto load_A = [&](int chunk) {          // a_mode 0 / 1: raw values into registers (unconditional loads)
+        const float *src; int ld; bool kvalid;
+        slice_src(chunk, src, ld, kvalid);
+        avalid = 0;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const bool ok = kvalid && spix[j] >= 0;
+            const int sp = spix[j] >= 0 ? spix[j] : 0;
+            areg[j] = ld4(src + (int64_t)sp * ld);           // padding / tail slots read pixel 0 and are discarded
+            avalid |= (ok ? 1u : 0u) << j;
+        }
+    };
+    auto store_A = [&]() {                  // registers -> transform -> LDS (zero padding AFTER the transform)
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int p = (tid >> 3) + j * 32;
+            if (p < npix) ldsA[p * 8 + (c4 ^ ((p >> 1) & 7))] = ((avalid >> j) & 1) ? xform(areg[j]) : zero;
+        }
+    };
+    auto stage_A_pool = [&](int chunk) {    // a_mode 2: source is (2H, 2W); mean of the 4 transformed values
+        const float *src; int ld; bool kvalid;
+        slice_src(chunk, src, ld, kvalid);
+        const int64_t w2 = (int64_t)W * 2;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int p = (tid >> 3) + j * 32;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (kvalid && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                if (a.a_mode == 0) {
-                    v = xform(ld4(src + ((int64_t)gy * W + gx) * ld));
-                } else if (a.a_mode == 1) {        // source is (H/2, W/2): nearest x2
-                    v = xform(ld4(src + ((int64_t)(gy >> 1) * (W >> 1) + (gx >> 1)) * ld));
-                } else {                           // source is (2H, 2W): 2x2 mean of transformed values
-                    const int64_t w2 = (int64_t)W * 2;
-                    const float *q = src + ((int64_t)(2 * gy) * w2 + 2 * gx) * ld;
-                    const f32x4 v00 = xform(ld4(q)), v01 = xform(ld4(q + ld));
-                    const f32x4 v10 = xform(ld4(q + w2 * ld)), v11 = xform(ld4(q + (w2 + 1) * ld));
-                    v = (((v00 + v01) + v10) + v11) * 0.25f;
-                }
+            if (kvalid && spix[j] >= 0) {
+                const float *q = src + (int64_t)spix[j] * ld;
+                const f32x4 r00 = ld4(q), r01 = ld4(q + ld), r10 = ld4(q + w2 * ld), r11 = ld4(q + (w2 + 1) * ld);
+                v = (((xform(r00) + xform(r01)) + xform(r10)) + xform(r11)) * 0.25f;
             }
-            ldsA[p * 8 + (c4 ^ ((p >> 1) & 7))] = v;
+            if (p < npix) ldsA[p * 8 + (c4 ^ ((p >> 1) & 7))] = v;
         }
     };
 
-    // ---- main loop -----------------------------------------------------------------------------
-    if (nsteps > 0) load_B(0);
-    for (int step = 0; step < nsteps; ++step) {
-        const int tap = step % taps;
-        __syncthreads();                            // previous step's LDS reads are done
-        store_B();
-        if (tap == 0) stage_A(c_begin + step / taps);
+    // ---- main loop: one barrier per K-step, loads one step (B) / one K-slice (A) ahead ---------------
+    // (tap, slice) of the step being computed and of the B tile being fetched are carried as counters:
+    // no runtime division in the loop.
+    int ld_tap = 0, ld_chunk = c_begin;          // next B tile to fetch
+    auto advance_ld = [&]() { if (++ld_tap == taps) { ld_tap = 0; ++ld_chunk; } };
+    if (nsteps > 0) {
+        load_B(ld_chunk, ld_tap); advance_ld();
+        if (a_mode == 2) stage_A_pool(c_begin);
+        else { load_A(c_begin); store_A(); }
+        store_B(0);
+        if (nsteps > 1) { load_B(ld_chunk, ld_tap); advance_ld(); }
+        if (a_mode != 2 && c_begin + 1 < c_end) load_A(c_begin + 1);
         __syncthreads();
-        if (step + 1 < nsteps) load_B(step + 1);    // in flight during the MFMAs below
-
-        const int tapoff = (KS == 3) ? (tap / 3) * HP + (tap % 3) : 0;
+    }
+    int tap = 0, chunk = c_begin, tapoff = 0, tx = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < nsteps) {
+            store_B(cur ^ 1);                            // tile for step+1 (its loads had a full step to land)
+            if (step + 2 < nsteps) { load_B(ld_chunk, ld_tap); advance_ld(); }
+        }
+        const f32x4 *ldsB = reinterpret_cast<const f32x4 *>(ldsBbase + cur * BTILE);
         int pA[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) pA[mt] = pixbase[mt] + tapoff;
 #pragma unroll
         for (int k8 = 0; k8 < KC / 8; ++k8) {
-            const int c4 = k8 * 2 + h;
+            const int q = k8 * 2 + h;
             f32x4 av[MT], bv[NT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = ldsA[pA[mt] * 8 + (c4 ^ ((pA[mt] >> 1) & 7))];
+            for (int mt = 0; mt < MT; ++mt) av[mt] = ldsA[pA[mt] * 8 + (q ^ ((pA[mt] >> 1) & 7))];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = ldsB[c4 * BN + ncol[nt]];
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = ldsB[q * BN + ncol[nt]];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -217,41 +299,67 @@ __global__ __launch_bounds__(256) void igemm_kernel(const anoddpm_igemm_args a, 
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][kk], bv[nt][kk], acc[mt][nt], 0, 0, 0);
         }
+        // advance (tap, slice); tapoff walks the 3x3 window: +1 along x, then down one halo row
+        ++tap; ++tx; ++tapoff;
+        if (tx == KS) { tx = 0; tapoff += HP - KS; }
+        if (tap == taps) {
+            tap = 0; tx = 0; tapoff = 0; ++chunk;
+            if (step + 1 < nsteps) {                     // K-slice boundary: replace the halo tile
+                __syncthreads();                         // every wave is done reading ldsA
+                if (a_mode == 2) stage_A_pool(chunk);
+                else {
+                    store_A();
+                    if (chunk + 1 < c_end) load_A(chunk + 1);
+                }
+            }
+        }
+        __syncthreads();
     }
 
     // ---- epilogue --------------------------------------------------------------------------------
+    // Two phases per 32x32 tile: ALL residual loads are issued first, then the adds and stores.  (A
+    // load->add->store chain per element is serialised by the possible aliasing of `res` and `out`:
+    // 64 dependent L2 round trips per thread.)
     const int P = H * W;
     const int Z = a.B * a.heads;
-    float *O = a.out + (int64_t)b * a.o_bs + (int64_t)hd * a.o_hs;
-    const float *R = a.res ? a.res + (int64_t)b * a.r_bs + (int64_t)hd * a.r_hs : nullptr;
+    float *__restrict__ O = a.out + (int64_t)b * a.o_bs + (int64_t)hd * a.o_hs;
+    const float *__restrict__ R = a.res ? a.res + (int64_t)b * a.r_bs + (int64_t)hd * a.r_hs : nullptr;
     const float *TE = a.temb ? a.temb + (int64_t)b * a.temb_ld : nullptr;
+    float *__restrict__ WS = ksplit > 1 ? a.ws + ((int64_t)ksi * Z + z) * P * N : nullptr;
+    // per-lane row geometry: pixel index of row r of tile mt (or -1 outside the image)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        int pixr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = (wm * MT + mt) * 32 + row;
+            const int oy = y0 + (m >> log2TW), ox = x0 + (m & (TW - 1));
+            pixr[r] = (oy < H && ox < W) ? oy * W + ox : -1;
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int n = n0 + ncol[nt];
-            if (n >= N) continue;
-            float add = 0.f;
-            if (ksplit == 1) {
-                if (a.bias) add += a.bias[n];
-                if (TE) add += TE[n];
+            const bool nok = n < N;
+            const int nc = nok ? n : 0;
+            if (ksplit > 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (nok && pixr[r] >= 0) WS[(int64_t)pixr[r] * N + nc] = acc[mt][nt][r];
+                continue;
             }
+            float add = 0.f;
+            if (a.bias) add += a.bias[nc];
+            if (TE) add += TE[nc];
+            float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int m = (wm * MT + mt) * 32 + row;
-                const int oy = y0 + (m >> log2TW), ox = x0 + (m & (TW - 1));
-                if (oy >= H || ox >= W) continue;              // partial tile on tiny feature maps
-                const int64_t pix = (int64_t)oy * W + ox;
-                float v = acc[mt][nt][r];
-                if (ksplit > 1) {
-                    a.ws[(((int64_t)ksi * Z + z) * P + pix) * N + n] = v;
-                } else {
-                    v = a.alpha * v + add;
-                    if (R) v += R[pix * a.res_ld + n];
-                    O[pix * a.out_ld + n] = v;
-                }
+                const int pc = pixr[r] >= 0 ? pixr[r] : 0;
+                rv[r] = R ? R[(int64_t)pc * a.res_ld + nc] : 0.f;       // unconditional, clamped
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (nok && pixr[r] >= 0) O[(int64_t)pixr[r] * a.out_ld + nc] = a.alpha * acc[mt][nt][r] + add + rv[r];
         }
     }
 }
@@ -331,8 +439,14 @@ extern "C" int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream)
     dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((a->N + BN - 1) / BN), (unsigned)(Z * a->ksplit));
     ANODDPM_REQUIRE(grid.y <= 65535 && Z * a->ksplit <= 65535, "igemm: grid too large");
     hipStream_t s = anoddpm::as_stream(stream);
-    if (BM == 128) hipLaunchKernelGGL((igemm_kernel<128, 128>), grid, dim3(256), 0, s, k, log2TW, TH, tiles_x);
-    else           hipLaunchKernelGGL((igemm_kernel<64, 64>), grid, dim3(256), 0, s, k, log2TW, TH, tiles_x);
+    const bool conv = (a->b_mode == 0) && ((a->c0 + a->c1) % KC == 0);
+    if (BM == 128) {
+        if (conv) hipLaunchKernelGGL((igemm_kernel<128, 128, true>), grid, dim3(256), 0, s, k, log2TW, TH, tiles_x);
+        else      hipLaunchKernelGGL((igemm_kernel<128, 128, false>), grid, dim3(256), 0, s, k, log2TW, TH, tiles_x);
+    } else {
+        if (conv) hipLaunchKernelGGL((igemm_kernel<64, 64, true>), grid, dim3(256), 0, s, k, log2TW, TH, tiles_x);
+        else      hipLaunchKernelGGL((igemm_kernel<64, 64, false>), grid, dim3(256), 0, s, k, log2TW, TH, tiles_x);
+    }
     if (a->ksplit > 1) {
         const int64_t total = Z * P * (a->N / 4);
         const int64_t blocks = (total + 255) / 256;

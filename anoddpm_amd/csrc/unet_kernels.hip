@@ -75,31 +75,44 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(anoddpm_gn_args a)
 
 __global__ __launch_bounds__(256) void gn_finalize_kernel(anoddpm_gn_args a)
 {
+    __shared__ double red_s[256];
+    __shared__ double red_q[256];
     __shared__ double mean_s[64];
     __shared__ double rstd_s[64];
     const int C = a.c0 + a.c1;
     const int cpg = C / a.groups;
     const int b = blockIdx.x;
-    if ((int)threadIdx.x < a.groups) {
-        double s = 0.0, q = 0.0;
-        for (int k = 0; k < a.nslab; ++k) {
-            const double *src = a.partial + ((int64_t)(b * a.nslab + k) * a.groups + threadIdx.x) * 2;
+    const int tid = threadIdx.x;
+    // slab partials are folded by all 256 threads: thread = (slab lane, group), fixed order -> deterministic
+    const int lanes = 256 / a.groups;                  // slab lanes per group (groups <= 64)
+    const int g = tid % a.groups, sl = tid / a.groups;
+    double s = 0.0, q = 0.0;
+    if (sl < lanes) {
+        for (int k = sl; k < a.nslab; k += lanes) {
+            const double *src = a.partial + ((int64_t)(b * a.nslab + k) * a.groups + g) * 2;
             s += src[0];
             q += src[1];
         }
+    }
+    red_s[tid] = s;
+    red_q[tid] = q;
+    __syncthreads();
+    if (tid < a.groups) {
+        double ts = 0.0, tq = 0.0;
+        for (int l = 0; l < lanes; ++l) { ts += red_s[l * a.groups + tid]; tq += red_q[l * a.groups + tid]; }
         const double n = (double)a.P * cpg;
-        const double mean = s / n;
-        double var = q / n - mean * mean;
+        const double mean = ts / n;
+        double var = tq / n - mean * mean;
         var = var > 0.0 ? var : 0.0;
-        mean_s[threadIdx.x] = mean;
-        rstd_s[threadIdx.x] = 1.0 / sqrt(var + (double)a.eps);
+        mean_s[tid] = mean;
+        rstd_s[tid] = 1.0 / sqrt(var + (double)a.eps);
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g = c / cpg;
-        const double sc = rstd_s[g] * (double)a.gamma[c];
+    for (int c = tid; c < C; c += blockDim.x) {
+        const int gg = c / cpg;
+        const double sc = rstd_s[gg] * (double)a.gamma[c];
         a.scale[(int64_t)b * C + c] = (float)sc;
-        a.shift[(int64_t)b * C + c] = (float)((double)a.beta[c] - mean_s[g] * sc);
+        a.shift[(int64_t)b * C + c] = (float)((double)a.beta[c] - mean_s[gg] * sc);
     }
 }
 
