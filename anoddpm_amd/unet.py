@@ -208,8 +208,14 @@ class UNetModel(nn.Module):
         self.up = nn.ModuleList([seq(b) for b in up])
         self.out = _indexed(_0=_Affine(out_ch), _2=_Weights((in_channels, self._final_cin, 3, 3), zero=True))
         self._plans = {}
+        self._weights_epoch = 0
 
     # ------------------------------------------------------------------ helpers
+    def mark_weights_changed(self):
+        """Tell the compiled plans that parameters were modified behind autograd's back (e.g. by the
+        fused optimizer kernel, which writes the flat parameter buffer directly)."""
+        self._weights_epoch += 1
+
     def _heads_for(self, c):
         return self.num_heads if self.num_head_channels == -1 else c // self.num_head_channels
 
@@ -397,7 +403,7 @@ class _Plan:
 
     def refresh_weights(self):
         params = list(self.model.parameters())
-        token = tuple((p.data_ptr(), p._version) for p in params)
+        token = (self.model._weights_epoch,) + tuple((p.data_ptr(), p._version) for p in params)
         if token == self.token:
             return
         named = dict(self.model.named_parameters())

@@ -1,0 +1,96 @@
+"""N>1 path on CPU: two gloo ranks.  The sharded gradient all-reduce must reproduce the single-process
+large-batch gradient, shards must tile the batch, and the bench's max-over-ranks timing
+reduction must work.  CPU only (the reducer is model-agnostic; HIP kernels are not involved)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from anoddpm_amd.training import FlatBuffers, GradAllReducer, shard_range
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _toy():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Conv2d(1, 8, 3, padding=1), torch.nn.SiLU(), torch.nn.Conv2d(8, 8, 3, padding=1),
+                               torch.nn.GroupNorm(4, 8), torch.nn.Conv2d(8, 1, 3, padding=1))
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(123)
+    x = torch.randn(8, 1, 12, 12)
+    tgt = torch.randn(8, 1, 12, 12)
+    model = _toy()
+    flat = FlatBuffers(model)
+    red = GradAllReducer(flat, bucket_bytes=256)            # tiny buckets -> several async all-reduces
+    assert len(red.buckets) > 2
+    lo, hi = shard_range(8, rank, world)
+    for _ in range(2):                                      # twice: hooks/buckets must reset correctly
+        flat.zero_grad()
+        loss = (model(x[lo:hi]) - tgt[lo:hi]).square().mean()
+        loss.backward()
+        red.finish()
+    # timing reduction used by bench.py: max over ranks
+    el = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    torch.save({"grad": flat.flat_grad.clone(), "max": el.item(), "range": (lo, hi)}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_matches_large_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+    torch.manual_seed(123)
+    x = torch.randn(8, 1, 12, 12)
+    tgt = torch.randn(8, 1, 12, 12)
+    model = _toy()
+    flat = FlatBuffers(model)
+    (model(x) - tgt).square().mean().backward()
+    ref = flat.flat_grad
+    for o in outs:
+        assert torch.allclose(o["grad"], ref, rtol=1e-5, atol=1e-7)
+        assert o["max"] == 2.0
+    assert torch.equal(outs[0]["grad"], outs[1]["grad"])            # identical on every rank -> one clip norm
+    assert [o["range"] for o in outs] == [(0, 4), (4, 8)]
+
+
+def test_shard_range_tiles_any_batch():
+    for n in (0, 1, 7, 8, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_flat_buffers_keep_module_semantics():
+    m = _toy()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    flat = FlatBuffers(m)
+    assert all(torch.equal(before[k], v) for k, v in m.state_dict().items())
+    assert all(p.data_ptr() == flat.flat_param.data_ptr() + 4 * o for p, o in zip(flat.params, flat.offsets))
+    (m(torch.ones(1, 1, 6, 6))).sum().backward()
+    assert flat.flat_grad.abs().sum() > 0
+    torch.optim.SGD(m.parameters(), lr=0.1).zero_grad(set_to_none=True)
+    flat.zero_grad()
+    assert all(p.grad is not None for p in flat.params) and flat.flat_grad.abs().sum() == 0
+    m.load_state_dict(before)
+    assert torch.equal(flat.flat_param[:flat.params[0].numel()].view_as(flat.params[0]), before["0.weight"])
