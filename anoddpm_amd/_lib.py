@@ -9,9 +9,9 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
-OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT = range(1, 9)
+OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE = range(1, 11)
 
 
 class SimplexArgs(Structure):
@@ -41,7 +41,7 @@ class IgemmArgs(Structure):
                 ("H", c_int32), ("W", c_int32), ("ks", c_int32), ("a_mode", c_int32), ("act", c_int32),
                 ("b_mode", c_int32), ("ldb", c_int32), ("N", c_int32), ("temb_ld", c_int32),
                 ("out_ld", c_int32), ("res_ld", c_int32), ("B", c_int32), ("heads", c_int32),
-                ("ksplit", c_int32), ("cfg", c_int32), ("alpha", c_float), ("gn_ld", c_int32)]
+                ("ksplit", c_int32), ("cfg", c_int32), ("alpha", c_float), ("gn_ld", c_int32), ("stats", c_void_p)]
 
 
 class GnArgs(Structure):
@@ -50,6 +50,18 @@ class GnArgs(Structure):
                 ("a0_bs", c_int64), ("a1_bs", c_int64),
                 ("c0", c_int32), ("c1", c_int32), ("a0_ld", c_int32), ("a1_ld", c_int32),
                 ("P", c_int32), ("B", c_int32), ("groups", c_int32), ("nslab", c_int32), ("eps", c_float)]
+
+
+class ChanStatsArgs(Structure):
+    _fields_ = [("a", c_void_p), ("stats", c_void_p), ("a_bs", c_int64),
+                ("C", c_int32), ("a_ld", c_int32), ("P", c_int32), ("B", c_int32), ("nslab", c_int32)]
+
+
+class GnFinalizeArgs(Structure):
+    _fields_ = [("stats0", c_void_p), ("stats1", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("scale", c_void_p), ("shift", c_void_p),
+                ("rows0", c_int32), ("rows1", c_int32), ("c0", c_int32), ("c1", c_int32),
+                ("P", c_int32), ("B", c_int32), ("groups", c_int32), ("eps", c_float)]
 
 
 class SoftmaxArgs(Structure):
@@ -93,7 +105,7 @@ class AdamwArgs(Structure):
 
 
 _STRUCTS = [SimplexArgs, PUpdateArgs, IgemmArgs, GnArgs, SoftmaxArgs, ResampleArgs, LinearArgs,
-            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs]
+            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs]
 
 # every symbol include/anoddpm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -101,7 +113,7 @@ SYMBOLS = [
     "anoddpm_simplex_perm_init", "anoddpm_simplex3_octaves_f64", "anoddpm_simplex3_octaves_f32",
     "anoddpm_simplex3_grid_f64",
     "anoddpm_q_sample", "anoddpm_p_sample_update", "anoddpm_chain_advance",
-    "anoddpm_igemm", "anoddpm_gn_stats", "anoddpm_softmax_rows", "anoddpm_resample2x",
+    "anoddpm_igemm", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
     "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_nhwc_to_nchw",
     "anoddpm_run_ops", "anoddpm_prof_enable", "anoddpm_prof_collect",
     "anoddpm_adamw_ema", "anoddpm_sumsq",
@@ -159,6 +171,8 @@ def lib():
     L.anoddpm_chain_advance.argtypes = [c_void_p, c_int32, c_void_p, c_void_p]
     L.anoddpm_igemm.argtypes = [POINTER(IgemmArgs), c_void_p]
     L.anoddpm_gn_stats.argtypes = [POINTER(GnArgs), c_void_p]
+    L.anoddpm_chan_stats.argtypes = [POINTER(ChanStatsArgs), c_void_p]
+    L.anoddpm_gn_finalize.argtypes = [POINTER(GnFinalizeArgs), c_void_p]
     L.anoddpm_softmax_rows.argtypes = [POINTER(SoftmaxArgs), c_void_p]
     L.anoddpm_resample2x.argtypes = [POINTER(ResampleArgs), c_void_p]
     L.anoddpm_linear_small.argtypes = [POINTER(LinearArgs), c_void_p]

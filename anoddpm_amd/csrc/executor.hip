@@ -39,6 +39,8 @@ static int dispatch(const anoddpm_op &op, void *stream)
         case ANODDPM_OP_POSEMB: return anoddpm_posemb(static_cast<const anoddpm_posemb_args *>(op.args), stream);
         case ANODDPM_OP_STEM: return anoddpm_conv_stem(static_cast<const anoddpm_stem_args *>(op.args), stream);
         case ANODDPM_OP_LAYOUT: return anoddpm_nhwc_to_nchw(static_cast<const anoddpm_layout_args *>(op.args), stream);
+        case ANODDPM_OP_CHAN_STATS: return anoddpm_chan_stats(static_cast<const anoddpm_chan_stats_args *>(op.args), stream);
+        case ANODDPM_OP_GN_FINALIZE: return anoddpm_gn_finalize(static_cast<const anoddpm_gn_finalize_args *>(op.args), stream);
         default: set_error("run_ops: unknown op code %d", op.code); return ANODDPM_EINVAL;
     }
 }
@@ -47,7 +49,7 @@ static int dispatch(const anoddpm_op &op, void *stream)
 
 using namespace anoddpm;
 
-extern "C" int anoddpm_abi_version(void) { return 1; }
+extern "C" int anoddpm_abi_version(void) { return 2; }
 
 extern "C" const char *anoddpm_last_error(void) { return g_err; }
 
@@ -139,6 +141,8 @@ extern "C" int anoddpm_struct_size(int32_t which)
         case 9: return (int)sizeof(anoddpm_layout_args);
         case 10: return (int)sizeof(anoddpm_op);
         case 11: return (int)sizeof(anoddpm_adamw_args);
+        case 12: return (int)sizeof(anoddpm_chan_stats_args);
+        case 13: return (int)sizeof(anoddpm_gn_finalize_args);
         default: return -1;
     }
 }

@@ -326,6 +326,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const anoddpm_igemm_args 
     const float *__restrict__ R = a.res ? a.res + (int64_t)b * a.r_bs + (int64_t)hd * a.r_hs : nullptr;
     const float *TE = a.temb ? a.temb + (int64_t)b * a.temb_ld : nullptr;
     float *__restrict__ WS = ksplit > 1 ? a.ws + ((int64_t)ksi * Z + z) * P * N : nullptr;
+    // fused GroupNorm statistics: per-column (= output channel) sums over this wave's rows
+    float cs[NT], cq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { cs[nt] = 0.f; cq[nt] = 0.f; }
     // per-lane row geometry: pixel index of row r of tile mt (or -1 outside the image)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -358,8 +362,25 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const anoddpm_igemm_args 
                 rv[r] = R ? R[(int64_t)pc * a.res_ld + nc] : 0.f;       // unconditional, clamped
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (nok && pixr[r] >= 0) O[(int64_t)pixr[r] * a.out_ld + nc] = a.alpha * acc[mt][nt][r] + add + rv[r];
+            for (int r = 0; r < 16; ++r) {
+                const float v = a.alpha * acc[mt][nt][r] + add + rv[r];
+                if (nok && pixr[r] >= 0) {
+                    O[(int64_t)pixr[r] * a.out_ld + nc] = v;
+                    cs[nt] += v;
+                    cq[nt] += v * v;
+                }
+            }
+        }
+    }
+    if (a.stats && ksplit == 1) {
+        // rows of this wave = MT*32 pixels; lane halves hold different rows of the same column
+        float *st = a.stats + ((int64_t)b * (gridDim.x * 2) + blockIdx.x * 2 + wm) * N * 2;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float s2 = cs[nt] + __shfl_xor(cs[nt], 32);
+            const float q2 = cq[nt] + __shfl_xor(cq[nt], 32);
+            const int n = n0 + ncol[nt];
+            if (h == 0 && n < N) { st[n * 2] = s2; st[n * 2 + 1] = q2; }
         }
     }
 }
@@ -405,6 +426,7 @@ extern "C" int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream)
     ANODDPM_REQUIRE(a->a_mode == 0 || a->ks == 3, "igemm: resampling is only fused into 3x3 loads");
     ANODDPM_REQUIRE(a->b_mode == 0 || a->ks == 1, "igemm: activation B operands need ks == 1");
     ANODDPM_REQUIRE(a->b_mode != 2 || a->N % 4 == 0, "igemm: b_mode 2 needs N %% 4 == 0");
+    ANODDPM_REQUIRE(!a->stats || (a->ksplit == 1 && a->heads == 1), "igemm: fused statistics need ksplit == 1 and heads == 1");
     ANODDPM_REQUIRE(a->b_mode == 0 || a->ldb % 4 == 0, "igemm: ldb must be a multiple of 4");
     ANODDPM_REQUIRE(a->a0_ld % 4 == 0 && (a->c1 == 0 || a->a1_ld % 4 == 0), "igemm: pixel strides must be multiples of 4 floats");
     ANODDPM_REQUIRE(al16(a->a0) && al16(a->bmat) && (!a->a1 || al16(a->a1)), "igemm: operands must be 16-byte aligned");

@@ -116,6 +116,95 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(anoddpm_gn_args a)
     }
 }
 
+// Per-channel partial sums (same format as the igemm epilogue's fused statistics).
+__global__ __launch_bounds__(256) void chan_stats_kernel(anoddpm_chan_stats_args a)
+{
+    __shared__ float lds_s[256 * 4];
+    __shared__ float lds_q[256 * 4];
+    const int C4 = a.C >> 2;
+    const int TQ = C4 < 256 ? C4 : 256;
+    const int R = 256 / TQ;
+    const int npass = (C4 + TQ - 1) / TQ;
+    const int tid = threadIdx.x;
+    const int tq = tid % TQ, tr = tid / TQ;
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int sp = (a.P + a.nslab - 1) / a.nslab;
+    const int p0 = slab * sp;
+    const int p1 = (p0 + sp < a.P) ? p0 + sp : a.P;
+    float *out = a.stats + ((int64_t)b * a.nslab + slab) * a.C * 2;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int quad = pass * TQ + tq;
+        float s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        if (tr < R && quad < C4) {
+            const float *src = a.a + (int64_t)b * a.a_bs + quad * 4;
+            for (int p = p0 + tr; p < p1; p += R) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + (int64_t)p * a.a_ld);
+                s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+                q0 += v.x * v.x; q1 += v.y * v.y; q2 += v.z * v.z; q3 += v.w * v.w;
+            }
+        }
+        if (tr < R) {
+            const int o = (tr * TQ + tq) * 4;
+            lds_s[o] = s0; lds_s[o + 1] = s1; lds_s[o + 2] = s2; lds_s[o + 3] = s3;
+            lds_q[o] = q0; lds_q[o + 1] = q1; lds_q[o + 2] = q2; lds_q[o + 3] = q3;
+        }
+        __syncthreads();
+        for (int cl = tid; cl < TQ * 4; cl += 256) {
+            const int c = pass * TQ * 4 + cl;
+            if (c < a.C) {
+                float s = 0.f, q = 0.f;
+                for (int r = 0; r < R; ++r) { s += lds_s[r * TQ * 4 + cl]; q += lds_q[r * TQ * 4 + cl]; }
+                out[c * 2] = s;
+                out[c * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// grid (groups, B): fold per-channel partials of up to two sources into scale/shift for one group.
+__global__ __launch_bounds__(256) void gn_finalize2_kernel(anoddpm_gn_finalize_args a)
+{
+    __shared__ double red_s[256];
+    __shared__ double red_q[256];
+    const int C = a.c0 + a.c1;
+    const int cpg = C / a.groups;
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int cc = 0; cc < cpg; ++cc) {
+        const int c = g * cpg + cc;
+        const float *st;
+        int rows, cl, cw;
+        if (c < a.c0) { st = a.stats0; rows = a.rows0; cl = c; cw = a.c0; }
+        else          { st = a.stats1; rows = a.rows1; cl = c - a.c0; cw = a.c1; }
+        st += (int64_t)b * rows * cw * 2;
+        for (int r = tid; r < rows; r += 256) {
+            const float2 v = *reinterpret_cast<const float2 *>(st + ((int64_t)r * cw + cl) * 2);
+            s += (double)v.x;
+            q += (double)v.y;
+        }
+    }
+    red_s[tid] = s;
+    red_q[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { red_s[tid] += red_s[tid + o]; red_q[tid] += red_q[tid + o]; }
+        __syncthreads();
+    }
+    const double n = (double)a.P * cpg;
+    const double mean = red_s[0] / n;
+    double var = red_q[0] / n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)a.eps);
+    if (tid < cpg) {
+        const int c = g * cpg + tid;
+        const double sc = rstd * (double)a.gamma[c];
+        a.scale[(int64_t)b * C + c] = (float)sc;
+        a.shift[(int64_t)b * C + c] = (float)((double)a.beta[c] - mean * sc);
+    }
+}
+
 // ---------------------------------------------------------------- softmax ---------------------
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float *x, int64_t rows, int L)
 {
@@ -286,6 +375,26 @@ extern "C" int anoddpm_gn_stats(const anoddpm_gn_args *a, void *stream)
     hipLaunchKernelGGL(gn_partial_kernel, dim3(a->nslab, a->B), dim3(256), 0, s, *a);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(a->B), dim3(256), 0, s, *a);
     return anoddpm::check_launch("gn_stats");
+}
+
+extern "C" int anoddpm_chan_stats(const anoddpm_chan_stats_args *a, void *stream)
+{
+    ANODDPM_REQUIRE(a && a->a && a->stats, "chan_stats: null pointer");
+    ANODDPM_REQUIRE(a->C > 0 && a->C % 4 == 0 && a->C / 4 <= 256 * 16 && a->a_ld % 4 == 0, "chan_stats: C must be a multiple of 4");
+    ANODDPM_REQUIRE(a->B > 0 && a->B <= 65535 && a->P > 0 && a->nslab > 0 && a->nslab <= 65535, "chan_stats: bad sizes");
+    hipLaunchKernelGGL(chan_stats_kernel, dim3(a->nslab, a->B), dim3(256), 0, anoddpm::as_stream(stream), *a);
+    return anoddpm::check_launch("chan_stats");
+}
+
+extern "C" int anoddpm_gn_finalize(const anoddpm_gn_finalize_args *a, void *stream)
+{
+    ANODDPM_REQUIRE(a && a->stats0 && a->gamma && a->beta && a->scale && a->shift, "gn_finalize: null pointer");
+    ANODDPM_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c1 == 0 || a->stats1), "gn_finalize: bad channel counts");
+    const int C = a->c0 + a->c1;
+    ANODDPM_REQUIRE(a->groups > 0 && a->groups <= 65535 && C % a->groups == 0 && C / a->groups <= 256, "gn_finalize: bad group size");
+    ANODDPM_REQUIRE(a->B > 0 && a->B <= 65535 && a->P > 0 && a->rows0 > 0 && (a->c1 == 0 || a->rows1 > 0), "gn_finalize: bad sizes");
+    hipLaunchKernelGGL(gn_finalize2_kernel, dim3(a->groups, a->B), dim3(256), 0, anoddpm::as_stream(stream), *a);
+    return anoddpm::check_launch("gn_finalize");
 }
 
 extern "C" int anoddpm_softmax_rows(const anoddpm_softmax_args *a, void *stream)

@@ -25,8 +25,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
-from ._lib import (GnArgs, IgemmArgs, LayoutArgs, LinearArgs, Op, PosembArgs, ResampleArgs,
-                   SoftmaxArgs, StemArgs, check, lib)
+from ._lib import (ChanStatsArgs, GnFinalizeArgs, IgemmArgs, LayoutArgs, LinearArgs, Op, PosembArgs,
+                   ResampleArgs, SoftmaxArgs, StemArgs, check, lib)
 
 __all__ = ["UNetModel", "update_ema_params", "zero_module", "GroupNorm32"]
 
@@ -372,6 +372,7 @@ class _Plan:
         self.flops = {"conv3": 0.0, "conv1": 0.0, "attn": 0.0, "qkvproj": 0.0}
         self.igemm_flops = 0.0
         self._ws_need = 0
+        self.stats_of = {}
         with torch.no_grad():
             self._build()
         n = len(self.ops)
@@ -418,30 +419,47 @@ class _Plan:
         self.token = token
 
     # -- op emitters ----------------------------------------------------------------------
+    def chan_stats(self, buf, C, P):
+        """Stand-alone per-channel partial sums for tensors whose producer could not emit them
+        (stem output, split-K outputs)."""
+        B = self.B
+        nslab = max(1, min(128, (P * (C // 4)) // 4096))
+        stats = self.buf(B, nslab, C, 2)
+        st = ChanStatsArgs()
+        st.a, st.stats, st.a_bs = buf.data_ptr(), stats.data_ptr(), P * C
+        st.C, st.a_ld, st.P, st.B, st.nslab = C, C, P, B, nslab
+        self.add(_lib.OP_CHAN_STATS, st)
+        self.stats_of[buf.data_ptr()] = (stats, nslab)
+
     def gn(self, srcs, P, gamma_key, beta_key):
-        """srcs: [(tensor[B,P,C], C)] one or two sources.  Returns (scale, shift) [B][Ctot]."""
+        """GroupNorm(32) affine of one or two concatenated sources from their per-channel partial sums
+        (emitted by the producing igemm's epilogue).  Returns (scale, shift) [B][Ctot]."""
         B = self.B
         c0 = srcs[0][1]
         c1 = srcs[1][1] if len(srcs) > 1 else 0
         C = c0 + c1
-        nslab = max(1, min(256, (P * (C // 4)) // 4096))
-        st = GnArgs()
-        st.a0 = srcs[0][0].data_ptr()
-        st.a1 = srcs[1][0].data_ptr() if c1 else None
+        for buf, c in [(s[0], s[1]) for s in srcs]:
+            if buf.data_ptr() not in self.stats_of:
+                self.chan_stats(buf, c, P)
+        st = GnFinalizeArgs()
+        s0, r0 = self.stats_of[srcs[0][0].data_ptr()]
+        st.stats0, st.rows0 = s0.data_ptr(), r0
+        if c1:
+            s1, r1 = self.stats_of[srcs[1][0].data_ptr()]
+            st.stats1, st.rows1 = s1.data_ptr(), r1
+        else:
+            st.stats1, st.rows1 = None, 0
         st.gamma = self.packed(gamma_key, lambda w: w.detach().float()).data_ptr()
         st.beta = self.packed(beta_key, lambda w: w.detach().float()).data_ptr()
         scale, shift = self.buf(B, C), self.buf(B, C)
         st.scale, st.shift = scale.data_ptr(), shift.data_ptr()
-        st.partial = self.buf(B * nslab * 64, dtype=torch.float64).data_ptr()
-        st.a0_bs, st.a1_bs = P * c0, P * c1
-        st.c0, st.c1, st.a0_ld, st.a1_ld = c0, c1, c0, max(c1, 4)
-        st.P, st.B, st.groups, st.nslab, st.eps = P, B, 32, nslab, 1e-5
-        self.add(_lib.OP_GN_STATS, st)
+        st.c0, st.c1, st.P, st.B, st.groups, st.eps = c0, c1, P, B, 32, 1e-5
+        self.add(_lib.OP_GN_FINALIZE, st)
         return scale, shift
 
     def igemm(self, *, srcs, H, W, ks, N, bmat, out, out_ld=None, gn=None, act=0, a_mode=0, bias=None,
               temb=None, temb_ld=0, res=None, res_ld=0, b_mode=0, ldb=0, heads=1, alpha=1.0,
-              a_strides=None, b_strides=(0, 0), o_strides=None, r_strides=None, kind="conv3"):
+              a_strides=None, b_strides=(0, 0), o_strides=None, r_strides=None, kind="conv3", want_stats=False):
         B = self.B
         P = H * W
         c0 = srcs[0][1]
@@ -506,7 +524,20 @@ class _Plan:
         st.ws = None                      # patched after the build (one shared workspace)
         if ksplit > 1:
             self._ws_need = max(self._ws_need, ksplit * Z * P * N)
+        st.stats = None
+        if want_stats and ksplit == 1 and heads == 1:
+            # the epilogue emits per-channel {sum, sumsq} per wave-row of every pixel tile
+            if ks == 1:
+                tiles = -(-P // bm)
+            else:
+                tw = min(W, 32)
+                tiles = (W // tw) * -(-H // (bm // tw))
+            stats = self.buf(B, tiles * 2, N, 2)
+            st.stats = stats.data_ptr()
+            self.stats_of[out.data_ptr()] = (stats, tiles * 2)
         self.add(_lib.OP_IGEMM, st)
+        if want_stats and st.stats is None:
+            self.chan_stats(out, N, P)
         fl = 2.0 * K * N * ks * ks * P * Z
         self.flops[kind] = self.flops.get(kind, 0.0) + fl
         self.igemm_flops += fl
@@ -575,7 +606,7 @@ class _Plan:
                        a_mode={None: 0, "up": 1, "down": 2}[resample],
                        bmat=self.packed(prefix + ".in_layers.2.weight", _pack_conv),
                        bias=self.packed(prefix + ".in_layers.2.bias", lambda t: t.detach().float()),
-                       temb=emb_all.data_ptr() + 4 * offs[prefix], temb_ld=tot, out=h1)
+                       temb=emb_all.data_ptr() + 4 * offs[prefix], temb_ld=tot, out=h1, want_stats=True)
             g2 = self.gn([(h1, cout)], Pout, prefix + ".out_layers.0.weight", prefix + ".out_layers.0.bias")
             if cin != cout:
                 sk = self.buf(B, Pout, cout)
@@ -598,7 +629,7 @@ class _Plan:
             self.igemm(srcs=[(h1, cout)], H=Hout, W=Hout, ks=3, N=cout, gn=g2, act=1,
                        bmat=self.packed(prefix + ".out_layers.3.weight", _pack_conv),
                        bias=self.packed(prefix + ".out_layers.3.bias", lambda t: t.detach().float()),
-                       res=sk, out=h2)
+                       res=sk, out=h2, want_stats=True)
             return h2, Hout
 
         def attn_block(prefix, x, Hc, C):
@@ -631,7 +662,7 @@ class _Plan:
             self.igemm(srcs=[(att, C)], H=Hc, W=Hc, ks=1, N=C, kind="qkvproj",
                        bmat=self.packed(prefix + ".proj_out.weight", _pack_conv),
                        bias=self.packed(prefix + ".proj_out.bias", lambda t: t.detach().float()),
-                       res=x, out=y)
+                       res=x, out=y, want_stats=True)
             return y
 
         def run(blks, srcs, Hc):

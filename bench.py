@@ -206,7 +206,8 @@ def main():
                     "algorithmic_gflop_per_step": flops_per_step / 1e9,
                     "class_ms_per_step": {name: ms[code] / args.steps for name, code in
                                           (("igemm", 1), ("gn_stats", 2), ("softmax", 3), ("resample", 4), ("linear", 5),
-                                           ("posemb", 6), ("stem", 7), ("layout", 8))},
+                                           ("posemb", 6), ("stem", 7), ("layout", 8), ("chan_stats", 9),
+                                           ("gn_finalize", 10))},
                     "instrumented_ms_per_step": prof_ms_per_step}
 
     out = {

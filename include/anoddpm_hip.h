@@ -127,7 +127,9 @@ enum {
     ANODDPM_OP_LINEAR = 5,       /* anoddpm_linear_args      */
     ANODDPM_OP_POSEMB = 6,       /* anoddpm_posemb_args      */
     ANODDPM_OP_STEM = 7,         /* anoddpm_stem_args        */
-    ANODDPM_OP_LAYOUT = 8        /* anoddpm_layout_args      */
+    ANODDPM_OP_LAYOUT = 8,       /* anoddpm_layout_args      */
+    ANODDPM_OP_CHAN_STATS = 9,   /* anoddpm_chan_stats_args  */
+    ANODDPM_OP_GN_FINALIZE = 10  /* anoddpm_gn_finalize_args */
 };
 
 /* Implicit-GEMM convolution / GEMM on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact fp32).
@@ -169,6 +171,10 @@ typedef struct {
     int32_t cfg;                    /* 0: 128x128 tile, 1: 64x64 tile */
     float alpha;
     int32_t gn_ld;                  /* row length of gn_scale/gn_shift (= K) */
+    float *stats;                   /* or NULL: per-channel partial sums of the OUTPUT, [B][tiles*2][N][2]
+                                       {sum, sum of squares} per wave-row of each pixel tile (needs ksplit==1,
+                                       heads==1); consumed by anoddpm_gn_finalize -- GroupNorm statistics
+                                       without re-reading the tensor */
 } anoddpm_igemm_args;
 
 int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream);
@@ -190,6 +196,30 @@ typedef struct {
 } anoddpm_gn_args;
 
 int anoddpm_gn_stats(const anoddpm_gn_args *a, void *stream);
+
+/* Per-channel partial sums of an NHWC tensor in the format the igemm epilogue emits:
+ * stats[b][slab][c] = {sum, sum of squares} over the slab's pixels (fp32 pairs). */
+typedef struct {
+    const float *a;
+    float *stats;                   /* [B][nslab][C][2] */
+    int64_t a_bs;
+    int32_t C, a_ld, P, B, nslab;
+} anoddpm_chan_stats_args;
+
+int anoddpm_chan_stats(const anoddpm_chan_stats_args *a, void *stream);
+
+/* GroupNorm(32, C) affine from per-channel partial sums of one or two concatenated sources
+ * (UNet.py:409-411 over torch.cat([h, skip], 1), UNet.py:402): fp64 fold, biased variance, eps. */
+typedef struct {
+    const float *stats0, *stats1;   /* [B][rows][c][2]; stats1 NULL when single source */
+    const float *gamma, *beta;      /* [C] */
+    float *scale, *shift;           /* [B][C] */
+    int32_t rows0, rows1, c0, c1;
+    int32_t P, B, groups;
+    float eps;
+} anoddpm_gn_finalize_args;
+
+int anoddpm_gn_finalize(const anoddpm_gn_finalize_args *a, void *stream);
 
 /* Row softmax in place (UNet.py:151): x[r][0..L) <- softmax(x[r][:]); rows = B*heads*L. */
 typedef struct {

@@ -5,7 +5,7 @@ import math
 import torch
 
 from anoddpm_amd import _lib
-from anoddpm_amd._lib import (GnArgs, IgemmArgs, LinearArgs, PosembArgs, ResampleArgs, SoftmaxArgs, StemArgs,
+from anoddpm_amd._lib import (ChanStatsArgs, GnFinalizeArgs, GnArgs, IgemmArgs, LinearArgs, PosembArgs, ResampleArgs, SoftmaxArgs, StemArgs,
                               check, current_stream, lib)
 from anoddpm_amd.unet import _pack_conv
 
@@ -37,7 +37,34 @@ def gn_affine(srcs, gamma, beta, nslab=None, eps=1e-5):
     return scale, shift
 
 
-def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=None, res=None, cfg=0, ksplit=1):
+def chan_stats(x, nslab):
+    """x NHWC -> stats [B][nslab][C][2]."""
+    B, H, W, C = x.shape
+    stats = torch.full((B, nslab, C, 2), float("nan"), device=x.device)
+    st = ChanStatsArgs()
+    st.a, st.stats, st.a_bs, st.C, st.a_ld, st.P, st.B, st.nslab = x.data_ptr(), stats.data_ptr(), H * W * C, C, C, H * W, B, nslab
+    check(lib().anoddpm_chan_stats(ctypes.byref(st), current_stream()), "chan_stats")
+    return stats
+
+
+def gn_finalize(stats, gamma, beta, P):
+    """stats: list of 1-2 tensors [B][rows][c][2] -> scale, shift [B][Ctot]."""
+    B = stats[0].shape[0]
+    c0 = stats[0].shape[2]
+    c1 = stats[1].shape[2] if len(stats) > 1 else 0
+    scale = torch.empty(B, c0 + c1, device=stats[0].device)
+    shift = torch.empty(B, c0 + c1, device=stats[0].device)
+    st = GnFinalizeArgs()
+    st.stats0, st.rows0 = stats[0].data_ptr(), stats[0].shape[1]
+    st.stats1, st.rows1 = (stats[1].data_ptr(), stats[1].shape[1]) if c1 else (None, 0)
+    st.gamma, st.beta, st.scale, st.shift = gamma.data_ptr(), beta.data_ptr(), scale.data_ptr(), shift.data_ptr()
+    st.c0, st.c1, st.P, st.B, st.groups, st.eps = c0, c1, P, B, 32, 1e-5
+    check(lib().anoddpm_gn_finalize(ctypes.byref(st), current_stream()), "gn_finalize")
+    return scale, shift
+
+
+def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=None, res=None, cfg=0, ksplit=1,
+               stats_out=None):
     """srcs: NHWC sources; w: OIHW weights.  Returns NHWC [B,Hout,Hout,N]."""
     dev = srcs[0].device
     B = srcs[0].shape[0]
@@ -67,6 +94,12 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
     st.cfg, st.ksplit = cfg, ksplit
     ws = torch.empty(max(1, ksplit * B * P * N), device=dev) if ksplit > 1 else None
     st.ws = ws.data_ptr() if ws is not None else None
+    if stats_out is not None:
+        bm = 128 if cfg == 0 else 64
+        tiles = -(-P // bm) if ks == 1 else (Hout // min(Hout, 32)) * -(-Hout // (bm // min(Hout, 32)))
+        stats = torch.full((B, tiles * 2, N, 2), float("nan"), device=dev)
+        st.stats = stats.data_ptr()
+        stats_out.append(stats)
     check(lib().anoddpm_igemm(ctypes.byref(st), current_stream()), "igemm")
     torch.cuda.synchronize()
     return out

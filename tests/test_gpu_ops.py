@@ -46,6 +46,31 @@ def test_gn_affine(shape):
         assert relerr(hipops.nchw(got), ref) < TOL
 
 
+@pytest.mark.parametrize("case", [(2, 128, 32, 3, 0), (1, 64, 64, 3, 0), (2, 96, 16, 3, 1), (3, 64, 4, 3, 1), (1, 256, 16, 1, 1), (1, 128, 128, 1, 0)])
+def test_fused_groupnorm_statistics(case):
+    """GroupNorm affine from the igemm epilogue's per-channel sums == group_norm of the conv output; and the
+    two-source fold (virtual concat) with one source coming from the stand-alone chan_stats kernel."""
+    import hipops
+    B, C, H, ks, cfg = case
+    x = rnd(B, 32, H, H, seed=61)
+    w, b = rnd(C, 32, ks, ks, seed=62, scale=0.2), rnd(C, seed=63)
+    y = F.conv2d(x, w, b, padding=ks // 2)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=64), 0.1 * rnd(C, seed=65)
+    st = []
+    got = hipops.conv_igemm([hipops.nhwc(x.to(dev()))], w.to(dev()), b.to(dev()), Hout=H, ks=ks, cfg=cfg, stats_out=st)
+    assert relerr(hipops.nchw(got), y) < TOL
+    sc, sh = hipops.gn_finalize(st, gamma.to(dev()), beta.to(dev()), H * H)
+    assert relerr(hipops.nchw(got * sc[:, None, None, :] + sh[:, None, None, :]), F.group_norm(y, 32, gamma, beta, eps=1e-5)) < TOL
+    # concat [y, skip]: skip statistics from the stand-alone kernel
+    skip = rnd(B, 32, H, H, seed=66) * 3 - 1
+    st2 = hipops.chan_stats(hipops.nhwc(skip.to(dev())), nslab=3 if H > 4 else 1)
+    g2, b2 = 1 + 0.1 * rnd(C + 32, seed=67), 0.1 * rnd(C + 32, seed=68)
+    sc, sh = hipops.gn_finalize([st[0], st2], g2.to(dev()), b2.to(dev()), H * H)
+    cat = torch.cat([y, skip], 1)
+    gotc = hipops.nhwc(cat.to(dev())) * sc[:, None, None, :] + sh[:, None, None, :]
+    assert relerr(hipops.nchw(gotc), F.group_norm(cat, 32, g2, b2, eps=1e-5)) < TOL
+
+
 CONV_CASES = [
     # B, Cin(c0,c1), Cout, Hout, ks, a_mode, gn, act, temb, res, cfg, ksplit
     (1, (64, 0), 128, 32, 3, 0, True, 1, True, True, 0, 1),
