@@ -115,7 +115,7 @@ SYMBOLS = [
     "anoddpm_q_sample", "anoddpm_p_sample_update", "anoddpm_chain_advance",
     "anoddpm_igemm", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
     "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_nhwc_to_nchw",
-    "anoddpm_run_ops", "anoddpm_prof_enable", "anoddpm_prof_collect",
+    "anoddpm_run_ops", "anoddpm_prof_enable", "anoddpm_prof_active", "anoddpm_prof_collect",
     "anoddpm_adamw_ema", "anoddpm_sumsq",
 ]
 

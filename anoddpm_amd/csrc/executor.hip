@@ -108,6 +108,8 @@ extern "C" int anoddpm_prof_enable(int32_t enable)
     return ANODDPM_OK;
 }
 
+extern "C" int anoddpm_prof_active(void) { return g_prof.on ? 1 : 0; }
+
 extern "C" int anoddpm_prof_collect(double *ms_per_code, int64_t *launches_per_code)
 {
     ANODDPM_REQUIRE(ms_per_code && launches_per_code, "prof_collect: null pointer");

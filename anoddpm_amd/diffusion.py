@@ -138,9 +138,17 @@ class ReverseChain:
     """Device-resident state of the reverse loop (GaussianDiffusion.py:351-357): x, t and a step counter
     live in HBM; one step = model forward + noise + ONE fused update launch + t -= 1."""
 
-    def __init__(self, owner, model, x, t_distance, denoise_fn):
+    def __init__(self, owner, model, x, t_distance, denoise_fn, use_graph=None):
         _lib.require_cuda(x, "ReverseChain")
         self.owner, self.model, self.denoise_fn = owner, model, denoise_fn
+        # HIP-graph replay of the step: on by default for the built-in UNetModel (every launch of a step
+        # is stream-ordered, allocation-free C-ABI work); ANODDPM_NO_GRAPH=1 forces eager launches.
+        import os
+        self.graph = None
+        self._graph_state = 0          # 0: next step eager (warm-up), 1: capture, 2: replay
+        if use_graph is None:
+            use_graph = hasattr(model, "forward_hip") and os.environ.get("ANODDPM_NO_GRAPH", "0") != "1"
+        self.use_graph = bool(use_graph)
         self.B = x.shape[0]
         self.x = owner._f32(x.detach()).clone()
         self.t = torch.full((self.B,), t_distance - 1, device=x.device, dtype=torch.int64)
@@ -166,6 +174,28 @@ class ReverseChain:
             self.noise = torch.empty_like(self.x)
 
     def step(self):
+        if self.use_graph and lib().anoddpm_prof_active() == 0:
+            if self._graph_state == 2:
+                self.graph.replay()
+                self.remaining -= 1
+                return self.x
+            if self._graph_state == 1:
+                # everything a step touches is static (x, t, step counter, noise, tables, plan buffers)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step_body()
+                self.graph = g
+                self._graph_state = 2
+                g.replay()                      # capture does not execute: run the captured step once
+                self.remaining -= 1
+                return self.x
+            self._graph_state = 1               # first step runs eagerly (builds the plan, packs weights)
+        self._step_body()
+        self.remaining -= 1
+        return self.x
+
+    def _step_body(self):
         o = self.owner
         with torch.no_grad():
             eps = self.model.forward_hip(self.x, self.t) if self.hip_model else self.model(self.x, self.t)
@@ -180,8 +210,6 @@ class ReverseChain:
                 noise = o._denoise_noise(self.x, self.t, self.denoise_fn)
             o._reverse_update(self.x, self.t, eps, noise, want_pred=False, out=self.x)     # in place
             check(lib().anoddpm_chain_advance(ptr(self.t), self.B, ptr(self.step_idx), current_stream()), "chain_advance")
-        self.remaining -= 1
-        return self.x
 
     def finish(self):
         if self.tables is not None and self._last_seed is not None:
