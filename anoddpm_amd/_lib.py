@@ -9,9 +9,9 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
-OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE = range(1, 11)
+OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 
 
 class SimplexArgs(Structure):
@@ -64,6 +64,11 @@ class GnFinalizeArgs(Structure):
                 ("P", c_int32), ("B", c_int32), ("groups", c_int32), ("eps", c_float)]
 
 
+class HeadArgs(Structure):
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("gn_scale", c_void_p), ("gn_shift", c_void_p),
+                ("out", c_void_p), ("B", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32), ("Cout", c_int32)]
+
+
 class SoftmaxArgs(Structure):
     _fields_ = [("x", c_void_p), ("rows", c_int64), ("L", c_int32)]
 
@@ -105,16 +110,16 @@ class AdamwArgs(Structure):
 
 
 _STRUCTS = [SimplexArgs, PUpdateArgs, IgemmArgs, GnArgs, SoftmaxArgs, ResampleArgs, LinearArgs,
-            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs]
+            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs]
 
 # every symbol include/anoddpm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "anoddpm_abi_version", "anoddpm_last_error", "anoddpm_device_count", "anoddpm_struct_size",
+    "anoddpm_abi_version", "anoddpm_last_error", "anoddpm_device_count", "anoddpm_debug_set", "anoddpm_struct_size",
     "anoddpm_simplex_perm_init", "anoddpm_simplex3_octaves_f64", "anoddpm_simplex3_octaves_f32",
     "anoddpm_simplex3_grid_f64",
     "anoddpm_q_sample", "anoddpm_p_sample_update", "anoddpm_chain_advance",
     "anoddpm_igemm", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
-    "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_nhwc_to_nchw",
+    "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_conv_head", "anoddpm_nhwc_to_nchw",
     "anoddpm_run_ops", "anoddpm_prof_enable", "anoddpm_prof_active", "anoddpm_prof_collect",
     "anoddpm_adamw_ema", "anoddpm_sumsq",
 ]
@@ -178,12 +183,16 @@ def lib():
     L.anoddpm_linear_small.argtypes = [POINTER(LinearArgs), c_void_p]
     L.anoddpm_posemb.argtypes = [POINTER(PosembArgs), c_void_p]
     L.anoddpm_conv_stem.argtypes = [POINTER(StemArgs), c_void_p]
+    L.anoddpm_conv_head.argtypes = [POINTER(HeadArgs), c_void_p]
     L.anoddpm_nhwc_to_nchw.argtypes = [POINTER(LayoutArgs), c_void_p]
     L.anoddpm_run_ops.argtypes = [POINTER(Op), c_int32, c_void_p]
     L.anoddpm_prof_enable.argtypes = [c_int32]
     L.anoddpm_prof_collect.argtypes = [POINTER(c_double), POINTER(c_int64)]
     L.anoddpm_adamw_ema.argtypes = [POINTER(AdamwArgs), c_void_p]
     L.anoddpm_sumsq.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
+    for i in range(8):
+        if os.environ.get(f"ANODDPM_DEBUG{i}"):
+            L.anoddpm_debug_set(i, int(os.environ[f"ANODDPM_DEBUG{i}"], 0))
     _lib = L
     return L
 

@@ -9,6 +9,7 @@
 namespace anoddpm {
 
 static thread_local char g_err[512] = "";
+int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 void set_error(const char *fmt, ...)
 {
@@ -40,6 +41,7 @@ static int dispatch(const anoddpm_op &op, void *stream)
         case ANODDPM_OP_STEM: return anoddpm_conv_stem(static_cast<const anoddpm_stem_args *>(op.args), stream);
         case ANODDPM_OP_LAYOUT: return anoddpm_nhwc_to_nchw(static_cast<const anoddpm_layout_args *>(op.args), stream);
         case ANODDPM_OP_CHAN_STATS: return anoddpm_chan_stats(static_cast<const anoddpm_chan_stats_args *>(op.args), stream);
+        case ANODDPM_OP_HEAD: return anoddpm_conv_head(static_cast<const anoddpm_head_args *>(op.args), stream);
         case ANODDPM_OP_GN_FINALIZE: return anoddpm_gn_finalize(static_cast<const anoddpm_gn_finalize_args *>(op.args), stream);
         default: set_error("run_ops: unknown op code %d", op.code); return ANODDPM_EINVAL;
     }
@@ -49,7 +51,14 @@ static int dispatch(const anoddpm_op &op, void *stream)
 
 using namespace anoddpm;
 
-extern "C" int anoddpm_abi_version(void) { return 2; }
+extern "C" int anoddpm_debug_set(int32_t key, int32_t value)
+{
+    if (key < 0 || key >= 8) return ANODDPM_EINVAL;
+    g_debug[key] = value;
+    return ANODDPM_OK;
+}
+
+extern "C" int anoddpm_abi_version(void) { return 3; }
 
 extern "C" const char *anoddpm_last_error(void) { return g_err; }
 
@@ -145,6 +154,7 @@ extern "C" int anoddpm_struct_size(int32_t which)
         case 11: return (int)sizeof(anoddpm_adamw_args);
         case 12: return (int)sizeof(anoddpm_chan_stats_args);
         case 13: return (int)sizeof(anoddpm_gn_finalize_args);
+        case 14: return (int)sizeof(anoddpm_head_args);
         default: return -1;
     }
 }

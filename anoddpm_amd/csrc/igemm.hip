@@ -125,16 +125,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const anoddpm_igemm_args 
     }
     auto load_B = [&](int chunk, int tap) {
         const int kbase = chunk * KC;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if (CONV) {
             const float *base = Bm + ((int64_t)tap * K4 + (kbase >> 2)) * N * 4;     // uniform
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) {
-                const f32x4 v = ld4(base + boff[j]);
-                breg[j] = ((bok >> j) & 1) ? v : zero;
-            }
-            return;
+            for (int j = 0; j < BJ; ++j) breg[j] = ld4(base + boff[j]);   // NO use of the value here: a select
+            return;                                                       // would force vmcnt(0) right away
         }
+        bok = 0;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int idx = tid + j * 256;
@@ -161,27 +158,30 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const anoddpm_igemm_args 
                 const int nc = n0 + n4 * 4 < N ? n0 + n4 * 4 : 0;
                 v = ld4(Bm + (int64_t)kc * a.ldb + nc);
             }
-            breg[j] = ok ? v : zero;
+            breg[j] = v;
+            bok |= (ok ? 1u : 0u) << j;                  // applied when the tile is written to LDS
         }
     };
     auto store_B = [&](int buf) {
         float *ldsBf = ldsBbase + buf * BTILE;
         f32x4 *ldsB = reinterpret_cast<f32x4 *>(ldsBf);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
             const int idx = tid + j * 256;
+            const f32x4 bj = ((bok >> j) & 1) ? breg[j] : zero;     // out-of-range k / n -> 0
             if (CONV || a.b_mode == 0) {
-                ldsB[idx] = breg[j];               // idx = r*BN + n already
+                ldsB[idx] = bj;                    // idx = r*BN + n already
             } else if (a.b_mode == 1) {
                 const int n = idx >> 3, r = idx & 7;
-                ldsB[r * BN + n] = breg[j];
+                ldsB[r * BN + n] = bj;
             } else {
                 const int k = idx / (BN / 4), n4 = idx % (BN / 4);
                 float *dst = ldsBf + (((k >> 2) * BN + n4 * 4) * 4 + (k & 3));
-                dst[0] = breg[j][0];
-                dst[4] = breg[j][1];
-                dst[8] = breg[j][2];
-                dst[12] = breg[j][3];
+                dst[0] = bj[0];
+                dst[4] = bj[1];
+                dst[8] = bj[2];
+                dst[12] = bj[3];
             }
         }
     };
@@ -275,29 +275,40 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const anoddpm_igemm_args 
     int tap = 0, chunk = c_begin, tapoff = 0, tx = 0;
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
-        if (step + 1 < nsteps) {
-            store_B(cur ^ 1);                            // tile for step+1 (its loads had a full step to land)
-            if (step + 2 < nsteps) { load_B(ld_chunk, ld_tap); advance_ld(); }
-        }
         const f32x4 *ldsB = reinterpret_cast<const f32x4 *>(ldsBbase + cur * BTILE);
         int pA[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) pA[mt] = pixbase[mt] + tapoff;
+        // fragments are software-pipelined over the four k-groups of the slice: group g+1 is read from
+        // LDS (into a second register set) before group g's sixteen MFMAs are issued
+        f32x4 av[2][MT], bv[2][NT];
+        auto read_frags = [&](int k8, int set) {
+            const int q = k8 * 2 + h;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[set][mt] = ldsA[pA[mt] * 8 + (q ^ ((pA[mt] >> 1) & 7))];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[set][nt] = ldsB[q * BN + ncol[nt]];
+        };
+        read_frags(0, 0);
 #pragma unroll
         for (int k8 = 0; k8 < KC / 8; ++k8) {
-            const int q = k8 * 2 + h;
-            f32x4 av[MT], bv[NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = ldsA[pA[mt] * 8 + (q ^ ((pA[mt] >> 1) & 7))];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = ldsB[q * BN + ncol[nt]];
+            const int set = k8 & 1;
+            if (k8 + 1 < KC / 8) read_frags(k8 + 1, set ^ 1);
+            // pin the reads ABOVE this group's MFMAs: left alone, the scheduler sinks them next to their
+            // first use and every group then stalls for the LDS latency (~25 % of the step)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][kk], bv[nt][kk], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[set][mt][kk], bv[set][nt][kk], acc[mt][nt], 0, 0, 0);
+            if (k8 == 0 && step + 1 < nsteps) {
+                // staging of the following steps rides behind the first MFMA group (other LDS buffer)
+                store_B(cur ^ 1);                        // tile for step+1 (its loads had a full step to land)
+                if (step + 2 < nsteps) { load_B(ld_chunk, ld_tap); advance_ld(); }
+            }
         }
         // advance (tap, slice); tapoff walks the 3x3 window: +1 along x, then down one halo row
         ++tap; ++tx; ++tapoff;
@@ -331,47 +342,63 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const anoddpm_igemm_args 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { cs[nt] = 0.f; cq[nt] = 0.f; }
     // per-lane row geometry: pixel index of row r of tile mt (or -1 outside the image)
+    int pixr[MT][16];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int pixr[16];
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
             const int m = (wm * MT + mt) * 32 + row;
             const int oy = y0 + (m >> log2TW), ox = x0 + (m & (TW - 1));
-            pixr[r] = (oy < H && ox < W) ? oy * W + ox : -1;
+            pixr[mt][r] = (oy < H && ox < W) ? oy * W + ox : -1;
         }
+    if (ksplit > 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n0 + ncol[nt];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (n < N && pixr[mt][r] >= 0) WS[(int64_t)pixr[mt][r] * N + n] = acc[mt][nt][r];
+            }
+        return;
+    }
+    // phase 1: every residual load of the whole 64x64 wave tile is in flight before the first add
+    float rv[MT][NT][16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + ncol[nt];
+            const int nc = n < N ? n : 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pc = pixr[mt][r] >= 0 ? pixr[mt][r] : 0;
+                rv[mt][nt][r] = R ? R[(int64_t)pc * a.res_ld + nc] : 0.f;      // unconditional, clamped
+            }
+        }
+    // phase 2: add, store, accumulate the fused statistics
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int n = n0 + ncol[nt];
             const bool nok = n < N;
             const int nc = nok ? n : 0;
-            if (ksplit > 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (nok && pixr[r] >= 0) WS[(int64_t)pixr[r] * N + nc] = acc[mt][nt][r];
-                continue;
-            }
             float add = 0.f;
             if (a.bias) add += a.bias[nc];
             if (TE) add += TE[nc];
-            float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int pc = pixr[r] >= 0 ? pixr[r] : 0;
-                rv[r] = R ? R[(int64_t)pc * a.res_ld + nc] : 0.f;       // unconditional, clamped
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = a.alpha * acc[mt][nt][r] + add + rv[r];
-                if (nok && pixr[r] >= 0) {
-                    O[(int64_t)pixr[r] * a.out_ld + nc] = v;
+                const float v = a.alpha * acc[mt][nt][r] + add + rv[mt][nt][r];
+                if (nok && pixr[mt][r] >= 0) {
+                    O[(int64_t)pixr[mt][r] * a.out_ld + nc] = v;
                     cs[nt] += v;
                     cq[nt] += v * v;
                 }
             }
         }
-    }
     if (a.stats && ksplit == 1) {
         // rows of this wave = MT*32 pixels; lane halves hold different rows of the same column
         float *st = a.stats + ((int64_t)b * (gridDim.x * 2) + blockIdx.x * 2 + wm) * N * 2;

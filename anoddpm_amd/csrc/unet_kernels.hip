@@ -348,6 +348,65 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(anoddpm_stem_args a)
     reinterpret_cast<float4 *>(a.out)[pix * QP + q] = acc;
 }
 
+// ---------------------------------------------------------------- head conv ------------------
+// out.2 of the reference (UNet.py:386-387): silu(GroupNorm(x)) -> 3x3 conv to Cout <= 4 channels.
+// Memory-bound (reads C floats per pixel, writes Cout): one wave per output pixel row segment.
+// A 8x8 pixel tile per block; the transformed (affine + SiLU) halo tile (10x10 pixels x C) is staged in
+// LDS once, so the transcendental work is done once per input element rather than once per tap.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_head_kernel(anoddpm_head_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [100][C] transformed halo + [9][C][COUT] weights
+    const int C = a.C, C4 = C >> 2;
+    float *wl = lds + 100 * C;
+    const int tid = threadIdx.x;
+    const int tiles_x = a.W >> 3;
+    const int b = blockIdx.y;
+    const int y0 = (blockIdx.x / tiles_x) * 8, x0 = (blockIdx.x % tiles_x) * 8;
+    for (int i = tid; i < 9 * C * COUT; i += 256) wl[i] = a.w[i];
+    const float *sc = a.gn_scale + (int64_t)b * C, *sh = a.gn_shift + (int64_t)b * C;
+    for (int i = tid; i < 100 * C4; i += 256) {
+        const int p = i / C4, q = i % C4;
+        const int gy = y0 + p / 10 - 1, gx = x0 + p % 10 - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+            v = *reinterpret_cast<const float4 *>(a.x + (((int64_t)b * a.H + gy) * a.W + gx) * C + q * 4);
+            const float4 s4 = *reinterpret_cast<const float4 *>(sc + q * 4);
+            const float4 h4 = *reinterpret_cast<const float4 *>(sh + q * 4);
+            v.x = silu_f(v.x * s4.x + h4.x); v.y = silu_f(v.y * s4.y + h4.y);
+            v.z = silu_f(v.z * s4.z + h4.z); v.w = silu_f(v.w * s4.w + h4.w);
+        }
+        *reinterpret_cast<float4 *>(lds + p * C + q * 4) = v;
+    }
+    __syncthreads();
+    // 4 lanes per output pixel: each sums a quarter of the channels, then a 4-lane shuffle reduce
+    const int pix = tid >> 2, part = tid & 3;
+    const int py = pix >> 3, px = pix & 7;
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const float *src = lds + ((py + tap / 3) * 10 + px + tap % 3) * C;
+        const float *wt = wl + tap * C * COUT;
+        for (int c = part; c < C; c += 4) {
+            const float v = src[c];
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) acc[o] += v * wt[c * COUT + o];
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+        acc[o] += __shfl_xor(acc[o], 1);
+        acc[o] += __shfl_xor(acc[o], 2);
+    }
+    if (part == 0 && y0 + py < a.H && x0 + px < a.W) {
+        // NCHW output: [B][COUT][H][W]
+#pragma unroll
+        for (int o = 0; o < COUT; ++o)
+            a.out[(((int64_t)b * COUT + o) * a.H + y0 + py) * a.W + x0 + px] = acc[o] + (a.bias ? a.bias[o] : 0.f);
+    }
+}
+
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(anoddpm_layout_args a)
 {
     const int64_t total = (int64_t)a.B * a.C * a.P;
@@ -446,6 +505,23 @@ extern "C" int anoddpm_conv_stem(const anoddpm_stem_args *a, void *stream)
     if (npix == 0) return ANODDPM_OK;
     hipLaunchKernelGGL(conv_stem_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, anoddpm::as_stream(stream), *a);
     return anoddpm::check_launch("conv_stem");
+}
+
+extern "C" int anoddpm_conv_head(const anoddpm_head_args *a, void *stream)
+{
+    ANODDPM_REQUIRE(a && a->x && a->w && a->out && a->gn_scale && a->gn_shift, "conv_head: null pointer");
+    ANODDPM_REQUIRE(a->Cout >= 1 && a->Cout <= 4 && a->C % 4 == 0 && a->W % 8 == 0 && a->H % 8 == 0, "conv_head: need Cout<=4, C%%4==0, H,W%%8==0");
+    const size_t lds = (size_t)(100 * a->C + 9 * a->C * a->Cout) * sizeof(float);
+    ANODDPM_REQUIRE(lds <= 64 * 1024, "conv_head: channel count too large for the 64 KiB dynamic LDS tile");
+    dim3 grid((a->H / 8) * (a->W / 8), a->B);
+    hipStream_t s = anoddpm::as_stream(stream);
+    switch (a->Cout) {
+        case 1: hipLaunchKernelGGL(conv_head_kernel<1>, grid, dim3(256), lds, s, *a); break;
+        case 2: hipLaunchKernelGGL(conv_head_kernel<2>, grid, dim3(256), lds, s, *a); break;
+        case 3: hipLaunchKernelGGL(conv_head_kernel<3>, grid, dim3(256), lds, s, *a); break;
+        default: hipLaunchKernelGGL(conv_head_kernel<4>, grid, dim3(256), lds, s, *a); break;
+    }
+    return anoddpm::check_launch("conv_head");
 }
 
 extern "C" int anoddpm_nhwc_to_nchw(const anoddpm_layout_args *a, void *stream)

@@ -31,6 +31,7 @@ extern "C" {
 int anoddpm_abi_version(void);          /* bumps whenever a struct below changes */
 const char *anoddpm_last_error(void);   /* [host] text of the last failure on this thread */
 int anoddpm_device_count(void);
+int anoddpm_debug_set(int32_t key, int32_t value);   /* tuning experiments only; all keys default to 0 */
 int anoddpm_struct_size(int32_t which); /* sizeof of the n-th *_args struct, in declaration order */
 
 /* ------------------------------------------------------------------ simplex ------------ */
@@ -129,7 +130,8 @@ enum {
     ANODDPM_OP_STEM = 7,         /* anoddpm_stem_args        */
     ANODDPM_OP_LAYOUT = 8,       /* anoddpm_layout_args      */
     ANODDPM_OP_CHAN_STATS = 9,   /* anoddpm_chan_stats_args  */
-    ANODDPM_OP_GN_FINALIZE = 10  /* anoddpm_gn_finalize_args */
+    ANODDPM_OP_GN_FINALIZE = 10, /* anoddpm_gn_finalize_args */
+    ANODDPM_OP_HEAD = 11         /* anoddpm_head_args        */
 };
 
 /* Implicit-GEMM convolution / GEMM on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact fp32).
@@ -279,6 +281,19 @@ typedef struct {
 } anoddpm_stem_args;
 
 int anoddpm_conv_stem(const anoddpm_stem_args *a, void *stream);
+
+/* Head convolution (UNet.py:384-388): silu(GroupNorm affine(x)) -> 3x3 pad 1 -> Cout <= 4 channels.
+ * x: NHWC [B][H][W][C]; w: [9][C][Cout]; out: NCHW [B][Cout][H][W] (the caller's layout). HBM-bound. */
+typedef struct {
+    const float *x;
+    const float *w;
+    const float *bias;              /* [Cout] or NULL */
+    const float *gn_scale, *gn_shift; /* [B][C] */
+    float *out;
+    int32_t B, H, W, C, Cout;
+} anoddpm_head_args;
+
+int anoddpm_conv_head(const anoddpm_head_args *a, void *stream);
 
 /* Layout change at the API edge: NHWC [B][P][C] -> NCHW [B][C][P] (C small, UNet output). */
 typedef struct {

@@ -5,7 +5,7 @@ import math
 import torch
 
 from anoddpm_amd import _lib
-from anoddpm_amd._lib import (ChanStatsArgs, GnFinalizeArgs, GnArgs, IgemmArgs, LinearArgs, PosembArgs, ResampleArgs, SoftmaxArgs, StemArgs,
+from anoddpm_amd._lib import (HeadArgs, ChanStatsArgs, GnFinalizeArgs, GnArgs, IgemmArgs, LinearArgs, PosembArgs, ResampleArgs, SoftmaxArgs, StemArgs,
                               check, current_stream, lib)
 from anoddpm_amd.unet import _pack_conv
 
@@ -178,5 +178,19 @@ def stem(x, w, b):
     st.x, st.w, st.bias, st.out = x.data_ptr(), wp.data_ptr(), b.data_ptr(), out.data_ptr()
     st.B, st.H, st.W, st.Cin, st.Cout = B, H, W, Cin, Cout
     check(lib().anoddpm_conv_stem(ctypes.byref(st), current_stream()), "stem")
+    torch.cuda.synchronize()
+    return out
+
+
+def head(x, w, b, scale, shift):
+    """x NHWC, w OIHW (O <= 4) -> NCHW output."""
+    B, H, W, C = x.shape
+    Cout = w.shape[0]
+    wp = w.permute(2, 3, 1, 0).reshape(-1, Cout).contiguous()
+    out = torch.full((B, Cout, H, W), float("nan"), device=x.device)
+    st = HeadArgs()
+    st.x, st.w, st.bias, st.gn_scale, st.gn_shift, st.out = x.data_ptr(), wp.data_ptr(), b.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr()
+    st.B, st.H, st.W, st.C, st.Cout = B, H, W, C, Cout
+    check(lib().anoddpm_conv_head(ctypes.byref(st), current_stream()), "conv_head")
     torch.cuda.synchronize()
     return out

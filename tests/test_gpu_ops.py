@@ -194,3 +194,17 @@ def test_stem(case):
     ref = F.conv2d(x, w, b, padding=1)
     got = hipops.stem(x.to(dev()), w.to(dev()), b.to(dev()))
     assert relerr(hipops.nchw(got), ref) < TOL
+
+
+@pytest.mark.parametrize("case", [(2, 128, 32, 1), (1, 64, 64, 3), (1, 32, 8, 2), (1, 128, 256, 1)])
+def test_head_conv(case):
+    import hipops
+    B, C, H, Cout = case
+    x = rnd(B, C, H, H, seed=71)
+    w, b = rnd(Cout, C, 3, 3, seed=72, scale=0.05), rnd(Cout, seed=73)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=74), 0.1 * rnd(C, seed=75)
+    ref = F.conv2d(F.silu(F.group_norm(x, 32, gamma, beta, eps=1e-5)), w, b, padding=1)
+    xs = hipops.nhwc(x.to(dev()))
+    sc, sh = hipops.gn_affine([xs], gamma.to(dev()), beta.to(dev()))
+    got = hipops.head(xs, w.to(dev()), b.to(dev()), sc, sh)
+    assert relerr(got, ref) < TOL
