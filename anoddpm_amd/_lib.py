@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 
@@ -41,7 +41,7 @@ class IgemmArgs(Structure):
                 ("H", c_int32), ("W", c_int32), ("ks", c_int32), ("a_mode", c_int32), ("act", c_int32),
                 ("b_mode", c_int32), ("ldb", c_int32), ("N", c_int32), ("temb_ld", c_int32),
                 ("out_ld", c_int32), ("res_ld", c_int32), ("B", c_int32), ("heads", c_int32),
-                ("ksplit", c_int32), ("cfg", c_int32), ("alpha", c_float), ("gn_ld", c_int32), ("stats", c_void_p)]
+                ("ksplit", c_int32), ("cfg", c_int32), ("alpha", c_float), ("gn_ld", c_int32), ("stats", c_void_p), ("stats_rows", c_int32)]
 
 
 class GnArgs(Structure):

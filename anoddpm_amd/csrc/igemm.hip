@@ -436,6 +436,63 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const anoddpm_igemm_
     }
 }
 
+// Split-K tail + fused GroupNorm statistics: grid (slabs, Z).  Thread = (pixel row, channel quad); a block
+// owns a slab of pixels and ALL channels, so it can emit one row of per-channel {sum, sumsq} of the values it
+// writes (same format as the igemm epilogue's statistics) -- no separate pass over the tensor.
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const anoddpm_igemm_args a, const int nslab)
+{
+    __shared__ float lds_s[256 * 4];
+    __shared__ float lds_q[256 * 4];
+    const int P = a.H * a.W, N = a.N, N4 = N >> 2;
+    const int Z = a.B * a.heads;                  // heads == 1 here
+    const int TQ = N4 < 256 ? N4 : 256;
+    const int R = 256 / TQ;
+    const int npass = (N4 + TQ - 1) / TQ;
+    const int tid = threadIdx.x;
+    const int tq = tid % TQ, tr = tid / TQ;
+    const int z = blockIdx.y, slab = blockIdx.x;
+    const int sp = (P + nslab - 1) / nslab;
+    const int p0 = slab * sp;
+    const int p1 = (p0 + sp < P) ? p0 + sp : P;
+    float *st = a.stats + ((int64_t)z * nslab + slab) * N * 2;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int n4 = pass * TQ + tq;
+        f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
+        if (tr < R && n4 < N4) {
+            f32x4 add = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) add += ld4(a.bias + n4 * 4);
+            if (a.temb) add += ld4(a.temb + (int64_t)z * a.temb_ld + n4 * 4);
+            for (int pix = p0 + tr; pix < p1; pix += R) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                for (int ks = 0; ks < a.ksplit; ++ks)
+                    v += ld4(a.ws + ((((int64_t)ks * Z + z) * P + pix) * N) + n4 * 4);
+                v = v * a.alpha + add;
+                if (a.res) v += ld4(a.res + (int64_t)z * a.r_bs + (int64_t)pix * a.res_ld + n4 * 4);
+                *reinterpret_cast<f32x4 *>(a.out + (int64_t)z * a.o_bs + (int64_t)pix * a.out_ld + n4 * 4) = v;
+                cs += v;
+                cq += v * v;
+            }
+        }
+        if (tr < R) {
+            const int o = (tr * TQ + tq) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lds_s[o + e] = cs[e]; lds_q[o + e] = cq[e]; }
+        }
+        __syncthreads();
+        for (int cl = tid; cl < TQ * 4; cl += 256) {
+            const int c = pass * TQ * 4 + cl;
+            if (c < N) {
+                float s = 0.f, q = 0.f;
+                for (int r = 0; r < R; ++r) { s += lds_s[r * TQ * 4 + cl]; q += lds_q[r * TQ * 4 + cl]; }
+                st[c * 2] = s;
+                st[c * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -453,7 +510,8 @@ extern "C" int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream)
     ANODDPM_REQUIRE(a->a_mode == 0 || a->ks == 3, "igemm: resampling is only fused into 3x3 loads");
     ANODDPM_REQUIRE(a->b_mode == 0 || a->ks == 1, "igemm: activation B operands need ks == 1");
     ANODDPM_REQUIRE(a->b_mode != 2 || a->N % 4 == 0, "igemm: b_mode 2 needs N %% 4 == 0");
-    ANODDPM_REQUIRE(!a->stats || (a->ksplit == 1 && a->heads == 1), "igemm: fused statistics need ksplit == 1 and heads == 1");
+    ANODDPM_REQUIRE(!a->stats || a->heads == 1, "igemm: fused statistics need heads == 1");
+    ANODDPM_REQUIRE(!a->stats || a->ksplit == 1 || a->stats_rows >= 1, "igemm: split-K statistics need stats_rows");
     ANODDPM_REQUIRE(a->b_mode == 0 || a->ldb % 4 == 0, "igemm: ldb must be a multiple of 4");
     ANODDPM_REQUIRE(a->a0_ld % 4 == 0 && (a->c1 == 0 || a->a1_ld % 4 == 0), "igemm: pixel strides must be multiples of 4 floats");
     ANODDPM_REQUIRE(al16(a->a0) && al16(a->bmat) && (!a->a1 || al16(a->a1)), "igemm: operands must be 16-byte aligned");
@@ -497,9 +555,13 @@ extern "C" int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream)
         else      hipLaunchKernelGGL((igemm_kernel<64, 64, false>), grid, dim3(256), 0, s, k, log2TW, TH, tiles_x);
     }
     if (a->ksplit > 1) {
-        const int64_t total = Z * P * (a->N / 4);
-        const int64_t blocks = (total + 255) / 256;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, *a);
+        if (a->stats) {
+            hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((unsigned)a->stats_rows, (unsigned)Z), dim3(256), 0, s, *a, a->stats_rows);
+        } else {
+            const int64_t total = Z * P * (a->N / 4);
+            const int64_t blocks = (total + 255) / 256;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, *a);
+        }
     }
     return anoddpm::check_launch("igemm");
 }

@@ -535,6 +535,14 @@ class _Plan:
             stats = self.buf(B, tiles * 2, N, 2)
             st.stats = stats.data_ptr()
             self.stats_of[out.data_ptr()] = (stats, tiles * 2)
+        st.stats_rows = 0
+        if want_stats and ksplit > 1 and heads == 1:
+            # the split-K reduction emits the statistics: one row per pixel slab
+            rows_per_block = 256 // min(N // 4, 256)          # pixel rows a 256-thread block covers per pass
+            nslab = max(1, -(-P // (4 * rows_per_block)))     # <= 4 pixels per thread: the k-slab loads are serial
+            stats = self.buf(B, nslab, N, 2)
+            st.stats, st.stats_rows = stats.data_ptr(), nslab
+            self.stats_of[out.data_ptr()] = (stats, nslab)
         self.add(_lib.OP_IGEMM, st)
         if want_stats and st.stats is None:
             self.chan_stats(out, N, P)

@@ -176,7 +176,9 @@ typedef struct {
     float *stats;                   /* or NULL: per-channel partial sums of the OUTPUT, [B][tiles*2][N][2]
                                        {sum, sum of squares} per wave-row of each pixel tile (needs ksplit==1,
                                        heads==1); consumed by anoddpm_gn_finalize -- GroupNorm statistics
-                                       without re-reading the tensor */
+                                       without re-reading the tensor.  With ksplit > 1 the split-K reduction
+                                       emits them instead, as [B][stats_rows][N][2] */
+    int32_t stats_rows;             /* split-K only: number of pixel slabs (= rows) of the statistics */
 } anoddpm_igemm_args;
 
 int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream);

@@ -94,7 +94,12 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
     st.cfg, st.ksplit = cfg, ksplit
     ws = torch.empty(max(1, ksplit * B * P * N), device=dev) if ksplit > 1 else None
     st.ws = ws.data_ptr() if ws is not None else None
-    if stats_out is not None:
+    if stats_out is not None and ksplit > 1:
+        nslab = 3 if P > 16 else 1
+        stats = torch.full((B, nslab, N, 2), float("nan"), device=dev)
+        st.stats, st.stats_rows = stats.data_ptr(), nslab
+        stats_out.append(stats)
+    elif stats_out is not None:
         bm = 128 if cfg == 0 else 64
         tiles = -(-P // bm) if ks == 1 else (Hout // min(Hout, 32)) * -(-Hout // (bm // min(Hout, 32)))
         stats = torch.full((B, tiles * 2, N, 2), float("nan"), device=dev)

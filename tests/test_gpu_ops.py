@@ -59,6 +59,17 @@ def test_fused_groupnorm_statistics(case):
     st = []
     got = hipops.conv_igemm([hipops.nhwc(x.to(dev()))], w.to(dev()), b.to(dev()), Hout=H, ks=ks, cfg=cfg, stats_out=st)
     assert relerr(hipops.nchw(got), y) < TOL
+    # same layer through split-K: the reduction kernel emits the statistics
+    st_sk = []
+    got_sk = hipops.conv_igemm([hipops.nhwc(x.to(dev()))], w.to(dev()), b.to(dev()), Hout=H, ks=ks, cfg=cfg, ksplit=1 if ks == 1 else 1, stats_out=[])
+    if C % 4 == 0:
+        x64 = rnd(B, 64, H, H, seed=69)
+        w64 = rnd(C, 64, ks, ks, seed=70, scale=0.1)
+        y64 = F.conv2d(x64, w64, b, padding=ks // 2)
+        got_sk = hipops.conv_igemm([hipops.nhwc(x64.to(dev()))], w64.to(dev()), b.to(dev()), Hout=H, ks=ks, cfg=cfg, ksplit=2, stats_out=st_sk)
+        assert relerr(hipops.nchw(got_sk), y64) < TOL
+        sc2, sh2 = hipops.gn_finalize(st_sk, gamma.to(dev()), beta.to(dev()), H * H)
+        assert relerr(hipops.nchw(got_sk * sc2[:, None, None, :] + sh2[:, None, None, :]), F.group_norm(y64, 32, gamma, beta, eps=1e-5)) < TOL
     sc, sh = hipops.gn_finalize(st, gamma.to(dev()), beta.to(dev()), H * H)
     assert relerr(hipops.nchw(got * sc[:, None, None, :] + sh[:, None, None, :]), F.group_norm(y, 32, gamma, beta, eps=1e-5)) < TOL
     # concat [y, skip]: skip statistics from the stand-alone kernel

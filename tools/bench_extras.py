@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Side measurements that are parity-test configurations rather than the bench line (BASELINE configs 3 & 4):
+  * config 4: rand_3d_octaves((1000,256,256), 8, 0.8, 64) -- HIP kernel time vs the C/OpenMP oracle on host cores
+  * config 3 (per-GPU share): one training step (p_loss -> backward -> clip -> fused AdamW+EMA), batch 4 at 256^2
+Run on the GPU box:  python tools/bench_extras.py  (prints one JSON object per measurement)."""
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def simplex_c4():
+    from anoddpm_amd import _lib
+    from anoddpm_amd._lib import SimplexArgs, check, current_stream, lib
+    from simplex import Simplex_CLASS
+    from oracle.simplex_oracle import OracleSimplex
+    s = Simplex_CLASS()
+    s.newSeed(12345)
+    dev = torch.device("cuda:0")
+    out = torch.empty((1000, 256, 256), dtype=torch.float64, device=dev)
+    a = SimplexArgs()
+    a.out, a.zvals, a.tables, a.table_sel = out.data_ptr(), None, s.device_tables(dev).data_ptr(), None
+    a.z0, a.out_slice_stride, a.nslices, a.H, a.W = 0, 256 * 256, 1000, 256, 256
+    a.table_slice_stride, a.table_sel_scale, a.octaves, a.persistence, a.frequency = 0, 1, 8, 0.8, 64.0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    check(lib().anoddpm_simplex3_octaves_f64(ctypes.byref(a), current_stream()))
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        check(lib().anoddpm_simplex3_octaves_f64(ctypes.byref(a), current_stream()))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    evals = 1000 * 256 * 256 * 8
+    o = OracleSimplex(12345)
+    t0 = time.perf_counter()
+    ref = o._octaves(np.arange(0, 1000, 25), 256, 256, 8, 0.8, 64)          # 40 of the 1000 slices
+    cpu_s = (time.perf_counter() - t0) * 25
+    ok = bool((out[::25].cpu().numpy().view(np.uint64) == ref.view(np.uint64)).all())
+    return {"what": "config4 simplex volume 1000x256x256 x 8 octaves (fp64 out)", "gpu_ms": ms,
+            "gpu_Gevals_per_s": evals / ms / 1e6, "gpu_out_GBps": 1000 * 256 * 256 * 8 / ms / 1e6,
+            "cpu_oracle_s_scaled_from_40_slices": cpu_s, "cpu_threads": os.cpu_count(), "speedup": cpu_s * 1e3 / ms,
+            "bit_exact_vs_oracle_on_sample": ok}
+
+
+def train_step_c3(batch=4, steps=3):
+    import copy
+    import GaussianDiffusion as GD
+    from UNet import UNetModel
+    from anoddpm_amd.training import FlatBuffers, FusedAdamWEMA, train_step
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = UNetModel(256, 128, n_heads=2, attention_resolutions="16,8").to(dev)
+    ema = copy.deepcopy(model)
+    flat, flat_ema = FlatBuffers(model), FlatBuffers(ema)
+    opt = FusedAdamWEMA(flat, flat_ema, lr=1e-4, notify=(model, ema))
+    diff = GD.GaussianDiffusionModel([256, 256], GD.get_beta_schedule(1000, "linear"), noise="simplex")
+    args = {"train_start": True, "sample_distance": 800}
+    x = torch.rand(batch, 1, 256, 256, device=dev) * 2 - 1
+    train_step(model, diff, x, args, flat, None, opt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = train_step(model, diff, x, args, flat, None, opt)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"what": f"config3 per-GPU share: train step batch {batch} @256^2 base128 (autograd interim fwd/bwd + fused AdamW+EMA)",
+            "sec_per_step": dt, "images_per_s": batch / dt, "loss": float(loss), "params": flat.numel,
+            "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c4", "c3"]
+    if "c4" in which:
+        print(json.dumps(simplex_c4()), flush=True)
+    if "c3" in which:
+        print(json.dumps(train_step_c3()), flush=True)
