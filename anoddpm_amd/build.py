@@ -20,6 +20,7 @@ SOURCES = {
     "diffusion.hip": ["-ffp-contract=off"],
     "unet_kernels.hip": [],
     "igemm.hip": [],
+    "winograd.hip": [],
     "executor.hip": [],
     "optim.hip": [],
 }

@@ -28,6 +28,8 @@ inline int check_launch(const char *what)
     return ANODDPM_OK;
 }
 
+int launch_winograd(const anoddpm_igemm_args *a, hipStream_t s);   // winograd.hip (cfg == 2 of anoddpm_igemm)
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 __device__ __forceinline__ float silu_f(float x)

@@ -359,6 +359,23 @@ def _pack_conv(w):
             .permute(0, 1, 3, 2).contiguous())
 
 
+_WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+
+
+def _pack_wino(w):
+    """OIHW 3x3 -> Winograd F(2x2,3x3) weights U = G g G^T, laid out [16][I/4][O][4] (xi = 4*u + v)."""
+    o, i, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    G = _WINO_G.to(device=w.device, dtype=torch.float64)
+    U = torch.einsum("ua,oiab,vb->uvio", G, w.detach().double(), G).float()          # [4][4][I][O]
+    return U.reshape(16, i // 4, 4, o).permute(0, 1, 3, 2).contiguous()
+
+
+def _use_winograd():
+    import os
+    return os.environ.get("ANODDPM_NO_WINOGRAD", "0") != "1"
+
+
 class _Plan:
     """Compiled forward for one (batch, size, device): buffers + packed weights + flat op list."""
 
@@ -373,6 +390,7 @@ class _Plan:
         self.igemm_flops = 0.0
         self._ws_need = 0
         self.stats_of = {}
+        self.igemm_log = []
         with torch.no_grad():
             self._build()
         n = len(self.ops)
@@ -392,7 +410,11 @@ class _Plan:
         """Fixed device buffer holding fn(param) -- refreshed in place when parameters change."""
         params = dict(self.model.named_parameters())
         src = params[key]
-        dst = fn(src.to(self.device)).contiguous()
+        res = fn(src.to(self.device))
+        # the packed buffer must OWN its storage: for fp32 bias / gamma / beta `fn` is the identity and the result
+        # would alias the parameter -- refresh_weights' dst.copy_() would then bump the parameter's version
+        # counter and trigger a full re-pack on every forward
+        dst = torch.empty(res.shape, dtype=res.dtype, device=self.device).copy_(res)
         self.keep.append(dst)
         self.packers.append((key, fn, dst))
         return dst
@@ -459,7 +481,8 @@ class _Plan:
 
     def igemm(self, *, srcs, H, W, ks, N, bmat, out, out_ld=None, gn=None, act=0, a_mode=0, bias=None,
               temb=None, temb_ld=0, res=None, res_ld=0, b_mode=0, ldb=0, heads=1, alpha=1.0,
-              a_strides=None, b_strides=(0, 0), o_strides=None, r_strides=None, kind="conv3", want_stats=False):
+              a_strides=None, b_strides=(0, 0), o_strides=None, r_strides=None, kind="conv3", want_stats=False,
+              wino=None):
         B = self.B
         P = H * W
         c0 = srcs[0][1]
@@ -480,7 +503,7 @@ class _Plan:
         st.gn_scale = gn[0].data_ptr() if gn else None
         st.gn_shift = gn[1].data_ptr() if gn else None
         st.gn_ld = K
-        st.bmat = bmat if isinstance(bmat, int) else bmat.data_ptr()
+        self._pending_bmat = (st, bmat, wino)
         st.b_bs, st.b_hs = b_strides
         st.bias = bias.data_ptr() if bias is not None else None
         st.temb = temb if temb else None
@@ -514,20 +537,30 @@ class _Plan:
             return th <= H and H % th == 0
         blocks128 = (P // 128) * ((N + 127) // 128) * Z if ok128() else 0
         cfg = 0 if (blocks128 >= 256 and N >= 96) else 1
+        wino_blocks = (H // 16) * (W // 16) * ((N + 63) // 64) * Z
+        if (wino and ks == 3 and b_mode == 0 and heads == 1 and a_mode in (0, 1) and H % 16 == 0 and W % 16 == 0
+                and K % 16 == 0 and (c1 == 0 or c0 % 16 == 0) and wino_blocks >= 96 and N >= 32 and _use_winograd()):
+            cfg = 2
         bm = 128 if cfg == 0 else 64
         blocks = -(-P // bm) * ((N + bm - 1) // bm) * Z
         nchunks = (K + 31) // 32
         ksplit = 1
-        if blocks < 512 and nchunks > 1 and N % 4 == 0:
+        if cfg != 2 and blocks < 512 and nchunks > 1 and N % 4 == 0:
             ksplit = int(min(nchunks, 16, max(1, -(-512 // blocks))))
         st.cfg, st.ksplit = cfg, ksplit
+        _st, _bmat, _wino = self._pending_bmat
+        if cfg == 2:
+            _bmat = _wino()                                    # Winograd-domain weights for this layer
+        st.bmat = _bmat if isinstance(_bmat, int) else _bmat.data_ptr()
         st.ws = None                      # patched after the build (one shared workspace)
         if ksplit > 1:
             self._ws_need = max(self._ws_need, ksplit * Z * P * N)
         st.stats = None
         if want_stats and ksplit == 1 and heads == 1:
             # the epilogue emits per-channel {sum, sumsq} per wave-row of every pixel tile
-            if ks == 1:
+            if cfg == 2:
+                tiles = (H // 16) * (W // 16)
+            elif ks == 1:
                 tiles = -(-P // bm)
             else:
                 tw = min(W, 32)
@@ -544,6 +577,8 @@ class _Plan:
             st.stats, st.stats_rows = stats.data_ptr(), nslab
             self.stats_of[out.data_ptr()] = (stats, nslab)
         self.add(_lib.OP_IGEMM, st)
+        self.igemm_log.append(dict(wino=(cfg == 2), kind=kind, H=H, W=W, K=K, N=N, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads,
+                                   cfg=cfg, ksplit=ksplit, dual=bool(c1), gflop=2.0 * K * N * ks * ks * P * Z / 1e9))
         if want_stats and st.stats is None:
             self.chan_stats(out, N, P)
         fl = 2.0 * K * N * ks * ks * P * Z
@@ -613,6 +648,7 @@ class _Plan:
             self.igemm(srcs=srcs, H=Hout, W=Hout, ks=3, N=cout, gn=g1, act=1,
                        a_mode={None: 0, "up": 1, "down": 2}[resample],
                        bmat=self.packed(prefix + ".in_layers.2.weight", _pack_conv),
+                       wino=lambda p=prefix: self.packed(p + ".in_layers.2.weight", _pack_wino),
                        bias=self.packed(prefix + ".in_layers.2.bias", lambda t: t.detach().float()),
                        temb=emb_all.data_ptr() + 4 * offs[prefix], temb_ld=tot, out=h1, want_stats=True)
             g2 = self.gn([(h1, cout)], Pout, prefix + ".out_layers.0.weight", prefix + ".out_layers.0.bias")
@@ -636,6 +672,7 @@ class _Plan:
             h2 = self.buf(B, Pout, cout)
             self.igemm(srcs=[(h1, cout)], H=Hout, W=Hout, ks=3, N=cout, gn=g2, act=1,
                        bmat=self.packed(prefix + ".out_layers.3.weight", _pack_conv),
+                       wino=lambda p=prefix: self.packed(p + ".out_layers.3.weight", _pack_wino),
                        bias=self.packed(prefix + ".out_layers.3.bias", lambda t: t.detach().float()),
                        res=sk, out=h2, want_stats=True)
             return h2, Hout

@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event instrumented pass")
+    ap.add_argument("--dump-plan", default="", help="write the igemm launch list of the compiled plan (JSON) here")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -174,6 +175,9 @@ def main():
         el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = el.item()
+    if args.dump_plan and rank == 0:
+        with open(args.dump_plan, "w") as f:
+            json.dump(next(iter(model._plans.values())).igemm_log, f)
     ms_per_step = 1000.0 * elapsed / args.steps
     value = (B * world) / (T_STEPS * ms_per_step / 1000.0)
     finite = bool(torch.isfinite(chain.x).all().item())

@@ -170,7 +170,8 @@ typedef struct {
     int32_t out_ld, res_ld;
     int32_t B, heads;               /* Z = B*heads */
     int32_t ksplit;                 /* >= 1 */
-    int32_t cfg;                    /* 0: 128x128 tile, 1: 64x64 tile */
+    int32_t cfg;                    /* 0: 128x128 tile, 1: 64x64 tile, 2: Winograd F(2x2,3x3): ks 3, a_mode 0/1, H,W % 16 == 0,
+                                       ksplit 1, bmat = host-transformed weights [16][K/4][N][4] (G g G^T) */
     float alpha;
     int32_t gn_ld;                  /* row length of gn_scale/gn_shift (= K) */
     float *stats;                   /* or NULL: per-channel partial sums of the OUTPUT, [B][tiles*2][N][2]

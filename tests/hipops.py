@@ -7,7 +7,7 @@ import torch
 from anoddpm_amd import _lib
 from anoddpm_amd._lib import (HeadArgs, ChanStatsArgs, GnFinalizeArgs, GnArgs, IgemmArgs, LinearArgs, PosembArgs, ResampleArgs, SoftmaxArgs, StemArgs,
                               check, current_stream, lib)
-from anoddpm_amd.unet import _pack_conv
+from anoddpm_amd.unet import _pack_conv, _pack_wino
 
 
 def nhwc(x):
@@ -74,7 +74,7 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
     P = Hout * Hout
     Pin = srcs[0].shape[1] * srcs[0].shape[2]
     st = IgemmArgs()
-    wp = _pack_conv(w)
+    wp = _pack_wino(w) if cfg == 2 else _pack_conv(w)
     out = torch.full((B, Hout, Hout, N), float("nan"), device=dev)
     st.a0, st.a1 = srcs[0].data_ptr(), srcs[1].data_ptr() if c1 else None
     st.a0_ld, st.a1_ld, st.c0, st.c1 = c0, max(c1, 4), c0, c1
@@ -101,7 +101,10 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
         stats_out.append(stats)
     elif stats_out is not None:
         bm = 128 if cfg == 0 else 64
-        tiles = -(-P // bm) if ks == 1 else (Hout // min(Hout, 32)) * -(-Hout // (bm // min(Hout, 32)))
+        if cfg == 2:
+            tiles = (Hout // 16) ** 2
+        else:
+            tiles = -(-P // bm) if ks == 1 else (Hout // min(Hout, 32)) * -(-Hout // (bm // min(Hout, 32)))
         stats = torch.full((B, tiles * 2, N, 2), float("nan"), device=dev)
         st.stats = stats.data_ptr()
         stats_out.append(stats)

@@ -219,3 +219,57 @@ def test_head_conv(case):
     sc, sh = hipops.gn_affine([xs], gamma.to(dev()), beta.to(dev()))
     got = hipops.head(xs, w.to(dev()), b.to(dev()), sc, sh)
     assert relerr(got, ref) < TOL
+
+
+WINO_CASES = [
+    # B, (c0, c1), Cout, Hout, a_mode, gn, act, temb, res
+    (1, (32, 0), 64, 16, 0, False, 0, False, False),       # bare transform check, one workgroup
+    (2, (64, 0), 128, 32, 0, True, 1, True, True),         # full ResBlock conv: GN + SiLU + temb + residual
+    (1, (128, 0), 128, 64, 0, True, 1, False, False),
+    (2, (64, 64), 128, 16, 0, True, 1, True, True),        # virtual concat
+    (1, (96, 32), 96, 32, 0, True, 1, False, True),        # N tail (96 = 64 + 32)
+    (1, (64, 0), 64, 32, 1, True, 1, False, False),        # fused nearest x2
+    (1, (16, 0), 32, 48, 0, False, 0, False, False),       # non power-of-two image, single K iteration
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_conv(case):
+    """cfg = 2: Winograd F(2x2,3x3) on the matrix pipe must equal the direct 3x3 convolution (fp32; the
+    transform adds a few ulps: tolerance 1e-4 of the tensor magnitude, north star 1e-3)."""
+    import hipops
+    B, (c0, c1), N, Hout, a_mode, use_gn, act, use_temb, use_res = case
+    C = c0 + c1
+    Hin = Hout if a_mode == 0 else Hout // 2
+    x = rnd(B, C, Hin, Hin, seed=81)
+    w = rnd(N, C, 3, 3, seed=82, scale=1.0 / math.sqrt(C * 9))
+    b = rnd(N, seed=83, scale=0.1)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=84), 0.1 * rnd(C, seed=85)
+    temb = rnd(B, N, seed=86) if use_temb else None
+    res = rnd(B, N, Hout, Hout, seed=87) if use_res else None
+    hh = x
+    if use_gn:
+        hh = F.group_norm(hh, 32, gamma, beta, eps=1e-5)
+    if act:
+        hh = F.silu(hh)
+    if a_mode == 1:
+        hh = F.interpolate(hh, scale_factor=2, mode="nearest")
+    ref = F.conv2d(hh, w, b, padding=1)
+    if temb is not None:
+        ref = ref + temb[:, :, None, None]
+    if res is not None:
+        ref = ref + res
+    xs = hipops.nhwc(x.to(dev()))
+    srcs = [xs[..., :c0].contiguous()] + ([xs[..., c0:].contiguous()] if c1 else [])
+    gn = hipops.gn_affine(srcs, gamma.to(dev()), beta.to(dev())) if use_gn else None
+    st = []
+    got = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), Hout=Hout, ks=3, gn=gn, act=act, a_mode=a_mode,
+                            temb=temb.to(dev()) if temb is not None else None,
+                            res=hipops.nhwc(res.to(dev())) if res is not None else None, cfg=2, stats_out=st)
+    err = relerr(hipops.nchw(got), ref)
+    assert err < 1e-4, err
+    # fused statistics of the Winograd epilogue
+    if N % 32 == 0:
+        g2, b2 = 1 + 0.1 * rnd(N, seed=88), 0.1 * rnd(N, seed=89)
+        sc, sh = hipops.gn_finalize(st, g2.to(dev()), b2.to(dev()), Hout * Hout)
+        assert relerr(hipops.nchw(got * sc[:, None, None, :] + sh[:, None, None, :]), F.group_norm(ref, 32, g2, b2, eps=1e-5)) < 2e-4

@@ -99,3 +99,22 @@ def test_batch_invariance_and_training_path_agree():
     assert ((yt.detach() - y).abs().max() / y.abs().max()) < REL
     yt.square().mean().backward()
     assert m.out["2"].weight.grad is not None and torch.isfinite(m.out["2"].weight.grad).all()
+
+
+def test_packed_weights_are_not_repacked_every_forward():
+    """Regression: packed buffers once aliased fp32 parameters, so every forward bumped the parameters' version
+    counters and re-packed all weights."""
+    name = "i32_b32_h1"
+    g = np.load(os.path.join(GOLDEN, f"unet_{name}.npz"))
+    m, sd, kw = build(name)
+    x, t = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["t"]).to(DEV)
+    with torch.no_grad():
+        m(x, t)
+        plan = next(iter(m._plans.values()))
+        tok = plan.token
+        versions = [p._version for p in m.parameters()]
+        m(x, t)
+        m(x, t)
+    assert plan.token == tok and versions == [p._version for p in m.parameters()]
+    ptrs = {p.data_ptr() for p in m.parameters()}
+    assert all(dst.data_ptr() not in ptrs for _, _, dst in plan.packers)
