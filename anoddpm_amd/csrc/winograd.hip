@@ -9,9 +9,10 @@
 // (weights are pre-transformed on the host, the 1/2 factors live there), measured error vs the direct form
 // is ~1e-6 of the tensor's magnitude.
 //
-// Mapping to gfx950.  The limit is accumulator capacity: a wave must hold 16 transform positions of its
-// tile.  One wave per SIMD (512 registers per lane): wave tile = 32 tiles x 32 output channels x 16 positions
-// = 256 accumulator registers.  Workgroup = 4 waves (2x2) = 64 Winograd tiles (a 16x16 output patch) x 64
+// Mapping to gfx950.  The limit is accumulator capacity: 16 transform positions of a 32 tiles x 32 channels
+// tile are 256 registers.  They are split over TWO waves (8 positions = 128 registers each), so a workgroup is
+// 8 waves = two per SIMD that cover each other's LDS / barrier stalls (a first version with one 256-accumulator
+// wave per SIMD left the matrix pipe < 50 % busy).  Workgroup = 64 Winograd tiles (a 16x16 output patch) x 64
 // output channels; K advances 16 channels per iteration:
 //   S1  activated 18x18 input patch (affine + SiLU, zero padding, nearest-x2 / concat on the load) -> LDS
 //       and the pre-transformed weight tile U[16][16 ch][64] -> LDS         (both prefetched into registers
@@ -37,7 +38,7 @@ constexpr int WPATCH = 18 * 18;    // input patch pixels
 
 __device__ __forceinline__ f32x4 wld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
-__global__ __launch_bounds__(256, 1) void wino_kernel(const anoddpm_igemm_args a)
+__global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a)
 {
     // LDS (floats): Dt[324][16] | V[16][64][16] | U[16][4][64][4]
     constexpr int DT_F = WPATCH * WKC, V_F = 16 * WTILES * WKC, U_F = 16 * (WKC / 4) * WBN * 4;
@@ -46,10 +47,15 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const anoddpm_igemm_args a
     f32x4 *ldsV = reinterpret_cast<f32x4 *>(lds + DT_F);          // [xi][tile][4 quads], quad ^= (tile>>2)&3
     f32x4 *ldsU = reinterpret_cast<f32x4 *>(lds + DT_F + V_F);    // [xi][k4][n]
 
+    // 8 waves: wave = (xh, wm, wn).  (wm, wn) picks the 32 tiles x 32 channels wave tile as before; xh picks
+    // which half of the transform rows (u = 2*xh, 2*xh+1 -> 8 of the 16 positions) the wave accumulates.
+    // Two waves share each SIMD and cover each other's LDS / barrier stalls; 128 accumulator registers each.
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int xh = __builtin_amdgcn_readfirstlane(wave >> 2);
+    const int wm = (wave >> 1) & 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
+    const int t256 = tid & 255;
 
     const int H = a.H, W = a.W;
     const int K = a.c0 + a.c1, N = a.N, K4 = K >> 2;
@@ -68,12 +74,12 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const anoddpm_igemm_args a
     const int nchunks = K / WKC;
 
     // ---- S1 geometry: patch slots of this thread (pixel = idx>>2, quad = idx&3), fixed for the workgroup
-    constexpr int PJ = (WPATCH * 4 + 255) / 256;                   // 6 slots
+    constexpr int PJ = (WPATCH * 4 + 511) / 512;                   // 3 slots
     int spix[PJ];
     const int pq = tid & 3;
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
-        const int idx = tid + j * 256;
+        const int idx = tid + j * 512;
         const int p = idx >> 2;
         const int py = p / 18, px = p - py * 18;
         const int gy = y0 + py - 1, gx = x0 + px - 1;
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const anoddpm_igemm_args a
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
-            const int idx = tid + j * 256;
+            const int idx = tid + j * 512;
             if (idx < WPATCH * 4) {
                 f32x4 v = praw[j];
                 if (affine) v = v * asc + ash;
@@ -112,47 +118,43 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const anoddpm_igemm_args a
         }
     };
 
-    // ---- U tile: thread owns (k4 = tid>>6, n = tid&63) of every transform position
-    f32x4 ureg[16];
-    const int un = tid & 63, uk4 = tid >> 6;
+    // ---- U tile: thread owns (k4, n) = t256 of every second transform position (parity tid>>8)
+    f32x4 ureg[8];
+    const int un = t256 & 63, uk4 = t256 >> 6, upar = tid >> 8;
     const int unc = n0 + un < N ? n0 + un : N - 1;                  // N tail: clamped, columns discarded later
     auto load_U = [&](int chunk) {
-        const float *base = a.bmat + (((int64_t)(chunk * (WKC / 4) + uk4)) * N + unc) * 4;
         const int64_t xi_stride = (int64_t)K4 * N * 4;
+        const float *base = a.bmat + (((int64_t)(chunk * (WKC / 4) + uk4)) * N + unc) * 4 + upar * xi_stride;
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) ureg[xi] = wld4(base + xi * xi_stride);
+        for (int j = 0; j < 8; ++j) ureg[j] = wld4(base + (2 * j) * xi_stride);
     };
     auto store_U = [&]() {
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) ldsU[xi * 256 + tid] = ureg[xi];   // [xi][k4][n] with k4*64+n == tid
+        for (int j = 0; j < 8; ++j) ldsU[(2 * j + upar) * 256 + t256] = ureg[j];   // [xi][k4][n], k4*64+n == t256
     };
 
-    // ---- S2: input transform, one thread per (tile, quad)
-    const int ttile = tid >> 2, tquad = tid & 3;
+    // ---- S2: input transform, one thread per (tile, quad, row-pair uh)
+    const int ttile = t256 >> 2, tquad = tid & 3, uh = tid >> 8;
     const int tty = ttile >> 3, ttx = ttile & 7;
     auto input_transform = [&]() {
-        // rows: t = B^T d   (B^T x = [x0-x2, x1+x2, x2-x1, x1-x3]); one patch column at a time keeps the
-        // live set at 16 + 4 float4
-        f32x4 t[4][4];
+        // rows u = 2*uh, 2*uh+1 of t = B^T d:  t0 = d0-d2, t1 = d1+d2 | t2 = d2-d1, t3 = d1-d3
+        f32x4 t[2][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4 d0 = ldsD[((2 * tty + 0) * 18 + 2 * ttx + j) * 4 + tquad];
-            const f32x4 d1 = ldsD[((2 * tty + 1) * 18 + 2 * ttx + j) * 4 + tquad];
-            const f32x4 d2 = ldsD[((2 * tty + 2) * 18 + 2 * ttx + j) * 4 + tquad];
-            const f32x4 d3 = ldsD[((2 * tty + 3) * 18 + 2 * ttx + j) * 4 + tquad];
-            t[0][j] = d0 - d2;
-            t[1][j] = d1 + d2;
-            t[2][j] = d2 - d1;
-            t[3][j] = d1 - d3;
+            const f32x4 dm = ldsD[((2 * tty + 1) * 18 + 2 * ttx + j) * 4 + tquad];      // d1
+            const f32x4 dn = ldsD[((2 * tty + 2) * 18 + 2 * ttx + j) * 4 + tquad];      // d2
+            const f32x4 de = ldsD[((2 * tty + (uh ? 3 : 0)) * 18 + 2 * ttx + j) * 4 + tquad];   // d0 or d3
+            if (uh == 0) { t[0][j] = de - dn; t[1][j] = dm + dn; }
+            else         { t[0][j] = dn - dm; t[1][j] = dm - de; }
         }
-        // columns: V = t B
         const int sw = (tquad ^ ((ttile >> 2) & 3));
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const f32x4 v0 = t[u][0] - t[u][2];
-            const f32x4 v1 = t[u][1] + t[u][2];
-            const f32x4 v2 = t[u][2] - t[u][1];
-            const f32x4 v3 = t[u][1] - t[u][3];
+        for (int uu = 0; uu < 2; ++uu) {
+            const int u = 2 * uh + uu;
+            const f32x4 v0 = t[uu][0] - t[uu][2];
+            const f32x4 v1 = t[uu][1] + t[uu][2];
+            const f32x4 v2 = t[uu][2] - t[uu][1];
+            const f32x4 v3 = t[uu][1] - t[uu][3];
             ldsV[((u * 4 + 0) * WTILES + ttile) * 4 + sw] = v0;
             ldsV[((u * 4 + 1) * WTILES + ttile) * 4 + sw] = v1;
             ldsV[((u * 4 + 2) * WTILES + ttile) * 4 + sw] = v2;
@@ -160,16 +162,17 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const anoddpm_igemm_args a
         }
     };
 
-    // ---- accumulators: 16 transform positions of a 32 tiles x 32 channels wave tile
-    f32x16 acc[16];
+    // ---- accumulators: 8 transform positions (u = 2*xh + {0,1}, v = 0..3) of a 32 x 32 wave tile
+    f32x16 acc[8];
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
+    for (int e = 0; e < 8; ++e)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
 
     const int atile = wm * 32 + l31;                                // this lane's A row (tile)
     const int asw = (atile >> 2) & 3;
     const int bcol = wn * 32 + l31;                                 // this lane's B column (channel)
+    const int xi0 = xh * 8;                                         // first transform position of this wave
 
     load_patch(0);
     load_U(0);
@@ -180,22 +183,65 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const anoddpm_igemm_args a
         input_transform();
         if (chunk + 1 < nchunks) { load_patch(chunk + 1); load_U(chunk + 1); }   // in flight behind the MFMAs
         __syncthreads();
+        // 16 operand pairs (8 positions x 2 k-groups); pair g+1 is read before pair g's four MFMAs are issued
+        f32x4 av[2], bv[2];
+        auto read_pair = [&](int g, int set) {
+            const int xi = xi0 + (g >> 1), q = (g & 1) * 2 + h;
+            av[set] = ldsV[(xi * WTILES + atile) * 4 + (q ^ asw)];
+            bv[set] = ldsU[(xi * (WKC / 4) + q) * WBN + bcol];
+        };
+        read_pair(0, 0);
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
+        for (int g = 0; g < 16; ++g) {
+            const int set = g & 1;
+            if (g + 1 < 16) read_pair(g + 1, set ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k8 = 0; k8 < WKC / 8; ++k8) {
-                const int q = k8 * 2 + h;
-                const f32x4 av = ldsV[(xi * WTILES + atile) * 4 + (q ^ asw)];
-                const f32x4 bv = ldsU[(xi * (WKC / 4) + q) * WBN + bcol];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc[xi], 0, 0, 0);
-            }
+            for (int kk = 0; kk < 4; ++kk)
+                acc[g >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[set][kk], bv[set][kk], acc[g >> 1], 0, 0, 0);
         }
         __syncthreads();
     }
 
-    // ---- epilogue: output transform A^T M A (A^T m = [m0+m1+m2, m1-m2-m3]) + bias / temb / residual / stats
+    // ---- epilogue.  The output transform Y = A^T M A is linear in M, so each wave forms the PARTIAL 2x2 outputs
+    // of its 8 positions (A^T = [[1,1,1,0],[0,1,-1,-1]]: rows u=0,1 give tm0 = M0+M1, tm1 = M1; rows u=2,3 give
+    // tm0 = M2, tm1 = -M2-M3), the two halves swap partials through LDS (each finalises 8 of the 16 tile rows).
+    auto partial = [&](int r, float (&out4)[4]) {                  // partial 2x2 output of tile row r from this wave's 8 positions
+        float tm[2][4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float m0 = acc[v][r], m1 = acc[4 + v][r];        // positions (2xh, v) and (2xh+1, v)
+            if (xh == 0) { tm[0][v] = m0 + m1; tm[1][v] = m1; }
+            else         { tm[0][v] = m0;      tm[1][v] = -m0 - m1; }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            out4[i * 2 + 0] = tm[i][0] + tm[i][1] + tm[i][2];
+            out4[i * 2 + 1] = tm[i][1] - tm[i][2] - tm[i][3];
+        }
+    };
+    // exchange buffer (re-uses the V region; the loop's last barrier has passed): ex[pair][writer xh][8 rows][4][64 lanes]
+    float *ex = lds + DT_F;
+    const int pair = wave & 3;
+    if (xh == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {                            // rows 8..15 are finalised by the xh = 1 wave
+            float p4[4];
+            partial(8 + rr, p4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ex[(((pair * 2 + 0) * 8 + rr) * 4 + e) * 64 + lane] = p4[e];
+        }
+    } else {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {                            // rows 0..7 are finalised by the xh = 0 wave
+            float p4[4];
+            partial(rr, p4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ex[(((pair * 2 + 1) * 8 + rr) * 4 + e) * 64 + lane] = p4[e];
+        }
+    }
+    __syncthreads();
+
     const int n = n0 + bcol;
     const bool nok = n < N;
     const int nc = nok ? n : 0;
@@ -205,43 +251,41 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const anoddpm_igemm_args a
     if (a.bias) add += a.bias[nc];
     if (a.temb) add += a.temb[(int64_t)b * a.temb_ld + nc];
     float cs = 0.f, cq = 0.f;
+    float rv[8][4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int rr = 0; rr < 8; ++rr) {                                // all residual loads first
+        const int r = xh * 8 + rr;
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         const int tile = wm * 32 + row;
         const int oy = y0 + 2 * (tile >> 3), ox = x0 + 2 * (tile & 7);
-        float tm[2][4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            tm[0][v] = acc[0 * 4 + v][r] + acc[1 * 4 + v][r] + acc[2 * 4 + v][r];
-            tm[1][v] = acc[1 * 4 + v][r] - acc[2 * 4 + v][r] - acc[3 * 4 + v][r];
-        }
-        float y[2][2];
+        for (int e = 0; e < 4; ++e)
+            rv[rr][e] = R ? R[((int64_t)(oy + (e >> 1)) * W + ox + (e & 1)) * a.res_ld + nc] : 0.f;
+    }
+    auto finalize = [&](int rbase) {                               // rbase is a literal (0 or 8): static accumulator indices
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            y[i][0] = tm[i][0] + tm[i][1] + tm[i][2];
-            y[i][1] = tm[i][1] - tm[i][2] - tm[i][3];
-        }
-        float rv[2][2];
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = rbase + rr;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int tile = wm * 32 + row;
+            const int oy = y0 + 2 * (tile >> 3), ox = x0 + 2 * (tile & 7);
+            float p4[4];
+            partial(r, p4);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                rv[i][j] = R ? R[((int64_t)(oy + i) * W + ox + j) * a.res_ld + nc] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float v = a.alpha * y[i][j] + add + rv[i][j];
+            for (int e = 0; e < 4; ++e) {
+                const float other = ex[(((pair * 2 + (1 - xh)) * 8 + rr) * 4 + e) * 64 + lane];
+                const float v = a.alpha * (p4[e] + other) + add + rv[rr][e];
                 if (nok) {
-                    O[((int64_t)(oy + i) * W + ox + j) * a.out_ld + nc] = v;
+                    O[((int64_t)(oy + (e >> 1)) * W + ox + (e & 1)) * a.out_ld + nc] = v;
                     cs += v;
                     cq += v * v;
                 }
             }
-    }
+        }
+    };
+    if (xh == 0) finalize(0); else finalize(8);
     if (a.stats) {
-        float *st = a.stats + ((int64_t)b * (gridDim.x * 2) + blockIdx.x * 2 + wm) * N * 2;
+        float *st = a.stats + ((int64_t)b * (gridDim.x * 4) + blockIdx.x * 4 + wm * 2 + xh) * N * 2;
         const float s2 = cs + __shfl_xor(cs, 32);
         const float q2 = cq + __shfl_xor(cq, 32);
         if (h == 0 && nok) { st[n * 2] = s2; st[n * 2 + 1] = q2; }
@@ -262,7 +306,7 @@ int launch_winograd(const anoddpm_igemm_args *a, hipStream_t s)
     ANODDPM_REQUIRE(K % WKC == 0 && (a->c1 == 0 || a->c0 % WKC == 0), "winograd: channel counts must be multiples of 16");
     dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)((a->N + WBN - 1) / WBN), (unsigned)a->B);
     ANODDPM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "winograd: grid too large");
-    hipLaunchKernelGGL(wino_kernel, grid, dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(wino_kernel, grid, dim3(512), 0, s, *a);
     return check_launch("winograd");
 }
 

@@ -539,7 +539,7 @@ class _Plan:
         cfg = 0 if (blocks128 >= 256 and N >= 96) else 1
         wino_blocks = (H // 16) * (W // 16) * ((N + 63) // 64) * Z
         if (wino and ks == 3 and b_mode == 0 and heads == 1 and a_mode in (0, 1) and H % 16 == 0 and W % 16 == 0
-                and K % 16 == 0 and (c1 == 0 or c0 % 16 == 0) and wino_blocks >= 96 and N >= 32 and _use_winograd()):
+                and K % 16 == 0 and (c1 == 0 or c0 % 16 == 0) and wino_blocks >= 200 and N >= 32 and _use_winograd()):
             cfg = 2
         bm = 128 if cfg == 0 else 64
         blocks = -(-P // bm) * ((N + bm - 1) // bm) * Z
@@ -565,9 +565,10 @@ class _Plan:
             else:
                 tw = min(W, 32)
                 tiles = (W // tw) * -(-H // (bm // tw))
-            stats = self.buf(B, tiles * 2, N, 2)
+            rows = tiles * (4 if cfg == 2 else 2)              # wave-rows per pixel tile that emit a partial row
+            stats = self.buf(B, rows, N, 2)
             st.stats = stats.data_ptr()
-            self.stats_of[out.data_ptr()] = (stats, tiles * 2)
+            self.stats_of[out.data_ptr()] = (stats, rows)
         st.stats_rows = 0
         if want_stats and ksplit > 1 and heads == 1:
             # the split-K reduction emits the statistics: one row per pixel slab

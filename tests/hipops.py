@@ -105,7 +105,7 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
             tiles = (Hout // 16) ** 2
         else:
             tiles = -(-P // bm) if ks == 1 else (Hout // min(Hout, 32)) * -(-Hout // (bm // min(Hout, 32)))
-        stats = torch.full((B, tiles * 2, N, 2), float("nan"), device=dev)
+        stats = torch.full((B, tiles * (4 if cfg == 2 else 2), N, 2), float("nan"), device=dev)
         st.stats = stats.data_ptr()
         stats_out.append(stats)
     check(lib().anoddpm_igemm(ctypes.byref(st), current_stream()), "igemm")
