@@ -33,29 +33,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WKC = 16;            // channels per K iteration
 constexpr int WBN = 64;            // output channels per workgroup
-constexpr int WTILES = 64;         // Winograd tiles per workgroup (8 x 8 tiles = 16 x 16 output pixels)
+
 constexpr int WPATCH = 18 * 18;    // input patch pixels
 
 __device__ __forceinline__ f32x4 wld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
+constexpr int DPITCH = 5;          // float4 per patch pixel in LDS: 4 quads + 1 pad (spreads the stride-2-pixel reads over banks)
+
 __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a)
 {
-    // LDS (floats): Dt[324][16] | V[16][64][16] | U[16][4][64][4]
-    constexpr int DT_F = WPATCH * WKC, V_F = 16 * WTILES * WKC, U_F = 16 * (WKC / 4) * WBN * 4;
-    __shared__ __attribute__((aligned(16))) float lds[DT_F + V_F + U_F];
-    f32x4 *ldsD = reinterpret_cast<f32x4 *>(lds);                 // [pixel][4 quads]
-    f32x4 *ldsV = reinterpret_cast<f32x4 *>(lds + DT_F);          // [xi][tile][4 quads], quad ^= (tile>>2)&3
-    f32x4 *ldsU = reinterpret_cast<f32x4 *>(lds + DT_F + V_F);    // [xi][k4][n]
+    // LDS: only the activated input patch, double buffered: Dt[2][324 pixels][5 float4]  (51.8 KB).
+    // Neither V (transformed input) nor U (transformed weights) ever touch LDS:
+    //   * a lane needs V only for ITS tile and channel quad, so it transforms patch -> A-operand registers;
+    //   * the B operand U[xi][k][n] is read by each lane straight from L2 (layout [xi][K/4][N][4] makes it
+    //     one coalesced 16-byte load per operand), prefetched one 16-MFMA group ahead in a register ring.
+    // One barrier per 16-channel iteration; the exchange buffer of the epilogue re-uses the same LDS.
+    constexpr int DT_F4 = WPATCH * DPITCH;                         // float4 per buffer
+    __shared__ __attribute__((aligned(16))) float lds[2 * DT_F4 * 4 > 4 * 2 * 8 * 4 * 64 ? 2 * DT_F4 * 4 : 4 * 2 * 8 * 4 * 64];
+    f32x4 *ldsD = reinterpret_cast<f32x4 *>(lds);
 
-    // 8 waves: wave = (xh, wm, wn).  (wm, wn) picks the 32 tiles x 32 channels wave tile as before; xh picks
-    // which half of the transform rows (u = 2*xh, 2*xh+1 -> 8 of the 16 positions) the wave accumulates.
-    // Two waves share each SIMD and cover each other's LDS / barrier stalls; 128 accumulator registers each.
+    // 8 waves: wave = (xh, wm, wn).  (wm, wn) picks the 32 tiles x 32 channels wave tile; xh picks which half of
+    // the transform rows (u = 2*xh, 2*xh+1 -> 8 of the 16 positions) the wave accumulates: 128 accumulators.
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int xh = __builtin_amdgcn_readfirstlane(wave >> 2);
     const int wm = (wave >> 1) & 1, wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
-    const int t256 = tid & 255;
 
     const int H = a.H, W = a.W;
     const int K = a.c0 + a.c1, N = a.N, K4 = K >> 2;
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
     const bool act = a.act != 0;
     const int nchunks = K / WKC;
 
-    // ---- S1 geometry: patch slots of this thread (pixel = idx>>2, quad = idx&3), fixed for the workgroup
+    // ---- patch staging: slots of this thread (pixel = idx>>2, quad = idx&3), geometry fixed for the workgroup
     constexpr int PJ = (WPATCH * 4 + 511) / 512;                   // 3 slots
     int spix[PJ];
     const int pq = tid & 3;
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
             praw[j] = wld4(src + (int64_t)sp * ld);
         }
     };
-    auto store_patch = [&]() {                                      // transform, zero padding AFTER it
+    auto store_patch = [&](int buf) {                               // transform, zero padding AFTER it
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
@@ -113,56 +116,12 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
                 f32x4 v = praw[j];
                 if (affine) v = v * asc + ash;
                 if (act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
-                ldsD[idx] = spix[j] >= 0 ? v : zero;
+                ldsD[buf * DT_F4 + (idx >> 2) * DPITCH + (idx & 3)] = spix[j] >= 0 ? v : zero;
             }
         }
     };
 
-    // ---- U tile: thread owns (k4, n) = t256 of every second transform position (parity tid>>8)
-    f32x4 ureg[8];
-    const int un = t256 & 63, uk4 = t256 >> 6, upar = tid >> 8;
-    const int unc = n0 + un < N ? n0 + un : N - 1;                  // N tail: clamped, columns discarded later
-    auto load_U = [&](int chunk) {
-        const int64_t xi_stride = (int64_t)K4 * N * 4;
-        const float *base = a.bmat + (((int64_t)(chunk * (WKC / 4) + uk4)) * N + unc) * 4 + upar * xi_stride;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ureg[j] = wld4(base + (2 * j) * xi_stride);
-    };
-    auto store_U = [&]() {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ldsU[(2 * j + upar) * 256 + t256] = ureg[j];   // [xi][k4][n], k4*64+n == t256
-    };
-
-    // ---- S2: input transform, one thread per (tile, quad, row-pair uh)
-    const int ttile = t256 >> 2, tquad = tid & 3, uh = tid >> 8;
-    const int tty = ttile >> 3, ttx = ttile & 7;
-    auto input_transform = [&]() {
-        // rows u = 2*uh, 2*uh+1 of t = B^T d:  t0 = d0-d2, t1 = d1+d2 | t2 = d2-d1, t3 = d1-d3
-        f32x4 t[2][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 dm = ldsD[((2 * tty + 1) * 18 + 2 * ttx + j) * 4 + tquad];      // d1
-            const f32x4 dn = ldsD[((2 * tty + 2) * 18 + 2 * ttx + j) * 4 + tquad];      // d2
-            const f32x4 de = ldsD[((2 * tty + (uh ? 3 : 0)) * 18 + 2 * ttx + j) * 4 + tquad];   // d0 or d3
-            if (uh == 0) { t[0][j] = de - dn; t[1][j] = dm + dn; }
-            else         { t[0][j] = dn - dm; t[1][j] = dm - de; }
-        }
-        const int sw = (tquad ^ ((ttile >> 2) & 3));
-#pragma unroll
-        for (int uu = 0; uu < 2; ++uu) {
-            const int u = 2 * uh + uu;
-            const f32x4 v0 = t[uu][0] - t[uu][2];
-            const f32x4 v1 = t[uu][1] + t[uu][2];
-            const f32x4 v2 = t[uu][2] - t[uu][1];
-            const f32x4 v3 = t[uu][1] - t[uu][3];
-            ldsV[((u * 4 + 0) * WTILES + ttile) * 4 + sw] = v0;
-            ldsV[((u * 4 + 1) * WTILES + ttile) * 4 + sw] = v1;
-            ldsV[((u * 4 + 2) * WTILES + ttile) * 4 + sw] = v2;
-            ldsV[((u * 4 + 3) * WTILES + ttile) * 4 + sw] = v3;
-        }
-    };
-
-    // ---- accumulators: 8 transform positions (u = 2*xh + {0,1}, v = 0..3) of a 32 x 32 wave tile
+    // ---- accumulators: 8 transform positions (u = 2*xh + uu, v = 0..3; index uu*4 + v) of a 32 x 32 wave tile
     f32x16 acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -170,35 +129,68 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
         for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
 
     const int atile = wm * 32 + l31;                                // this lane's A row (tile)
-    const int asw = (atile >> 2) & 3;
+    const int tty = atile >> 3, ttx = atile & 7;
+    const int dbase = ((2 * tty) * 18 + 2 * ttx) * DPITCH;          // float4 index of the tile's patch corner
     const int bcol = wn * 32 + l31;                                 // this lane's B column (channel)
-    const int xi0 = xh * 8;                                         // first transform position of this wave
+    const int nbc = n0 + bcol < N ? n0 + bcol : N - 1;              // N tail: clamped, column discarded later
+    const int64_t xi_stride = (int64_t)K4 * N * 4;
+    const float *ubase = a.bmat + (int64_t)nbc * 4 + (int64_t)(xh * 8) * xi_stride;
+
+    // B-operand ring: group G = (chunk, kg, uu) needs U[xi = 8xh + 4uu + v][k4 = 4*chunk + 2kg + h][n], v = 0..3
+    f32x4 bvr[2][4];
+    auto load_bgroup = [&](int chunk, int kg, int uu, int set) {
+        const float *p = ubase + ((int64_t)(chunk * 4 + 2 * kg + h) * N) * 4 + (int64_t)(uu * 4) * xi_stride;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) bvr[set][v] = wld4(p + v * xi_stride);
+    };
 
     load_patch(0);
-    load_U(0);
+    store_patch(0);
+    if (nchunks > 1) load_patch(1);
+    load_bgroup(0, 0, 0, 0);
+    __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        store_patch();
-        store_U();
-        __syncthreads();
-        input_transform();
-        if (chunk + 1 < nchunks) { load_patch(chunk + 1); load_U(chunk + 1); }   // in flight behind the MFMAs
-        __syncthreads();
-        // 16 operand pairs (8 positions x 2 k-groups); pair g+1 is read before pair g's four MFMAs are issued
-        f32x4 av[2], bv[2];
-        auto read_pair = [&](int g, int set) {
-            const int xi = xi0 + (g >> 1), q = (g & 1) * 2 + h;
-            av[set] = ldsV[(xi * WTILES + atile) * 4 + (q ^ asw)];
-            bv[set] = ldsU[(xi * (WKC / 4) + q) * WBN + bcol];
-        };
-        read_pair(0, 0);
+        const f32x4 *D = ldsD + (chunk & 1) * DT_F4 + dbase;
+        const bool more = chunk + 1 < nchunks;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int set = g & 1;
-            if (g + 1 < 16) read_pair(g + 1, set ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int kg = 0; kg < 2; ++kg) {
+            const int q = 2 * kg + h;
+            // rows u = 2*xh, 2*xh+1 of t = B^T d:  t0 = d0-d2, t1 = d1+d2 | t2 = d2-d1, t3 = d1-d3
+            f32x4 t[2][4];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                acc[g >> 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[set][kk], bv[set][kk], acc[g >> 1], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 dm = D[(1 * 18 + j) * DPITCH + q];      // d1
+                const f32x4 dn = D[(2 * 18 + j) * DPITCH + q];      // d2
+                const f32x4 de = D[((xh ? 3 : 0) * 18 + j) * DPITCH + q];   // d0 or d3
+                if (xh == 0) { t[0][j] = de - dn; t[1][j] = dm + dn; }
+                else         { t[0][j] = dn - dm; t[1][j] = dm - de; }
+            }
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+                const int set = uu;                                 // 4 groups per chunk: ring parity = uu
+                // next group's B operands (may belong to the next chunk) are requested before this group's MFMAs
+                if (uu == 0)      load_bgroup(chunk, kg, 1, 1);
+                else if (kg == 0) load_bgroup(chunk, 1, 0, 0);
+                else if (more)    load_bgroup(chunk + 1, 0, 0, 0);
+                f32x4 av[4];
+                av[0] = t[uu][0] - t[uu][2];
+                av[1] = t[uu][1] + t[uu][2];
+                av[2] = t[uu][2] - t[uu][1];
+                av[3] = t[uu][1] - t[uu][3];
+                __builtin_amdgcn_sched_barrier(0);
+                // kk OUTER, position inner: consecutive MFMAs go to four different accumulators (a run of MFMAs
+                // into the same accumulator is a dependent chain and does not issue back to back)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        acc[uu * 4 + v] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v][kk], bvr[set][v][kk], acc[uu * 4 + v], 0, 0, 0);
+            }
+            if (kg == 0 && more) {
+                // the next iteration's patch goes to the other buffer while this iteration's MFMAs are in flight
+                store_patch((chunk + 1) & 1);
+                if (chunk + 2 < nchunks) load_patch(chunk + 2);
+            }
         }
         __syncthreads();
     }
@@ -221,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
         }
     };
     // exchange buffer (re-uses the V region; the loop's last barrier has passed): ex[pair][writer xh][8 rows][4][64 lanes]
-    float *ex = lds + DT_F;
+    float *ex = lds;
     const int pair = wave & 3;
     if (xh == 0) {
 #pragma unroll
