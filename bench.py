@@ -39,6 +39,7 @@ CONFIGS = {
                name="64x64 base64 batch1 (BASELINE config 1 shape, on GPU)"),
 }
 T_STEPS = 1000
+MEASURED_TRAFFIC_BYTES_PER_LAUNCH = 1.038e8      # profiles/r1d_pmc_hbm_by_kernel.csv, config c2 batch 4
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
@@ -201,11 +202,23 @@ def main():
         _lib.check(L.anoddpm_prof_collect(ms, cnt), "prof_collect")
         L.anoddpm_prof_enable(0)
         ig_ms, ig_n = ms[_lib.OP_IGEMM], cnt[_lib.OP_IGEMM]
-        flops_per_step = plan.igemm_flops                      # algorithmic FLOPs of all igemm launches
+        flops_per_step = plan.igemm_flops                      # algorithmic (direct-convolution) FLOPs of all launches
         achieved = flops_per_step * args.steps / (ig_ms / 1000.0) / 1e12 if ig_ms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3x3/1x1/attention, v_mfma_f32_32x32x2_f32)",
+        # FLOPs the matrix pipe actually executes: Winograd F(2x2,3x3) layers issue 4/9 of the direct count
+        exec_flops = sum(e["gflop"] * (4.0 / 9.0 if e["wino"] else 1.0) for e in plan.igemm_log) * 1e9
+        executed = exec_flops * args.steps / (ig_ms / 1000.0) / 1e12 if ig_ms > 0 else 0.0
+        roofline = {"bound": "mfma",
+                    "kernel": "anoddpm_igemm launches: wino_kernel (Winograd F(2x2,3x3)) + igemm_kernel (direct conv / 1x1 / attention), v_mfma_f32_32x32x2_f32",
                     "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                    "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
+                    # HBM-side bytes per launch from the committed PMC passes (not collectable from inside this
+                    # process): (2*FETCH_SIZE + WRITE_SIZE) KB averaged over the launches of one step, with the
+                    # guide's gfx950 FETCH_SIZE x2 correction.  Only quoted for the workload it was measured on.
+                    "traffic": MEASURED_TRAFFIC_BYTES_PER_LAUNCH if (args.config == "c2" and B == 4) else None,
+                    "traffic_source": "profiles/r1d_pmc_hbm_by_kernel.csv",
+                    "achieved_is": "ALGORITHMIC direct-convolution FLOPs / HIP-event time of the launches (can exceed the executed rate: Winograd does 2.25x fewer multiplies)",
+                    "executed_tflops": executed, "executed_frac": executed / PEAK_FP32_MATRIX_TFLOPS,
+                    "winograd_share_of_algorithmic_flops": sum(e["gflop"] for e in plan.igemm_log if e["wino"]) * 1e9 / max(flops_per_step, 1.0),
                     "launches_per_step": ig_n / args.steps, "avg_launch_ms": ig_ms / max(ig_n, 1),
                     "algorithmic_gflop_per_step": flops_per_step / 1e9,
                     "class_ms_per_step": {name: ms[code] / args.steps for name, code in
