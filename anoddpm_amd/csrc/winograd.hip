@@ -40,16 +40,21 @@ __device__ __forceinline__ f32x4 wld4(const float *p) { return *reinterpret_cast
 
 constexpr int DPITCH = 5;          // float4 per patch pixel in LDS: 4 quads + 1 pad (spreads the stride-2-pixel reads over banks)
 
+// FAST = every operand element gets GroupNorm-apply + SiLU (all 3x3 layers of the UNet): the staging code is then
+// branch-free, which keeps the whole K iteration one basic block for the scheduler.
+template <bool FAST>
 __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a)
 {
-    // LDS: only the activated input patch, double buffered: Dt[2][324 pixels][5 float4]  (51.8 KB).
+    // LDS: only the activated input patch, double buffered: Dt[2][384 pixel slots][5 float4]  (60 KB; 324 pixels
+    // are real, the rest absorbs the unconditional stores of the last staging slot).
     // Neither V (transformed input) nor U (transformed weights) ever touch LDS:
     //   * a lane needs V only for ITS tile and channel quad, so it transforms patch -> A-operand registers;
     //   * the B operand U[xi][k][n] is read by each lane straight from L2 (layout [xi][K/4][N][4] makes it
-    //     one coalesced 16-byte load per operand), prefetched one 16-MFMA group ahead in a register ring.
+    //     one coalesced 16-byte load per operand) through a two-deep register ring.
     // One barrier per 16-channel iteration; the exchange buffer of the epilogue re-uses the same LDS.
-    constexpr int DT_F4 = WPATCH * DPITCH;                         // float4 per buffer
-    __shared__ __attribute__((aligned(16))) float lds[2 * DT_F4 * 4 > 4 * 2 * 8 * 4 * 64 ? 2 * DT_F4 * 4 : 4 * 2 * 8 * 4 * 64];
+    constexpr int DT_F4 = 384 * DPITCH;                            // float4 per buffer
+    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * 8 * 4 * 64];      // 64 KB >= 2 * DT_F4 * 16 B
+    static_assert(2 * DT_F4 * 4 <= 4 * 2 * 8 * 4 * 64, "patch buffers must fit the exchange buffer");
     f32x4 *ldsD = reinterpret_cast<f32x4 *>(lds);
 
     // 8 waves: wave = (xh, wm, wn).  (wm, wn) picks the 32 tiles x 32 channels wave tile; xh picks which half of
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
     const int nchunks = K / WKC;
 
     // ---- patch staging: slots of this thread (pixel = idx>>2, quad = idx&3), geometry fixed for the workgroup
-    constexpr int PJ = (WPATCH * 4 + 511) / 512;                   // 3 slots
+    constexpr int PJ = 3;                                           // 3 * 512 slots >= 324 pixels * 4 quads
     int spix[PJ];
     const int pq = tid & 3;
 #pragma unroll
@@ -95,29 +100,32 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
     f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
     auto load_patch = [&](int chunk) {                              // unconditional loads, clamped addresses
         const int kbase = chunk * WKC;
-        const float *src;
+        const float *src;                                           // wave-uniform part of the address
         int ld, koff;
         if (kbase < a.c0) { src = A0; ld = a.a0_ld; koff = kbase; }
         else              { src = A1; ld = a.a1_ld; koff = kbase - a.c0; }
-        src += koff + pq * 4;
-        if (affine) { asc = wld4(gsc + kbase + pq * 4); ash = wld4(gsh + kbase + pq * 4); }
+        src += koff;
+        if (FAST || affine) { asc = wld4(gsc + kbase + pq * 4); ash = wld4(gsh + kbase + pq * 4); }
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
-            const int sp = spix[j] >= 0 ? spix[j] : 0;
-            praw[j] = wld4(src + (int64_t)sp * ld);
+            const unsigned sp = spix[j] >= 0 ? (unsigned)spix[j] : 0u;
+            praw[j] = wld4(src + (sp * (unsigned)ld + (unsigned)(pq * 4)));
         }
     };
     auto store_patch = [&](int buf) {                               // transform, zero padding AFTER it
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
-            const int idx = tid + j * 512;
-            if (idx < WPATCH * 4) {
-                f32x4 v = praw[j];
+            const int idx = tid + j * 512;                          // < 1536 = 384 slots * 4: always in the buffer
+            f32x4 v = praw[j];
+            if (FAST) {
+                v = v * asc + ash;
+                v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
+            } else {
                 if (affine) v = v * asc + ash;
                 if (act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
-                ldsD[buf * DT_F4 + (idx >> 2) * DPITCH + (idx & 3)] = spix[j] >= 0 ? v : zero;
             }
+            ldsD[buf * DT_F4 + (idx >> 2) * DPITCH + (idx & 3)] = spix[j] >= 0 ? v : zero;
         }
     };
 
@@ -130,69 +138,98 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
 
     const int atile = wm * 32 + l31;                                // this lane's A row (tile)
     const int tty = atile >> 3, ttx = atile & 7;
-    const int dbase = ((2 * tty) * 18 + 2 * ttx) * DPITCH;          // float4 index of the tile's patch corner
+    const int dbase = ((2 * tty) * 18 + 2 * ttx) * DPITCH + h;      // float4 index: tile's patch corner, quad h
     const int bcol = wn * 32 + l31;                                 // this lane's B column (channel)
     const int nbc = n0 + bcol < N ? n0 + bcol : N - 1;              // N tail: clamped, column discarded later
     const int64_t xi_stride = (int64_t)K4 * N * 4;
-    const float *ubase = a.bmat + (int64_t)nbc * 4 + (int64_t)(xh * 8) * xi_stride;
 
-    // B-operand ring: group G = (chunk, kg, uu) needs U[xi = 8xh + 4uu + v][k4 = 4*chunk + 2kg + h][n], v = 0..3
+    // Row u = 2*xh + uu of t = B^T d is  X - Y  or  X + Y  of two patch rows (wave-uniform choice):
+    //   xh=0: uu=0: d0 - d2   uu=1: d1 + d2        xh=1: uu=0: d2 - d1   uu=1: d1 - d3
+    const int rowX0 = xh ? 2 : 0, rowY0 = xh ? 1 : 2;
+    const int rowX1 = 1,          rowY1 = xh ? 3 : 2;
+    const float sg1 = xh ? -1.f : 1.f;                              // sign of Y for uu = 1 (uu = 0 is always -1)
+    const int offX[2] = {rowX0 * 18 * DPITCH, rowX1 * 18 * DPITCH};
+    const int offY[2] = {rowY0 * 18 * DPITCH, rowY1 * 18 * DPITCH};
+
+    // A group = 16 MFMAs: (chunk, kg, uu) -> 4 positions v x K = 4 (quad q = 2*kg + h of the 16-channel chunk).
+    // B operands of a group: U[xi = 8xh + 4uu + v][k4 = 4*chunk + 2kg + h][n], v = 0..3
+    const float *ubase = a.bmat + (int64_t)(xh * 8) * xi_stride;    // wave-uniform
+    const unsigned ulane = (unsigned)(nbc * 4 + h * N * 4);         // per-lane element offset
     f32x4 bvr[2][4];
-    auto load_bgroup = [&](int chunk, int kg, int uu, int set) {
-        const float *p = ubase + ((int64_t)(chunk * 4 + 2 * kg + h) * N) * 4 + (int64_t)(uu * 4) * xi_stride;
+    auto load_b = [&](int chunk, int kg, int uu, int set) {
+        const float *p = ubase + ((int64_t)(chunk * 4 + 2 * kg) * N * 4 + (int64_t)(uu * 4) * xi_stride);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) bvr[set][v] = wld4(p + v * xi_stride);
+        for (int v = 0; v < 4; ++v) bvr[set][v] = wld4(p + v * xi_stride + ulane);
+    };
+    f32x4 rawX[4], rawY[4], av[4];
+    auto issue_reads = [&](int buf, int kg, int uu, int which) {    // 4 ds_read_b128: one patch row of the tile
+        const f32x4 *D = ldsD + buf * DT_F4 + dbase + 2 * kg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (which == 0) rawX[j] = D[offX[uu] + j * DPITCH];
+            else            rawY[j] = D[offY[uu] + j * DPITCH];
+        }
+    };
+    auto make_av = [&](int uu) {                                    // row transform, then the column transform
+        const float sg = uu ? sg1 : -1.f;
+        f32x4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = rawX[j] + sg * rawY[j];
+        av[0] = t[0] - t[2];
+        av[1] = t[1] + t[2];
+        av[2] = t[2] - t[1];
+        av[3] = t[1] - t[3];
     };
 
+    const int last = nchunks - 1;
     load_patch(0);
     store_patch(0);
-    if (nchunks > 1) load_patch(1);
-    load_bgroup(0, 0, 0, 0);
+    load_patch(last < 1 ? last : 1);
+    load_b(0, 0, 0, 0);
+    load_b(0, 0, 1, 1);
     __syncthreads();
+    issue_reads(0, 0, 0, 0);
+    issue_reads(0, 0, 0, 1);
+    make_av(0);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const f32x4 *D = ldsD + (chunk & 1) * DT_F4 + dbase;
-        const bool more = chunk + 1 < nchunks;
+        const int nxt = chunk < last ? chunk + 1 : last;            // clamped: the tail re-loads valid memory, unused
+        const int nxt2 = chunk + 2 < nchunks ? chunk + 2 : last;
 #pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
-            const int q = 2 * kg + h;
-            // rows u = 2*xh, 2*xh+1 of t = B^T d:  t0 = d0-d2, t1 = d1+d2 | t2 = d2-d1, t3 = d1-d3
-            f32x4 t[2][4];
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int uu = g4 & 1;
+            // The next group's two patch rows are requested ahead of / in the middle of this group's MFMAs (the second
+            // row lands in registers the first half of the burst has released).  Group 3 reads the NEXT chunk's
+            // buffer: its stores were made during this iteration; the barrier publishes them and also retires
+            // every read of the buffer that iteration chunk+1 overwrites.
+            if (g4 == 3) __syncthreads();
+            const int rbuf = g4 < 3 ? (chunk & 1) : ((chunk + 1) & 1);
+            const int rkg = g4 < 3 ? (g4 + 1) >> 1 : 0, ruu = (g4 + 1) & 1;
+            issue_reads(rbuf, rkg, ruu, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 dm = D[(1 * 18 + j) * DPITCH + q];      // d1
-                const f32x4 dn = D[(2 * 18 + j) * DPITCH + q];      // d2
-                const f32x4 de = D[((xh ? 3 : 0) * 18 + j) * DPITCH + q];   // d0 or d3
-                if (xh == 0) { t[0][j] = de - dn; t[1][j] = dm + dn; }
-                else         { t[0][j] = dn - dm; t[1][j] = dm - de; }
-            }
-#pragma unroll
-            for (int uu = 0; uu < 2; ++uu) {
-                const int set = uu;                                 // 4 groups per chunk: ring parity = uu
-                // next group's B operands (may belong to the next chunk) are requested before this group's MFMAs
-                if (uu == 0)      load_bgroup(chunk, kg, 1, 1);
-                else if (kg == 0) load_bgroup(chunk, 1, 0, 0);
-                else if (more)    load_bgroup(chunk + 1, 0, 0, 0);
-                f32x4 av[4];
-                av[0] = t[uu][0] - t[uu][2];
-                av[1] = t[uu][1] + t[uu][2];
-                av[2] = t[uu][2] - t[uu][1];
-                av[3] = t[uu][1] - t[uu][3];
-                __builtin_amdgcn_sched_barrier(0);
-                // kk OUTER, position inner: consecutive MFMAs go to four different accumulators (a run of MFMAs
-                // into the same accumulator is a dependent chain and does not issue back to back)
+            for (int v = 0; v < 2; ++v)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
+                    acc[uu * 4 + v] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v][kk], bvr[uu][v][kk], acc[uu * 4 + v], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_reads(rbuf, rkg, ruu, 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        acc[uu * 4 + v] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v][kk], bvr[set][v][kk], acc[uu * 4 + v], 0, 0, 0);
-            }
-            if (kg == 0 && more) {
+            for (int v = 2; v < 4; ++v)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    acc[uu * 4 + v] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v][kk], bvr[uu][v][kk], acc[uu * 4 + v], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ring: the set just consumed is refilled with the operands of the group after next
+            if (g4 < 2) load_b(chunk, 1, uu, uu);
+            else        load_b(nxt, 0, uu, uu);
+            if (g4 == 0) {
                 // the next iteration's patch goes to the other buffer while this iteration's MFMAs are in flight
                 store_patch((chunk + 1) & 1);
-                if (chunk + 2 < nchunks) load_patch(chunk + 2);
+                load_patch(nxt2);
             }
+            make_av(ruu);
         }
-        __syncthreads();
     }
 
     // ---- epilogue.  The output transform Y = A^T M A is linear in M, so each wave forms the PARTIAL 2x2 outputs
@@ -298,7 +335,8 @@ int launch_winograd(const anoddpm_igemm_args *a, hipStream_t s)
     ANODDPM_REQUIRE(K % WKC == 0 && (a->c1 == 0 || a->c0 % WKC == 0), "winograd: channel counts must be multiples of 16");
     dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)((a->N + WBN - 1) / WBN), (unsigned)a->B);
     ANODDPM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "winograd: grid too large");
-    hipLaunchKernelGGL(wino_kernel, grid, dim3(512), 0, s, *a);
+    if (a->gn_scale && a->act) hipLaunchKernelGGL(wino_kernel<true>, grid, dim3(512), 0, s, *a);
+    else                       hipLaunchKernelGGL(wino_kernel<false>, grid, dim3(512), 0, s, *a);
     return check_launch("winograd");
 }
 
