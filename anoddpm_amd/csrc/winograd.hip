@@ -37,6 +37,18 @@ constexpr int WBN = 64;            // output channels per workgroup
 constexpr int WPATCH = 18 * 18;    // input patch pixels
 
 __device__ __forceinline__ f32x4 wld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+// Buffer loads: descriptor (SGPRs) + per-lane 32-bit byte offset (VGPR) + wave-uniform 32-bit byte offset (SGPR).
+// All address arithmetic that changes inside the K loop is then scalar -- VALU instructions are NOT hidden by the
+// fp32 MFMA on gfx950, 64-bit VALU pointer adds would come straight out of the matrix issue time.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wrsrc(const float *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7ffffffe, 0x00020000);
+}
+__device__ __forceinline__ f32x4 wbld4(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned wave_bytes)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)wave_bytes, 0));
+}
 
 constexpr int DPITCH = 5;          // float4 per patch pixel in LDS: 4 quads + 1 pad (spreads the stride-2-pixel reads over banks)
 
@@ -98,18 +110,22 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
     }
     f32x4 praw[PJ];
     f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rA0 = wrsrc(A0), rA1 = wrsrc(A1 ? A1 : A0);
+    const __amdgpu_buffer_rsrc_t rSc = wrsrc(gsc ? gsc : A0), rSh = wrsrc(gsh ? gsh : A0);
     auto load_patch = [&](int chunk) {                              // unconditional loads, clamped addresses
         const int kbase = chunk * WKC;
-        const float *src;                                           // wave-uniform part of the address
-        int ld, koff;
-        if (kbase < a.c0) { src = A0; ld = a.a0_ld; koff = kbase; }
-        else              { src = A1; ld = a.a1_ld; koff = kbase - a.c0; }
-        src += koff;
-        if (FAST || affine) { asc = wld4(gsc + kbase + pq * 4); ash = wld4(gsh + kbase + pq * 4); }
+        const bool first = kbase < a.c0;                            // wave-uniform source choice
+        const __amdgpu_buffer_rsrc_t r = first ? rA0 : rA1;
+        const unsigned ld = (unsigned)(first ? a.a0_ld : a.a1_ld);
+        const unsigned koff = (unsigned)(first ? kbase : kbase - a.c0) * 4u;
+        if (FAST || affine) {
+            asc = wbld4(rSc, (unsigned)(pq * 16), (unsigned)kbase * 4u);
+            ash = wbld4(rSh, (unsigned)(pq * 16), (unsigned)kbase * 4u);
+        }
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
             const unsigned sp = spix[j] >= 0 ? (unsigned)spix[j] : 0u;
-            praw[j] = wld4(src + (sp * (unsigned)ld + (unsigned)(pq * 4)));
+            praw[j] = wbld4(r, (sp * ld + (unsigned)(pq * 4)) * 4u, koff);
         }
     };
     auto store_patch = [&](int buf) {                               // transform, zero padding AFTER it
@@ -153,13 +169,15 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
 
     // A group = 16 MFMAs: (chunk, kg, uu) -> 4 positions v x K = 4 (quad q = 2*kg + h of the 16-channel chunk).
     // B operands of a group: U[xi = 8xh + 4uu + v][k4 = 4*chunk + 2kg + h][n], v = 0..3
-    const float *ubase = a.bmat + (int64_t)(xh * 8) * xi_stride;    // wave-uniform
-    const unsigned ulane = (unsigned)(nbc * 4 + h * N * 4);         // per-lane element offset
+    const __amdgpu_buffer_rsrc_t rU = wrsrc(a.bmat);
+    const unsigned xi_bytes = (unsigned)xi_stride * 4u;             // launcher guarantees 16 * xi_bytes < 2^31
+    const unsigned ubase = (unsigned)(xh * 8) * xi_bytes;           // wave-uniform
+    const unsigned ulane = (unsigned)(nbc * 4 + h * N * 4) * 4u;    // per-lane byte offset
     f32x4 bvr[2][4];
     auto load_b = [&](int chunk, int kg, int uu, int set) {
-        const float *p = ubase + ((int64_t)(chunk * 4 + 2 * kg) * N * 4 + (int64_t)(uu * 4) * xi_stride);
+        const unsigned w = ubase + (unsigned)(chunk * 4 + 2 * kg) * (unsigned)N * 16u + (unsigned)(uu * 4) * xi_bytes;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) bvr[set][v] = wld4(p + v * xi_stride + ulane);
+        for (int v = 0; v < 4; ++v) bvr[set][v] = wbld4(rU, ulane, w + (unsigned)v * xi_bytes);
     };
     f32x4 rawX[4], rawY[4], av[4];
     auto issue_reads = [&](int buf, int kg, int uu, int which) {    // 4 ds_read_b128: one patch row of the tile
@@ -335,6 +353,9 @@ int launch_winograd(const anoddpm_igemm_args *a, hipStream_t s)
     ANODDPM_REQUIRE(K % WKC == 0 && (a->c1 == 0 || a->c0 % WKC == 0), "winograd: channel counts must be multiples of 16");
     dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)((a->N + WBN - 1) / WBN), (unsigned)a->B);
     ANODDPM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "winograd: grid too large");
+    ANODDPM_REQUIRE((int64_t)16 * K * a->N * 4 < ((int64_t)1 << 31), "winograd: transformed weights exceed 32-bit buffer offsets");
+    ANODDPM_REQUIRE((int64_t)a->H * a->W * (a->a0_ld > a->a1_ld ? a->a0_ld : a->a1_ld) * 4 < ((int64_t)1 << 31),
+                    "winograd: operand slice exceeds 32-bit buffer offsets");
     if (a->gn_scale && a->act) hipLaunchKernelGGL(wino_kernel<true>, grid, dim3(512), 0, s, *a);
     else                       hipLaunchKernelGGL(wino_kernel<false>, grid, dim3(512), 0, s, *a);
     return check_launch("winograd");
