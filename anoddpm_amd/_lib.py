@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 
@@ -109,8 +109,19 @@ class AdamwArgs(Structure):
                 ("weight_decay", c_float), ("ema_decay", c_float), ("step", c_int32)]
 
 
+class AnomalyArgs(Structure):
+    _fields_ = [("recon", c_void_p), ("real", c_void_p), ("mask", c_void_p),
+                ("mean", c_void_p), ("sqerr", c_void_p), ("mse_img", c_void_p), ("thr_img", c_void_p), ("pred", c_void_p),
+                ("counts", c_void_p), ("workspace", c_void_p), ("workspace_doubles", c_int64),
+                ("n", c_int64), ("recon_as", c_int64), ("recon_bs", c_int64),
+                ("navg", c_int32), ("B", c_int32), ("threshold", c_float)]
+
+
+ANOMALY_NCOUNTS = 12
+ANOMALY_BLOCKS = 64
+
 _STRUCTS = [SimplexArgs, PUpdateArgs, IgemmArgs, GnArgs, SoftmaxArgs, ResampleArgs, LinearArgs,
-            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs]
+            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, AnomalyArgs]
 
 # every symbol include/anoddpm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -121,7 +132,7 @@ SYMBOLS = [
     "anoddpm_igemm", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
     "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_conv_head", "anoddpm_nhwc_to_nchw",
     "anoddpm_run_ops", "anoddpm_prof_enable", "anoddpm_prof_active", "anoddpm_prof_collect",
-    "anoddpm_adamw_ema", "anoddpm_sumsq",
+    "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map",
 ]
 
 _lib = None
@@ -190,6 +201,7 @@ def lib():
     L.anoddpm_prof_collect.argtypes = [POINTER(c_double), POINTER(c_int64)]
     L.anoddpm_adamw_ema.argtypes = [POINTER(AdamwArgs), c_void_p]
     L.anoddpm_sumsq.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
+    L.anoddpm_anomaly_map.argtypes = [POINTER(AnomalyArgs), c_void_p]
     for i in range(8):
         if os.environ.get(f"ANODDPM_DEBUG{i}"):
             L.anoddpm_debug_set(i, int(os.environ[f"ANODDPM_DEBUG{i}"], 0))

@@ -23,6 +23,7 @@ SOURCES = {
     "winograd.hip": [],
     "executor.hip": [],
     "optim.hip": [],
+    "metrics.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

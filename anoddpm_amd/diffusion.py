@@ -547,10 +547,108 @@ class GaussianDiffusionModel:
             output[(i - 1) * 6:i * 6, ...] = torch.cat((x_0, x_noised, x, mse, mse_threshold, mask))
         return output
 
-    def detection_A(self, *a, **k):
-        raise NotImplementedError("detection_A writes matplotlib figures (GaussianDiffusion.py:480-529); its compute "
-                                  "loop is forward_backward(..., denoise_fn=...) -- plotting is out of scope (SURVEY 2 row 1b)")
+    # The (t_distance, avg) loops of detection_A / detection_B.  Upstream runs `total_avg` chains of one image
+    # one after the other (:499-514, :554-569); the chains are independent, so they are stacked as ONE batch:
+    # total_avg x fewer UNet launches at a batch size that fills the GPU, the mean / mse / threshold images and
+    # the segmentation counts come from one fused pass (metrics.anomaly_maps).  RNG: the same generators are
+    # consumed (np.random for simplex seeds, torch's for randn) but the draws of different chains interleave
+    # differently from the serial loop, so outputs are equal in distribution, not sample-for-sample.
+    def _avg_chains(self, model, x_0, t_distance, total_avg):
+        _lib.require_cuda(x_0, "GaussianDiffusionModel.detection")
+        if x_0.shape[0] != 1:
+            raise ValueError("detection loops take one image (upstream stores each chain into output[avg], :514)")
+        t_tensor = torch.full((1,), int(t_distance), device=x_0.device, dtype=torch.int64)
+        noise = torch.cat([self.noise_fn(x_0, t_tensor).float() for _ in range(total_avg)])
+        x = self.sample_q(x_0.repeat(total_avg, 1, 1, 1), t_tensor.repeat(total_avg), noise)
+        with torch.no_grad():
+            return self._reverse_chain(model, x, int(t_distance), "gauss", None)      # sample_p default noise, :508
 
-    def detection_B(self, *a, **k):
-        raise NotImplementedError("detection_B writes matplotlib figures (GaussianDiffusion.py:531-594); its compute "
-                                  "loop is forward_backward(..., denoise_fn=...) -- plotting is out of scope (SURVEY 2 row 1b)")
+    @staticmethod
+    def _figure_dirs(paths):
+        import os
+        for d in paths:
+            try:
+                os.makedirs(d)
+            except OSError:
+                pass
+
+    @staticmethod
+    def _save_grid(out, nrow, filename):
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+        except Exception:                                               # pragma: no cover
+            return
+        from .helpers import gridify_output
+        plt.imshow(gridify_output(out, nrow), cmap='gray')
+        plt.axis('off')
+        plt.savefig(filename)
+        plt.clf()
+
+    def _detection_record(self, x_0, output, mask, extra):
+        from . import metrics
+        maps, counts = metrics.anomaly_maps(x_0, output, mask, threshold=0.5)
+        rec = dict(extra)
+        rec.update(output=output, mean=maps["mean"], mse=maps["mse_img"], threshold=maps["thr_img"],
+                   counts=counts)
+        return rec, maps
+
+    def detection_A(self, model, x_0, args, file, mask, total_avg=2, save=True):
+        """GaussianDiffusion.py:480-529: simplex frequencies 2^7..2^1 x t_distance 50..0.6T step 50, `total_avg`
+        chains each (batched here).  Returns None as upstream; per-setting results are kept in
+        `self.last_detection` (mean / mse / threshold images and the segmentation counts, all on the device)."""
+        import os
+        base = f"./diffusion-videos/ARGS={args['arg_num']}/Anomalous/{file[0]}"
+        if save:
+            self._figure_dirs([base, f"{base}/{file[1]}/", f"{base}/{file[1]}/A"])
+        self.last_detection = []
+        for i in range(7, 0, -1):
+            freq = 2 ** i
+            self.noise_fn = lambda x, t: generate_simplex_noise(
+                    self.simplex, x, t, False, frequency=freq,
+                    in_channels=self.img_channels
+                    )
+            for t_distance in range(50, int(args["T"] * 0.6), 50):
+                output = self._avg_chains(model, x_0, t_distance, total_avg)
+                rec, maps = self._detection_record(x_0, output, mask, {"freq": i, "t_distance": t_distance})
+                self.last_detection.append(rec)
+                if save:
+                    out = torch.cat([x_0, output[:3], maps["mean"], maps["mse_img"], maps["thr_img"], mask])
+                    temp = os.listdir(f"{base}/{file[1]}/A")
+                    self._save_grid(out, 4, f"{base}/{file[1]}/A/freq={i}-t={t_distance}-{len(temp) + 1}.png")
+
+    def detection_B(self, model, x_0, args, file, mask, denoise_fn="gauss", total_avg=5, save=True):
+        """GaussianDiffusion.py:531-594: t_distance 50..end step 50 with gaussian or 6-octave simplex forward noise,
+        `total_avg` chains each (batched here).  Returns the list upstream returns -- the values of
+        `evaluation.heatmap(...)`, which are None -- and keeps the device-side results in `self.last_detection`."""
+        import os
+        from . import metrics
+        assert type(file) == tuple
+        base = f"./diffusion-videos/ARGS={args['arg_num']}/Anomalous/{file[0]}"
+        if save:
+            self._figure_dirs([base, f"{base}/{file[1]}", f"{base}/{file[1]}/{denoise_fn}"])
+        if denoise_fn == "octave":
+            end = int(args["T"] * 0.6)
+            self.noise_fn = lambda x, t: generate_simplex_noise(
+                    self.simplex, x, t, False, frequency=64, octave=6,
+                    persistence=0.8
+                    ).float()
+        else:
+            end = int(args["T"] * 0.8)
+            self.noise_fn = lambda x, t: torch.randn_like(x)
+        dice_coeff = []
+        self.last_detection = []
+        for t_distance in range(50, end, 50):
+            output = self._avg_chains(model, x_0, t_distance, total_avg)
+            rec, maps = self._detection_record(x_0, output, mask, {"t_distance": t_distance})
+            self.last_detection.append(rec)
+            dice = None
+            if save:
+                temp = os.listdir(f"{base}/{file[1]}/{denoise_fn}")
+                dice = metrics.heatmap(real=x_0, recon=maps["mean"], mask=mask,
+                                       filename=f"{base}/{file[1]}/{denoise_fn}/heatmap-t={t_distance}-{len(temp) + 1}.png")
+                out = torch.cat([x_0, output[:3], maps["mean"], maps["mse_img"], maps["thr_img"], mask])
+                self._save_grid(out, 4, f"{base}/{file[1]}/{denoise_fn}/t={t_distance}-{len(temp) + 1}.png")
+            dice_coeff.append(dice)
+        return dice_coeff

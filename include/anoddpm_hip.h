@@ -344,6 +344,37 @@ int anoddpm_adamw_ema(const anoddpm_adamw_args *a, void *stream);
  * (clip_grad_norm_, diffusion_training.py:104) */
 int anoddpm_sumsq(const float *g, int64_t n, float *out, void *stream);
 
+/* ------------------------------------------------------------------ anomaly map + segmentation counts
+ * One pass over an image and its `navg` reconstructions (the (t_distance, avg) chains of detection_A/B):
+ *   mean over the chains                                  GaussianDiffusion.py:517, 572
+ *   sqerr = (mean - real)^2                                detection.py:229; evaluation.py:31
+ *   mse_img = sqerr*2 - 1 ; thr_img = (mse_img > 0)*2 - 1  GaussianDiffusion.py:518-520, 581-583; evaluation.py:13-15
+ *   pred = (sqerr > threshold)                             detection.py:232 (threshold 0.5)
+ * and the sums behind dice_coeff / IoU / precision / recall / FPR / PSNR (evaluation.py:26-76) as
+ * counts[b][ANODDPM_ANOMALY_NCOUNTS] (fp64):
+ *   0 sum(pred)  1 sum(mask)  2 sum(pred*mask)  3 #(mask==1&pred==1)  4 #(mask==1&pred==0)  5 #(mask==0&pred==1)
+ *   6 #(mask==0&pred==0)  7 #(mask!=0 & pred!=0)  8 #(mask!=0 | pred!=0)  9 sum(sqerr)  10 max(real)  11 reserved
+ * recon: [navg] slices of n floats per image, slice stride recon_as, image stride recon_bs (elements).
+ * Any of mean / sqerr / mse_img / thr_img / pred may be NULL.  mask may be NULL (treated as all zero).
+ * workspace: ANODDPM_ANOMALY_BLOCKS * B * NCOUNTS doubles [dev].  Deterministic (fixed-order fold). */
+#define ANODDPM_ANOMALY_NCOUNTS 12
+#define ANODDPM_ANOMALY_BLOCKS 64
+typedef struct anoddpm_anomaly_args {
+    const float *recon;
+    const float *real;
+    const float *mask;
+    float *mean, *sqerr, *mse_img, *thr_img, *pred;
+    double *counts;                 /* [B][ANODDPM_ANOMALY_NCOUNTS] */
+    double *workspace;
+    int64_t workspace_doubles;
+    int64_t n;                      /* pixels (x channels) per image */
+    int64_t recon_as, recon_bs;
+    int32_t navg, B;
+    float threshold;
+} anoddpm_anomaly_args;
+
+int anoddpm_anomaly_map(const anoddpm_anomaly_args *a, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,7 @@ recipe from SURVEY.md 8c).  Outputs are DATA (inputs + expected outputs), never 
     simplex_kat.npz      _init tables, noise3 point KATs (bit patterns), octave fields, C4 crops
     diffusion_kat.npz    schedule tables (linear/cosine), sample_q / p_mean_variance / sample_p
     unet_<name>.npz      UNetModel.forward outputs (+ per-block activation probes)
+    metrics_kat.npz      evaluation.py metrics + the mean / mse / threshold images of detection_A/B
 """
 import os
 import sys
@@ -231,8 +232,39 @@ def gen_unet():
     print("unet_c2_256_b128.npz params", int(out["n_params"]), "|y| mean", float(np.abs(out["y"]).mean()))
 
 
+def gen_metrics():
+    """Anomaly-map arithmetic and segmentation metrics: the reference's evaluation.py functions (called) and the
+    inline tensor expressions of GaussianDiffusion.py:572, 581-583 / detection.py:229-232 (evaluated with torch CPU)."""
+    import torch
+    ev = ref_gd.evaluation
+    rng = np.random.RandomState(77)
+    out = {}
+    for case, (B, H, navg) in {"one": (1, 32, 5), "batch": (3, 24, 1)}.items():
+        real = (rng.rand(B, 1, H, H).astype(np.float32) * 2 - 1)
+        recon = np.clip(real[None] + rng.randn(navg, B, 1, H, H).astype(np.float32) * 0.6, -1, 1).astype(np.float32)
+        mask = (rng.rand(B, 1, H, H) > 0.7).astype(np.float32)
+        x0, outp, mk = torch.from_numpy(real), torch.from_numpy(recon), torch.from_numpy(mask)
+        mean = torch.mean(outp, dim=[0]).reshape(B, 1, H, H)                   # GaussianDiffusion.py:572
+        mse_img = ((mean - x0).square() * 2) - 1                                # :581
+        thr_img = ((mse_img > 0).float() * 2) - 1                               # :582-583
+        se = (x0 - mean).square()                                               # detection.py:229
+        pred = (se > 0.5).float()                                               # detection.py:232
+        out[f"{case}_real"], out[f"{case}_recon"], out[f"{case}_mask"] = real, recon, mask
+        out[f"{case}_mean"], out[f"{case}_mse_img"], out[f"{case}_thr_img"] = mean.numpy(), mse_img.numpy(), thr_img.numpy()
+        out[f"{case}_sqerr"], out[f"{case}_pred"] = se.numpy(), pred.numpy()
+        out[f"{case}_dice"] = ev.dice_coeff(x0, mean, mk).numpy()
+        out[f"{case}_dice_mse"] = ev.dice_coeff(x0, mean, mk, mse=pred).numpy()
+        out[f"{case}_precision"] = ev.precision(mk, pred).numpy()
+        out[f"{case}_recall"] = ev.recall(mk, pred).numpy()
+        out[f"{case}_FPR"] = ev.FPR(mk, pred).numpy()
+        out[f"{case}_IoU"] = np.float64(ev.IoU(mk, pred))
+        out[f"{case}_PSNR"] = ev.PSNR(mean, x0)
+    np.savez_compressed(os.path.join(HERE, "metrics_kat.npz"), **out)
+    print("metrics_kat.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["simplex", "diffusion", "unet"]
+    which = sys.argv[1:] or ["simplex", "diffusion", "unet", "metrics"]
     torch.set_num_threads(8)
     if "simplex" in which:
         gen_simplex()
@@ -240,3 +272,5 @@ if __name__ == "__main__":
         gen_diffusion()
     if "unet" in which:
         gen_unet()
+    if "metrics" in which:
+        gen_metrics()
