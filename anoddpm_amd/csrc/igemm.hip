@@ -495,6 +495,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const anoddpm_
 
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Second launch of a split-K contraction (direct or Winograd): fold the slabs, add bias / temb / residual, and
+// (optionally) emit the GroupNorm statistics rows.
+void launch_splitk_tail(const anoddpm_igemm_args *a, int64_t Z, int64_t P, hipStream_t s)
+{
+    if (a->stats) {
+        hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((unsigned)a->stats_rows, (unsigned)Z), dim3(256), 0, s, *a, a->stats_rows);
+    } else {
+        const int64_t total = Z * P * (a->N / 4);
+        const int64_t blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, *a);
+    }
+}
+
 }  // namespace
 
 extern "C" int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream)
@@ -523,8 +536,13 @@ extern "C" int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream)
                     "igemm: split-K needs a workspace and 16-byte aligned epilogue operands");
     int H = a->H, W = a->W, log2TW, TH;
     ANODDPM_REQUIRE(H >= 1 && W >= 1, "igemm: bad image size");
-    if (a->cfg == 2) return anoddpm::launch_winograd(a, anoddpm::as_stream(stream));
     const int64_t P = (int64_t)H * W;
+    if (a->cfg == 2) {
+        const int rc = anoddpm::launch_winograd(a, anoddpm::as_stream(stream));
+        if (rc != ANODDPM_OK) return rc;
+        if (a->ksplit > 1) launch_splitk_tail(a, (int64_t)a->B, P, anoddpm::as_stream(stream));
+        return anoddpm::check_launch("igemm(winograd split-K tail)");
+    }
     anoddpm_igemm_args k = *a;
     int tiles_x, tiles_y;
     if (a->ks == 1) {                 // treat the image as one row of P pixels
@@ -555,14 +573,6 @@ extern "C" int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream)
         if (conv) hipLaunchKernelGGL((igemm_kernel<64, 64, true>), grid, dim3(256), 0, s, k, log2TW, TH, tiles_x);
         else      hipLaunchKernelGGL((igemm_kernel<64, 64, false>), grid, dim3(256), 0, s, k, log2TW, TH, tiles_x);
     }
-    if (a->ksplit > 1) {
-        if (a->stats) {
-            hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((unsigned)a->stats_rows, (unsigned)Z), dim3(256), 0, s, *a, a->stats_rows);
-        } else {
-            const int64_t total = Z * P * (a->N / 4);
-            const int64_t blocks = (total + 255) / 256;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, *a);
-        }
-    }
+    if (a->ksplit > 1) launch_splitk_tail(a, Z, P, s);
     return anoddpm::check_launch("igemm");
 }

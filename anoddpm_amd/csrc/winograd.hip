@@ -82,7 +82,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
     const int bx = blockIdx.x % (W >> 4), by = blockIdx.x / (W >> 4);
     const int y0 = by * 16, x0 = bx * 16;                          // output patch origin
     const int n0 = blockIdx.y * WBN;
-    const int b = blockIdx.z;
+    const int ksplit = a.ksplit;                                   // split-K over 16-channel chunks (small maps)
+    const int ksi = blockIdx.z % ksplit;
+    const int b = blockIdx.z / ksplit;
     const int a_mode = a.a_mode;
 
     const float *A0 = a.a0 + (int64_t)b * a.a0_bs;
@@ -91,7 +93,10 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
     const float *gsh = a.gn_shift ? a.gn_shift + (int64_t)b * a.gn_ld : nullptr;
     const bool affine = (gsc != nullptr);
     const bool act = a.act != 0;
-    const int nchunks = K / WKC;
+    const int nchunks_all = K / WKC;
+    const int cps = (nchunks_all + ksplit - 1) / ksplit;
+    const int cbeg = ksi * cps;                                     // launcher guarantees cbeg < nchunks_all
+    const int nchunks = cbeg + cps < nchunks_all ? cbeg + cps : nchunks_all;   // end of this block's chunk range
 
     // ---- patch staging: slots of this thread (pixel = idx>>2, quad = idx&3), geometry fixed for the workgroup
     constexpr int PJ = 3;                                           // 3 * 512 slots >= 324 pixels * 4 quads
@@ -200,16 +205,16 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
     };
 
     const int last = nchunks - 1;
-    load_patch(0);
-    store_patch(0);
-    load_patch(last < 1 ? last : 1);
-    load_b(0, 0, 0, 0);
-    load_b(0, 0, 1, 1);
+    load_patch(cbeg);
+    store_patch(cbeg & 1);
+    load_patch(cbeg < last ? cbeg + 1 : last);
+    load_b(cbeg, 0, 0, 0);
+    load_b(cbeg, 0, 1, 1);
     __syncthreads();
-    issue_reads(0, 0, 0, 0);
-    issue_reads(0, 0, 0, 1);
+    issue_reads(cbeg & 1, 0, 0, 0);
+    issue_reads(cbeg & 1, 0, 0, 1);
     make_av(0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    for (int chunk = cbeg; chunk < nchunks; ++chunk) {
         const int nxt = chunk < last ? chunk + 1 : last;            // clamped: the tail re-loads valid memory, unused
         const int nxt2 = chunk + 2 < nchunks ? chunk + 2 : last;
 #pragma unroll
@@ -292,11 +297,16 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
     const int n = n0 + bcol;
     const bool nok = n < N;
     const int nc = nok ? n : 0;
-    float *__restrict__ O = a.out + (int64_t)b * a.o_bs;
-    const float *__restrict__ R = a.res ? a.res + (int64_t)b * a.r_bs : nullptr;
+    // split-K: raw partial sums go to this block's slab ws[ksi][b][pixel][N]; the tail launch of anoddpm_igemm
+    // folds the slabs and applies alpha / bias / temb / residual / statistics
+    const bool part = ksplit > 1;
+    float *__restrict__ O = part ? a.ws + ((int64_t)ksi * a.B + b) * ((int64_t)H * W) * N : a.out + (int64_t)b * a.o_bs;
+    const int o_ld = part ? N : a.out_ld;
+    const float alpha = part ? 1.f : a.alpha;
+    const float *__restrict__ R = (a.res && !part) ? a.res + (int64_t)b * a.r_bs : nullptr;
     float add = 0.f;
-    if (a.bias) add += a.bias[nc];
-    if (a.temb) add += a.temb[(int64_t)b * a.temb_ld + nc];
+    if (a.bias && !part) add += a.bias[nc];
+    if (a.temb && !part) add += a.temb[(int64_t)b * a.temb_ld + nc];
     float cs = 0.f, cq = 0.f;
     float rv[8][4];
 #pragma unroll
@@ -321,9 +331,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float other = ex[(((pair * 2 + (1 - xh)) * 8 + rr) * 4 + e) * 64 + lane];
-                const float v = a.alpha * (p4[e] + other) + add + rv[rr][e];
+                const float v = alpha * (p4[e] + other) + add + rv[rr][e];
                 if (nok) {
-                    O[((int64_t)(oy + (e >> 1)) * W + ox + (e & 1)) * a.out_ld + nc] = v;
+                    O[((int64_t)(oy + (e >> 1)) * W + ox + (e & 1)) * o_ld + nc] = v;
                     cs += v;
                     cq += v * v;
                 }
@@ -331,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
         }
     };
     if (xh == 0) finalize(0); else finalize(8);
-    if (a.stats) {
+    if (a.stats && !part) {
         float *st = a.stats + ((int64_t)b * (gridDim.x * 4) + blockIdx.x * 4 + wm * 2 + xh) * N * 2;
         const float s2 = cs + __shfl_xor(cs, 32);
         const float q2 = cq + __shfl_xor(cq, 32);
@@ -346,13 +356,16 @@ namespace anoddpm {
 // Called by anoddpm_igemm for cfg == 2 (arguments already validated there).
 int launch_winograd(const anoddpm_igemm_args *a, hipStream_t s)
 {
-    ANODDPM_REQUIRE(a->ks == 3 && a->b_mode == 0 && a->heads == 1 && a->ksplit == 1, "winograd: needs a 3x3 conv, packed weights, no split-K");
+    ANODDPM_REQUIRE(a->ks == 3 && a->b_mode == 0 && a->heads == 1, "winograd: needs a 3x3 conv with packed weights");
     ANODDPM_REQUIRE(a->a_mode == 0 || a->a_mode == 1, "winograd: pooled operand loads use the direct kernel");
     ANODDPM_REQUIRE(a->H % 16 == 0 && a->W % 16 == 0, "winograd: H and W must be multiples of 16");
     const int K = a->c0 + a->c1;
     ANODDPM_REQUIRE(K % WKC == 0 && (a->c1 == 0 || a->c0 % WKC == 0), "winograd: channel counts must be multiples of 16");
-    dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)((a->N + WBN - 1) / WBN), (unsigned)a->B);
-    ANODDPM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "winograd: grid too large");
+    const int cps = (K / WKC + a->ksplit - 1) / a->ksplit;
+    ANODDPM_REQUIRE((a->ksplit - 1) * cps < K / WKC, "winograd: ksplit leaves a block without channels");
+    ANODDPM_REQUIRE(a->ksplit == 1 || !a->stats || a->stats_rows >= 1, "winograd: split-K statistics need stats_rows");
+    dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)((a->N + WBN - 1) / WBN), (unsigned)(a->B * a->ksplit));
+    ANODDPM_REQUIRE(grid.y <= 65535 && (int64_t)a->B * a->ksplit <= 65535, "winograd: grid too large");
     ANODDPM_REQUIRE((int64_t)16 * K * a->N * 4 < ((int64_t)1 << 31), "winograd: transformed weights exceed 32-bit buffer offsets");
     ANODDPM_REQUIRE((int64_t)a->H * a->W * (a->a0_ld > a->a1_ld ? a->a0_ld : a->a1_ld) * 4 < ((int64_t)1 << 31),
                     "winograd: operand slice exceeds 32-bit buffer offsets");

@@ -18,6 +18,7 @@ the next step of the build plan (SURVEY.md section 7.6 lists this as the legitim
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -538,13 +539,25 @@ class _Plan:
         blocks128 = (P // 128) * ((N + 127) // 128) * Z if ok128() else 0
         cfg = 0 if (blocks128 >= 256 and N >= 96) else 1
         wino_blocks = (H // 16) * (W // 16) * ((N + 63) // 64) * Z
-        if (wino and ks == 3 and b_mode == 0 and heads == 1 and a_mode in (0, 1) and H % 16 == 0 and W % 16 == 0
-                and K % 16 == 0 and (c1 == 0 or c0 % 16 == 0) and wino_blocks >= 200 and N >= 32 and _use_winograd()):
+        wino_ksplit = 1
+        wino_ok = (wino and ks == 3 and b_mode == 0 and heads == 1 and a_mode in (0, 1) and H % 16 == 0 and W % 16 == 0
+                   and K % 16 == 0 and (c1 == 0 or c0 % 16 == 0) and N >= 32 and _use_winograd())
+        if wino_ok and wino_blocks < 200:
+            # small maps: split K over 16-channel chunks until one round of workgroups fills the 256 CUs, keeping
+            # >= 4 chunks per workgroup (the prologue / epilogue of a workgroup cost about two chunks)
+            wch = K // 16
+            wino_ksplit = int(min(max(1, wch // 4), -(-256 // wino_blocks)))
+            if N % 4 or wino_blocks * wino_ksplit < 128 or os.environ.get("ANODDPM_NO_WINOGRAD_SPLITK"):
+                wino_ok = False
+            else:
+                cps = -(-wch // wino_ksplit)
+                wino_ksplit = -(-wch // cps)                   # no empty trailing block
+        if wino_ok:
             cfg = 2
         bm = 128 if cfg == 0 else 64
         blocks = -(-P // bm) * ((N + bm - 1) // bm) * Z
         nchunks = (K + 31) // 32
-        ksplit = 1
+        ksplit = wino_ksplit if cfg == 2 else 1
         if cfg != 2 and blocks < 512 and nchunks > 1 and N % 4 == 0:
             ksplit = int(min(nchunks, 16, max(1, -(-512 // blocks))))
         st.cfg, st.ksplit = cfg, ksplit

@@ -230,6 +230,11 @@ WINO_CASES = [
     (1, (96, 32), 96, 32, 0, True, 1, False, True),        # N tail (96 = 64 + 32)
     (1, (64, 0), 64, 32, 1, True, 1, False, False),        # fused nearest x2
     (1, (16, 0), 32, 48, 0, False, 0, False, False),       # non power-of-two image, single K iteration
+    # split-K over 16-channel chunks (small maps): last element = ksplit
+    (2, (256, 0), 128, 32, 0, True, 1, True, True, 4),
+    (1, (128, 64), 64, 16, 0, True, 1, False, True, 3),    # virtual concat, split inside and across the sources
+    (1, (160, 0), 96, 16, 0, True, 1, True, False, 4),     # 10 chunks over 4 blocks: ragged last block, N tail
+    (2, (64, 0), 64, 32, 1, True, 1, False, False, 2),     # fused nearest x2
 ]
 
 
@@ -238,7 +243,8 @@ def test_winograd_conv(case):
     """cfg = 2: Winograd F(2x2,3x3) on the matrix pipe must equal the direct 3x3 convolution (fp32; the
     transform adds a few ulps: tolerance 1e-4 of the tensor magnitude, north star 1e-3)."""
     import hipops
-    B, (c0, c1), N, Hout, a_mode, use_gn, act, use_temb, use_res = case
+    B, (c0, c1), N, Hout, a_mode, use_gn, act, use_temb, use_res = case[:9]
+    ksplit = case[9] if len(case) > 9 else 1
     C = c0 + c1
     Hin = Hout if a_mode == 0 else Hout // 2
     x = rnd(B, C, Hin, Hin, seed=81)
@@ -265,7 +271,8 @@ def test_winograd_conv(case):
     st = []
     got = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), Hout=Hout, ks=3, gn=gn, act=act, a_mode=a_mode,
                             temb=temb.to(dev()) if temb is not None else None,
-                            res=hipops.nhwc(res.to(dev())) if res is not None else None, cfg=2, stats_out=st)
+                            res=hipops.nhwc(res.to(dev())) if res is not None else None, cfg=2, ksplit=ksplit,
+                            stats_out=st)
     err = relerr(hipops.nchw(got), ref)
     assert err < 1e-4, err
     # fused statistics of the Winograd epilogue
