@@ -356,14 +356,20 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(anoddpm_stem_args a)
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_head_kernel(anoddpm_head_args a)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [100][C] transformed halo + [9][C][COUT] weights
-    const int C = a.C, C4 = C >> 2;
-    float *wl = lds + 100 * C;
+    // LDS: [100 halo pixels][C + 16] activated values + [9][COUT][C] weights.  The 16-float pad makes the pixel stride
+    // = 16 (mod 64) banks, so the 16 lanes of a ds_read_b128 service group (4 pixels x 4 channel parts) hit 16
+    // different 4-bank groups.
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int C = a.C, C4 = C >> 2, CP = C + 16;
+    float *wl = lds + 100 * CP;
     const int tid = threadIdx.x;
     const int tiles_x = a.W >> 3;
     const int b = blockIdx.y;
     const int y0 = (blockIdx.x / tiles_x) * 8, x0 = (blockIdx.x % tiles_x) * 8;
-    for (int i = tid; i < 9 * C * COUT; i += 256) wl[i] = a.w[i];
+    for (int i = tid; i < 9 * C * COUT; i += 256) {                 // global [tap][c][o] -> LDS [tap][o][c]
+        const int o = i % COUT, c = (i / COUT) % C, tap = i / (COUT * C);
+        wl[(tap * COUT + o) * C + c] = a.w[i];
+    }
     const float *sc = a.gn_scale + (int64_t)b * C, *sh = a.gn_shift + (int64_t)b * C;
     for (int i = tid; i < 100 * C4; i += 256) {
         const int p = i / C4, q = i % C4;
@@ -376,22 +382,26 @@ __global__ __launch_bounds__(256) void conv_head_kernel(anoddpm_head_args a)
             v.x = silu_f(v.x * s4.x + h4.x); v.y = silu_f(v.y * s4.y + h4.y);
             v.z = silu_f(v.z * s4.z + h4.z); v.w = silu_f(v.w * s4.w + h4.w);
         }
-        *reinterpret_cast<float4 *>(lds + p * C + q * 4) = v;
+        *reinterpret_cast<float4 *>(lds + p * CP + q * 4) = v;
     }
     __syncthreads();
-    // 4 lanes per output pixel: each sums a quarter of the channels, then a 4-lane shuffle reduce
+    // 4 lanes per output pixel; lane `part` sums the channel quads q = part, part + 4, ... (16-byte LDS reads for
+    // both the activations and the weights), then a 4-lane shuffle reduce
     const int pix = tid >> 2, part = tid & 3;
     const int py = pix >> 3, px = pix & 7;
     float acc[COUT];
 #pragma unroll
     for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
     for (int tap = 0; tap < 9; ++tap) {
-        const float *src = lds + ((py + tap / 3) * 10 + px + tap % 3) * C;
-        const float *wt = wl + tap * C * COUT;
-        for (int c = part; c < C; c += 4) {
-            const float v = src[c];
+        const float *src = lds + ((py + tap / 3) * 10 + px + tap % 3) * CP;
+        const float *wt = wl + tap * COUT * C;
+        for (int q = part; q < C4; q += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + q * 4);
 #pragma unroll
-            for (int o = 0; o < COUT; ++o) acc[o] += v * wt[c * COUT + o];
+            for (int o = 0; o < COUT; ++o) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(wt + o * C + q * 4);
+                acc[o] += v.x * w4.x + v.y * w4.y + v.z * w4.z + v.w * w4.w;
+            }
         }
     }
 #pragma unroll
@@ -511,7 +521,7 @@ extern "C" int anoddpm_conv_head(const anoddpm_head_args *a, void *stream)
 {
     ANODDPM_REQUIRE(a && a->x && a->w && a->out && a->gn_scale && a->gn_shift, "conv_head: null pointer");
     ANODDPM_REQUIRE(a->Cout >= 1 && a->Cout <= 4 && a->C % 4 == 0 && a->W % 8 == 0 && a->H % 8 == 0, "conv_head: need Cout<=4, C%%4==0, H,W%%8==0");
-    const size_t lds = (size_t)(100 * a->C + 9 * a->C * a->Cout) * sizeof(float);
+    const size_t lds = (size_t)(100 * (a->C + 16) + 9 * a->C * a->Cout) * sizeof(float);
     ANODDPM_REQUIRE(lds <= 64 * 1024, "conv_head: channel count too large for the 64 KiB dynamic LDS tile");
     dim3 grid((a->H / 8) * (a->W / 8), a->B);
     hipStream_t s = anoddpm::as_stream(stream);

@@ -759,7 +759,7 @@ class _Plan:
         hfin, cfin = srcs[0]
         g = self.gn([(hfin, cfin)], S * S, "out.0.weight", "out.0.bias")
         nout = m.in_channels
-        if nout <= 4 and S % 8 == 0 and (100 * cfin + 9 * cfin * nout) * 4 <= 64 * 1024:
+        if nout <= 4 and S % 8 == 0 and (100 * (cfin + 16) + 9 * cfin * nout) * 4 <= 64 * 1024:
             # dedicated HBM-bound head kernel, writes the caller's NCHW layout directly
             self.y = self.buf(B, nout, S, S)
             st = HeadArgs()
