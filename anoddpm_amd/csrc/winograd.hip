@@ -34,7 +34,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int WKC = 16;            // channels per K iteration
 constexpr int WBN = 64;            // output channels per workgroup
 
-constexpr int WPATCH = 18 * 18;    // input patch pixels
 
 __device__ __forceinline__ f32x4 wld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 // Buffer loads: descriptor (SGPRs) + per-lane 32-bit byte offset (VGPR) + wave-uniform 32-bit byte offset (SGPR).
@@ -54,33 +53,45 @@ constexpr int DPITCH = 5;          // float4 per patch pixel in LDS: 4 quads + 1
 
 // FAST = every operand element gets GroupNorm-apply + SiLU (all 3x3 layers of the UNet): the staging code is then
 // branch-free, which keeps the whole K iteration one basic block for the scheduler.
-template <bool FAST>
-__global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a)
+// WMW = wave rows: a workgroup is 4*WMW waves on an (8*WMW) x 16 output patch.  WMW = 1 (256 threads) lets TWO independent
+// workgroups share a CU, so one's prologue / epilogue (patch latency, LDS exchange, stores: ~20 % of a K = 128
+// workgroup's life) overlaps the other's MFMA stream; WMW = 2 is the original 512-thread shape (smaller halo).
+template <bool FAST, int WMW, bool PROBE = false>
+__global__ __launch_bounds__(256 * WMW, 2) void wino_kernel(const anoddpm_igemm_args a)
 {
-    // LDS: only the activated input patch, double buffered: Dt[2][384 pixel slots][5 float4]  (60 KB; 324 pixels
-    // are real, the rest absorbs the unconditional stores of the last staging slot).
+    // PROBE (tools/wino_phases.py only): wave 0 records s_memtime at the phase boundaries into a.ws[block][8]
+    unsigned long long tstamp[5];
+    if (PROBE) tstamp[0] = __builtin_amdgcn_s_memtime();
+    constexpr int NT = 256 * WMW;                                  // threads
+    constexpr int PROWS = 8 * WMW + 2;                             // patch rows (18 columns)
+    constexpr int WPATCH = PROWS * 18;                             // input patch pixels
+    constexpr int SLOTPX = 192 * WMW;                              // pixel slots per buffer (3 * NT / 4 >= WPATCH)
+    // LDS: only the activated input patch, double buffered: Dt[2][SLOTPX pixel slots][5 float4]  (30 KB * WMW; WPATCH
+    // pixels are real, the rest absorbs the unconditional stores of the last staging slot).
     // Neither V (transformed input) nor U (transformed weights) ever touch LDS:
     //   * a lane needs V only for ITS tile and channel quad, so it transforms patch -> A-operand registers;
     //   * the B operand U[xi][k][n] is read by each lane straight from L2 (layout [xi][K/4][N][4] makes it
     //     one coalesced 16-byte load per operand) through a two-deep register ring.
     // One barrier per 16-channel iteration; the exchange buffer of the epilogue re-uses the same LDS.
-    constexpr int DT_F4 = 384 * DPITCH;                            // float4 per buffer
-    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * 8 * 4 * 64];      // 64 KB >= 2 * DT_F4 * 16 B
-    static_assert(2 * DT_F4 * 4 <= 4 * 2 * 8 * 4 * 64, "patch buffers must fit the exchange buffer");
+    constexpr int DT_F4 = SLOTPX * DPITCH;                         // float4 per buffer
+    constexpr int EX_FLOATS = (2 * WMW) * 2 * 8 * 4 * 64;          // exchange buffer of the epilogue: 32 KB * WMW
+    __shared__ __attribute__((aligned(16))) float lds[EX_FLOATS];
+    static_assert(2 * DT_F4 * 4 <= EX_FLOATS, "patch buffers must fit the exchange buffer");
+    static_assert(3 * NT >= WPATCH * 4 && 3 * NT <= SLOTPX * 4, "staging slots");
     f32x4 *ldsD = reinterpret_cast<f32x4 *>(lds);
 
-    // 8 waves: wave = (xh, wm, wn).  (wm, wn) picks the 32 tiles x 32 channels wave tile; xh picks which half of
+    // 4*WMW waves: wave = (xh, wm, wn).  (wm, wn) picks the 32 tiles x 32 channels wave tile; xh picks which half of
     // the transform rows (u = 2*xh, 2*xh+1 -> 8 of the 16 positions) the wave accumulates: 128 accumulators.
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int xh = __builtin_amdgcn_readfirstlane(wave >> 2);
-    const int wm = (wave >> 1) & 1, wn = wave & 1;
+    const int xh = __builtin_amdgcn_readfirstlane(wave / (2 * WMW));
+    const int wm = (wave >> 1) & (WMW - 1), wn = wave & 1;
     const int h = lane >> 5, l31 = lane & 31;
 
     const int H = a.H, W = a.W;
     const int K = a.c0 + a.c1, N = a.N, K4 = K >> 2;
     const int bx = blockIdx.x % (W >> 4), by = blockIdx.x / (W >> 4);
-    const int y0 = by * 16, x0 = bx * 16;                          // output patch origin
+    const int y0 = by * (8 * WMW), x0 = bx * 16;                   // output patch origin
     const int n0 = blockIdx.y * WBN;
     const int ksplit = a.ksplit;                                   // split-K over 16-channel chunks (small maps)
     const int ksi = blockIdx.z % ksplit;
@@ -99,12 +110,12 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
     const int nchunks = cbeg + cps < nchunks_all ? cbeg + cps : nchunks_all;   // end of this block's chunk range
 
     // ---- patch staging: slots of this thread (pixel = idx>>2, quad = idx&3), geometry fixed for the workgroup
-    constexpr int PJ = 3;                                           // 3 * 512 slots >= 324 pixels * 4 quads
+    constexpr int PJ = 3;                                           // 3 * NT slots >= WPATCH pixels * 4 quads
     int spix[PJ];
     const int pq = tid & 3;
 #pragma unroll
     for (int j = 0; j < PJ; ++j) {
-        const int idx = tid + j * 512;
+        const int idx = tid + j * NT;
         const int p = idx >> 2;
         const int py = p / 18, px = p - py * 18;
         const int gy = y0 + py - 1, gx = x0 + px - 1;
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < PJ; ++j) {
-            const int idx = tid + j * 512;                          // < 1536 = 384 slots * 4: always in the buffer
+            const int idx = tid + j * NT;                           // < 3 * NT <= SLOTPX * 4: always in the buffer
             f32x4 v = praw[j];
             if (FAST) {
                 v = v * asc + ash;
@@ -214,6 +225,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
     issue_reads(cbeg & 1, 0, 0, 0);
     issue_reads(cbeg & 1, 0, 0, 1);
     make_av(0);
+    if (PROBE) tstamp[1] = __builtin_amdgcn_s_memtime();
     for (int chunk = cbeg; chunk < nchunks; ++chunk) {
         const int nxt = chunk < last ? chunk + 1 : last;            // clamped: the tail re-loads valid memory, unused
         const int nxt2 = chunk + 2 < nchunks ? chunk + 2 : last;
@@ -255,6 +267,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
         }
     }
 
+    if (PROBE) tstamp[2] = __builtin_amdgcn_s_memtime();
     // ---- epilogue.  The output transform Y = A^T M A is linear in M, so each wave forms the PARTIAL 2x2 outputs
     // of its 8 positions (A^T = [[1,1,1,0],[0,1,-1,-1]]: rows u=0,1 give tm0 = M0+M1, tm1 = M1; rows u=2,3 give
     // tm0 = M2, tm1 = -M2-M3), the two halves swap partials through LDS (each finalises 8 of the 16 tile rows).
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
     };
     // exchange buffer (re-uses the V region; the loop's last barrier has passed): ex[pair][writer xh][8 rows][4][64 lanes]
     float *ex = lds;
-    const int pair = wave & 3;
+    const int pair = wave & (2 * WMW - 1);
     if (xh == 0) {
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {                            // rows 8..15 are finalised by the xh = 1 wave
@@ -293,6 +306,7 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
         }
     }
     __syncthreads();
+    if (PROBE) tstamp[3] = __builtin_amdgcn_s_memtime();
 
     const int n = n0 + bcol;
     const bool nok = n < N;
@@ -342,10 +356,19 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const anoddpm_igemm_args a
     };
     if (xh == 0) finalize(0); else finalize(8);
     if (a.stats && !part) {
-        float *st = a.stats + ((int64_t)b * (gridDim.x * 4) + blockIdx.x * 4 + wm * 2 + xh) * N * 2;
+        float *st = a.stats + ((int64_t)b * (gridDim.x * 2 * WMW) + blockIdx.x * (2 * WMW) + wm * 2 + xh) * N * 2;
         const float s2 = cs + __shfl_xor(cs, 32);
         const float q2 = cq + __shfl_xor(cq, 32);
         if (h == 0 && nok) { st[n * 2] = s2; st[n * 2 + 1] = q2; }
+    }
+    if (PROBE) {
+        __builtin_amdgcn_s_waitcnt(0);                               // stores retired: what the wave waits for before it can end
+        tstamp[4] = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(a.ws) +
+                                      (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8;
+            for (int i = 0; i < 5; ++i) dbg[i] = tstamp[i];
+        }
     }
 }
 
@@ -364,13 +387,23 @@ int launch_winograd(const anoddpm_igemm_args *a, hipStream_t s)
     const int cps = (K / WKC + a->ksplit - 1) / a->ksplit;
     ANODDPM_REQUIRE((a->ksplit - 1) * cps < K / WKC, "winograd: ksplit leaves a block without channels");
     ANODDPM_REQUIRE(a->ksplit == 1 || !a->stats || a->stats_rows >= 1, "winograd: split-K statistics need stats_rows");
-    dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)((a->N + WBN - 1) / WBN), (unsigned)(a->B * a->ksplit));
+    // 256-thread workgroups (two per CU) by default; ANODDPM_DEBUG0=1 selects the 512-thread shape
+    const int wmw = anoddpm::g_debug[0] == 1 ? 2 : 1;
+    dim3 grid((unsigned)((a->H / (8 * wmw)) * (a->W / 16)), (unsigned)((a->N + WBN - 1) / WBN), (unsigned)(a->B * a->ksplit));
     ANODDPM_REQUIRE(grid.y <= 65535 && (int64_t)a->B * a->ksplit <= 65535, "winograd: grid too large");
     ANODDPM_REQUIRE((int64_t)16 * K * a->N * 4 < ((int64_t)1 << 31), "winograd: transformed weights exceed 32-bit buffer offsets");
     ANODDPM_REQUIRE((int64_t)a->H * a->W * (a->a0_ld > a->a1_ld ? a->a0_ld : a->a1_ld) * 4 < ((int64_t)1 << 31),
                     "winograd: operand slice exceeds 32-bit buffer offsets");
-    if (a->gn_scale && a->act) hipLaunchKernelGGL(wino_kernel<true>, grid, dim3(512), 0, s, *a);
-    else                       hipLaunchKernelGGL(wino_kernel<false>, grid, dim3(512), 0, s, *a);
+    const bool fast = a->gn_scale && a->act;
+    if (wmw == 2) {
+        if (fast) hipLaunchKernelGGL((wino_kernel<true, 2>), grid, dim3(512), 0, s, *a);
+        else      hipLaunchKernelGGL((wino_kernel<false, 2>), grid, dim3(512), 0, s, *a);
+    } else if (anoddpm::g_debug[1] == 1 && fast && a->ksplit == 1 && a->ws) {
+        hipLaunchKernelGGL((wino_kernel<true, 1, true>), grid, dim3(256), 0, s, *a);     // phase probe (tools/wino_phases.py)
+    } else {
+        if (fast) hipLaunchKernelGGL((wino_kernel<true, 1>), grid, dim3(256), 0, s, *a);
+        else      hipLaunchKernelGGL((wino_kernel<false, 1>), grid, dim3(256), 0, s, *a);
+    }
     return check_launch("winograd");
 }
 
