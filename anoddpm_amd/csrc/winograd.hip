@@ -285,29 +285,6 @@ __global__ __launch_bounds__(256 * WMW, 2) void wino_kernel(const anoddpm_igemm_
             out4[i * 2 + 1] = tm[i][1] - tm[i][2] - tm[i][3];
         }
     };
-    // exchange buffer (re-uses the V region; the loop's last barrier has passed): ex[pair][writer xh][8 rows][4][64 lanes]
-    float *ex = lds;
-    const int pair = wave & (2 * WMW - 1);
-    if (xh == 0) {
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {                            // rows 8..15 are finalised by the xh = 1 wave
-            float p4[4];
-            partial(8 + rr, p4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ex[(((pair * 2 + 0) * 8 + rr) * 4 + e) * 64 + lane] = p4[e];
-        }
-    } else {
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {                            // rows 0..7 are finalised by the xh = 0 wave
-            float p4[4];
-            partial(rr, p4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ex[(((pair * 2 + 1) * 8 + rr) * 4 + e) * 64 + lane] = p4[e];
-        }
-    }
-    __syncthreads();
-    if (PROBE) tstamp[3] = __builtin_amdgcn_s_memtime();
-
     const int n = n0 + bcol;
     const bool nok = n < N;
     const int nc = nok ? n : 0;
@@ -333,6 +310,29 @@ __global__ __launch_bounds__(256 * WMW, 2) void wino_kernel(const anoddpm_igemm_
         for (int e = 0; e < 4; ++e)
             rv[rr][e] = R ? R[((int64_t)(oy + (e >> 1)) * W + ox + (e & 1)) * a.res_ld + nc] : 0.f;
     }
+    // exchange buffer (re-uses the V region; the loop's last barrier has passed): ex[pair][writer xh][8 rows][4][64 lanes]
+    float *ex = lds;
+    const int pair = wave & (2 * WMW - 1);
+    if (xh == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {                            // rows 8..15 are finalised by the xh = 1 wave
+            float p4[4];
+            partial(8 + rr, p4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ex[(((pair * 2 + 0) * 8 + rr) * 4 + e) * 64 + lane] = p4[e];
+        }
+    } else {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {                            // rows 0..7 are finalised by the xh = 0 wave
+            float p4[4];
+            partial(rr, p4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ex[(((pair * 2 + 1) * 8 + rr) * 4 + e) * 64 + lane] = p4[e];
+        }
+    }
+    __syncthreads();
+    if (PROBE) tstamp[3] = __builtin_amdgcn_s_memtime();
+
     auto finalize = [&](int rbase) {                               // rbase is a literal (0 or 8): static accumulator indices
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
