@@ -39,7 +39,7 @@ CONFIGS = {
                name="64x64 base64 batch1 (BASELINE config 1 shape, on GPU)"),
 }
 T_STEPS = 1000
-MEASURED_TRAFFIC_BYTES_PER_LAUNCH = 1.038e8      # profiles/r1d_pmc_hbm_by_kernel.csv, config c2 batch 4
+MEASURED_TRAFFIC_BYTES_PER_LAUNCH = 1.135e8      # profiles/r1e_pmc_hbm_by_kernel.csv, config c2 batch 4
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
@@ -215,7 +215,7 @@ def main():
                     # process): (2*FETCH_SIZE + WRITE_SIZE) KB averaged over the launches of one step, with the
                     # guide's gfx950 FETCH_SIZE x2 correction.  Only quoted for the workload it was measured on.
                     "traffic": MEASURED_TRAFFIC_BYTES_PER_LAUNCH if (args.config == "c2" and B == 4) else None,
-                    "traffic_source": "profiles/r1d_pmc_hbm_by_kernel.csv",
+                    "traffic_source": "profiles/r1e_pmc_hbm_by_kernel.csv",
                     "achieved_is": "ALGORITHMIC direct-convolution FLOPs / HIP-event time of the launches (can exceed the executed rate: Winograd does 2.25x fewer multiplies)",
                     "executed_tflops": executed, "executed_frac": executed / PEAK_FP32_MATRIX_TFLOPS,
                     "winograd_share_of_algorithmic_flops": sum(e["gflop"] for e in plan.igemm_log if e["wino"]) * 1e9 / max(flops_per_step, 1.0),
