@@ -2,7 +2,9 @@
 """Side measurements that are parity-test configurations rather than the bench line (BASELINE configs 3 & 4):
   * config 4: rand_3d_octaves((1000,256,256), 8, 0.8, 64) -- HIP kernel time vs the C/OpenMP oracle on host cores
   * config 3 (per-GPU share): one training step (p_loss -> backward -> clip -> fused AdamW+EMA), batch 4 at 256^2
-Run on the GPU box:  python tools/bench_extras.py  (prints one JSON object per measurement)."""
+  * detection: the `total_avg` chains of one detection_B setting, batched (this build) vs one at a time (upstream's loop)
+Lives under tests/ because the config-4 leg times the CPU oracle.
+Run on the GPU box:  python tests/extras_bench.py [c4] [c3] [detect]  (prints one JSON object per measurement)."""
 import ctypes
 import json
 import os
@@ -76,9 +78,33 @@ def train_step_c3(batch=4, steps=3):
             "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}
 
 
+def detection_chains(total_avg=5, t_distance=50):
+    import GaussianDiffusion as GD
+    from UNet import UNetModel
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = UNetModel(256, 128, n_heads=2, attention_resolutions="16,8").to(dev).eval()
+    diff = GD.GaussianDiffusionModel([256, 256], GD.get_beta_schedule(1000, "linear"), noise="gauss")
+    x_0 = torch.rand(1, 1, 256, 256, device=dev) * 2 - 1
+    out = {}
+    for name, fn in (("batched", lambda: diff._avg_chains(model, x_0, t_distance, total_avg)),
+                     ("serial", lambda: [diff._avg_chains(model, x_0, t_distance, 1) for _ in range(total_avg)])):
+        fn()                                             # plan build + graph capture for this batch size
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        out[name] = time.perf_counter() - t0
+    return {"what": f"detection setting: {total_avg} chains x {t_distance} reverse steps @256^2 base128 (GaussianDiffusion.py:554-569)",
+            "batched_s": out["batched"], "serial_s": out["serial"], "speedup": out["serial"] / out["batched"],
+            "chain_steps_per_s_batched": total_avg * t_distance / out["batched"]}
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c4", "c3"]
+    which = sys.argv[1:] or ["c4", "c3", "detect"]
     if "c4" in which:
         print(json.dumps(simplex_c4()), flush=True)
     if "c3" in which:
         print(json.dumps(train_step_c3()), flush=True)
+    if "detect" in which:
+        print(json.dumps(detection_chains()), flush=True)

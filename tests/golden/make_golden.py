@@ -169,6 +169,10 @@ UNET_CASES = {
     "i64_b32_hc32": (dict(img_size=64, base_channels=32, n_head_channels=32, attention_resolutions="16,8"), 2, [0, 999]),
     "i64_b64_c3": (dict(img_size=64, base_channels=64, n_heads=2, in_channels=3), 1, [42]),
     "i128_b32_h2": (dict(img_size=128, base_channels=32, n_heads=2, attention_resolutions="16,8"), 1, [250]),
+    # BASELINE config 5's topology at a quarter of its size: explicit mults (1,1,2,2,4,4), attention "32,16,8"
+    # (sequence lengths 1024 / 256 / 64 as in the 512^2 model)
+    "c5like_i128_b32": (dict(img_size=128, base_channels=32, n_heads=2, channel_mults=(1, 1, 2, 2, 4, 4),
+                             attention_resolutions="32,16,8"), 2, [7, 640]),
 }
 
 
@@ -218,12 +222,16 @@ def run_unet_case(name, kw, batch, ts, probes=True):
     return out
 
 
-def gen_unet():
+def gen_unet(only=None):
     for name, (kw, batch, ts) in UNET_CASES.items():
+        if only and name not in only:
+            continue
         out = run_unet_case(name, kw, batch, ts)
         np.savez_compressed(os.path.join(HERE, f"unet_{name}.npz"), **out)
         print(f"unet_{name}.npz", "y", out["y"].shape, "params", int(out["n_params"]),
               "|y| mean", float(np.abs(out["y"]).mean()))
+    if only and "c2_256_b128" not in only:
+        return
     # BASELINE config-2 shaped forward (256^2, base 128, heads 2, attn 16,8), batch 1
     kw = dict(img_size=256, base_channels=128, n_heads=2, attention_resolutions="16,8")
     out = run_unet_case("c2_256_b128", kw, 1, [123], probes=True)
@@ -272,5 +280,7 @@ if __name__ == "__main__":
         gen_diffusion()
     if "unet" in which:
         gen_unet()
+    if any(w.startswith("unet:") for w in which):
+        gen_unet([w.split(":", 1)[1] for w in which if w.startswith("unet:")])
     if "metrics" in which:
         gen_metrics()

@@ -16,12 +16,14 @@ CASES = {
     "i64_b32_hc32": dict(img_size=64, base_channels=32, n_head_channels=32, attention_resolutions="16,8"),
     "i64_b64_c3": dict(img_size=64, base_channels=64, n_heads=2, in_channels=3),
     "i128_b32_h2": dict(img_size=128, base_channels=32, n_heads=2, attention_resolutions="16,8"),
+    "c5like_i128_b32": dict(img_size=128, base_channels=32, n_heads=2, channel_mults=(1, 1, 2, 2, 4, 4),
+                            attention_resolutions="32,16,8"),
     "c2_256_b128": dict(img_size=256, base_channels=128, n_heads=2, attention_resolutions="16,8"),
 }
 
 
 def shapes_of(kw):
-    return uo.param_shapes(kw["img_size"], kw["base_channels"], "", 2,
+    return uo.param_shapes(kw["img_size"], kw["base_channels"], kw.get("channel_mults", ""), 2,
                            kw.get("attention_resolutions", "32,16,8"), kw.get("in_channels", 1))
 
 
