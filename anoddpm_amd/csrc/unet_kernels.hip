@@ -163,38 +163,63 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(anoddpm_chan_stats_args
 }
 
 // grid (groups, B): fold per-channel partials of up to two sources into scale/shift for one group.
+// A group's channels are contiguous inside a statistics row ({sum, sumsq} pairs), so a thread takes whole rows and
+// reads the group's 2*cpg floats with 16-byte loads; fp64 accumulation, fixed order (thread-strided rows, then a
+// shuffle tree, then the four wave results in order) -> deterministic.
 __global__ __launch_bounds__(256) void gn_finalize2_kernel(anoddpm_gn_finalize_args a)
 {
-    __shared__ double red_s[256];
-    __shared__ double red_q[256];
+    __shared__ double red_s[4];
+    __shared__ double red_q[4];
     const int C = a.c0 + a.c1;
     const int cpg = C / a.groups;
     const int g = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int cc = 0; cc < cpg; ++cc) {
-        const int c = g * cpg + cc;
+    const int cbeg = g * cpg;
+    const bool one_source = (cbeg + cpg <= a.c0) || (cbeg >= a.c0);       // block-uniform
+    if (one_source && (cpg & 1) == 0 && (a.c0 & 1) == 0 && (a.c1 & 1) == 0) {
+        // 2*cpg floats = cpg/2 float4 per row, 16-byte aligned
         const float *st;
         int rows, cl, cw;
-        if (c < a.c0) { st = a.stats0; rows = a.rows0; cl = c; cw = a.c0; }
-        else          { st = a.stats1; rows = a.rows1; cl = c - a.c0; cw = a.c1; }
-        st += (int64_t)b * rows * cw * 2;
+        if (cbeg < a.c0) { st = a.stats0; rows = a.rows0; cl = cbeg; cw = a.c0; }
+        else             { st = a.stats1; rows = a.rows1; cl = cbeg - a.c0; cw = a.c1; }
+        st += (int64_t)b * rows * cw * 2 + (int64_t)cl * 2;
+        const int nq = cpg >> 1;
         for (int r = tid; r < rows; r += 256) {
-            const float2 v = *reinterpret_cast<const float2 *>(st + ((int64_t)r * cw + cl) * 2);
-            s += (double)v.x;
-            q += (double)v.y;
+            const float4 *p = reinterpret_cast<const float4 *>(st + (int64_t)r * cw * 2);
+            for (int k = 0; k < nq; ++k) {
+                const float4 v = p[k];
+                s += (double)v.x + (double)v.z;
+                q += (double)v.y + (double)v.w;
+            }
+        }
+    } else {
+        // a group that straddles the two sources of a virtual concat (e.g. 256 + 128 channels, 12 per group)
+        for (int cc = 0; cc < cpg; ++cc) {
+            const int c = cbeg + cc;
+            const float *st;
+            int rows, cl, cw;
+            if (c < a.c0) { st = a.stats0; rows = a.rows0; cl = c; cw = a.c0; }
+            else          { st = a.stats1; rows = a.rows1; cl = c - a.c0; cw = a.c1; }
+            st += (int64_t)b * rows * cw * 2;
+            for (int r = tid; r < rows; r += 256) {
+                const float2 v = *reinterpret_cast<const float2 *>(st + ((int64_t)r * cw + cl) * 2);
+                s += (double)v.x;
+                q += (double)v.y;
+            }
         }
     }
-    red_s[tid] = s;
-    red_q[tid] = q;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) { red_s[tid] += red_s[tid + o]; red_q[tid] += red_q[tid + o]; }
-        __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        q += __shfl_xor(q, o);
     }
+    if ((tid & 63) == 0) { red_s[tid >> 6] = s; red_q[tid >> 6] = q; }
+    __syncthreads();
+    const double ts = ((red_s[0] + red_s[1]) + red_s[2]) + red_s[3];
+    const double tq = ((red_q[0] + red_q[1]) + red_q[2]) + red_q[3];
     const double n = (double)a.P * cpg;
-    const double mean = red_s[0] / n;
-    double var = red_q[0] / n - mean * mean;
+    const double mean = ts / n;
+    double var = tq / n - mean * mean;
     var = var > 0.0 ? var : 0.0;
     const double rstd = 1.0 / sqrt(var + (double)a.eps);
     if (tid < cpg) {
