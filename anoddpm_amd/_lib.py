@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 
@@ -117,11 +117,19 @@ class AnomalyArgs(Structure):
                 ("navg", c_int32), ("B", c_int32), ("threshold", c_float)]
 
 
+class VlbArgs(Structure):
+    _fields_ = [("x0", c_void_p), ("xt", c_void_p), ("eps", c_void_p), ("noise", c_void_p), ("t", c_void_p),
+                ("c_recip", c_void_p), ("c_recipm1", c_void_p), ("c_coef1", c_void_p), ("c_coef2", c_void_p),
+                ("c_post_logvar", c_void_p), ("c_model_logvar", c_void_p),
+                ("pred_x0", c_void_p), ("out", c_void_p), ("workspace", c_void_p), ("workspace_doubles", c_int64),
+                ("n", c_int64), ("B", c_int32), ("T", c_int32)]
+
+
 ANOMALY_NCOUNTS = 12
 ANOMALY_BLOCKS = 64
 
 _STRUCTS = [SimplexArgs, PUpdateArgs, IgemmArgs, GnArgs, SoftmaxArgs, ResampleArgs, LinearArgs,
-            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, AnomalyArgs]
+            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, AnomalyArgs, VlbArgs]
 
 # every symbol include/anoddpm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -132,7 +140,7 @@ SYMBOLS = [
     "anoddpm_igemm", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
     "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_conv_head", "anoddpm_nhwc_to_nchw",
     "anoddpm_run_ops", "anoddpm_prof_enable", "anoddpm_prof_active", "anoddpm_prof_collect",
-    "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map",
+    "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map", "anoddpm_vlb_terms",
 ]
 
 _lib = None
@@ -202,6 +210,7 @@ def lib():
     L.anoddpm_adamw_ema.argtypes = [POINTER(AdamwArgs), c_void_p]
     L.anoddpm_sumsq.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
     L.anoddpm_anomaly_map.argtypes = [POINTER(AnomalyArgs), c_void_p]
+    L.anoddpm_vlb_terms.argtypes = [POINTER(VlbArgs), c_void_p]
     for i in range(8):
         if os.environ.get(f"ANODDPM_DEBUG{i}"):
             L.anoddpm_debug_set(i, int(os.environ[f"ANODDPM_DEBUG{i}"], 0))

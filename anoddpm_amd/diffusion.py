@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import PUpdateArgs, check, current_stream, lib, ptr
+from ._lib import PUpdateArgs, VlbArgs, check, current_stream, lib, ptr
 from .simplex import Simplex_CLASS, perm_tables
 
 __all__ = ["SimplexNoiseFn", "ReverseChain", "get_beta_schedule", "extract", "mean_flat", "normal_kl", "approx_standard_normal_cdf",
@@ -233,6 +233,7 @@ class _DeviceTables:
         model_logvar = np.log(model_var)
         self.model_variance = up(model_var)
         self.model_log_variance = up(model_logvar)
+        self.posterior_log_variance_clipped = up(owner.posterior_log_variance_clipped)
         # exp(0.5*log_variance) evaluated by the same fp32 torch expression the reference uses (:317)
         self.sigma = torch.exp(0.5 * torch.from_numpy(model_logvar).float()).to(device)
 
@@ -463,7 +464,36 @@ class GaussianDiffusionModel:
         tb = self._tables(x_t.device)
         return self._axpby(tb.sqrt_alphas, tb.sqrt_betas, x_t, t, noise)
 
+    def vlb_terms(self, x_0, x_t, t, eps, noise=None, want_pred=True):
+        """Fused variational-bound terms of one step (anoddpm_vlb_terms): returns (vlb [B] in bits/dim,
+        mean((pred_x_0-x_0)^2) [B], mean((eps'-noise)^2) [B], pred_x_0 or None).  No autograd."""
+        _lib.require_cuda(x_t, "GaussianDiffusionModel.vlb_terms")
+        tb = self._tables(x_t.device)
+        B = x_t.shape[0]
+        x_0, x_t, eps = self._f32(x_0), self._f32(x_t), self._f32(eps)
+        noise = self._f32(noise) if noise is not None else None
+        tt = self._t64(t, x_t.device)
+        out = torch.empty((3, B), dtype=torch.float32, device=x_t.device)
+        ws = torch.empty((64 * B * 3,), dtype=torch.float64, device=x_t.device)
+        pred = torch.empty_like(x_t) if want_pred else None
+        a = VlbArgs()
+        a.x0, a.xt, a.eps, a.noise, a.t = ptr(x_0), ptr(x_t), ptr(eps), (ptr(noise) if noise is not None else None), ptr(tt)
+        a.c_recip, a.c_recipm1 = ptr(tb.sqrt_recip_alphas_cumprod), ptr(tb.sqrt_recipm1_alphas_cumprod)
+        a.c_coef1, a.c_coef2 = ptr(tb.posterior_mean_coef1), ptr(tb.posterior_mean_coef2)
+        a.c_post_logvar, a.c_model_logvar = ptr(tb.posterior_log_variance_clipped), ptr(tb.model_log_variance)
+        a.pred_x0 = ptr(pred) if pred is not None else None
+        a.out, a.workspace, a.workspace_doubles = ptr(out), ptr(ws), ws.numel()
+        a.n, a.B, a.T = (x_t[0].numel() if B else 0), B, self.num_timesteps
+        check(lib().anoddpm_vlb_terms(ctypes.byref(a), current_stream()), "vlb_terms")
+        return out[0], out[1], out[2], pred
+
     def calc_vlb_xt(self, model, x_0, x_t, t, estimate_noise=None):
+        """GaussianDiffusion.py:384-397.  Without autograd (calc_total_vlb, logging) the whole term is one fused
+        launch after the model call; with autograd recording (the hybrid loss) it stays differentiable torch ops."""
+        if not torch.is_grad_enabled():
+            eps = model(x_t, t) if estimate_noise is None else estimate_noise
+            vlb, _, _, pred = self.vlb_terms(x_0, x_t, t, eps)
+            return {"output": vlb, "pred_x_0": pred}
         true_mean, _, true_log_var = self.q_posterior_mean_variance(x_0, x_t, t)
         output = self.p_mean_variance(model, x_t, t, estimate_noise)
         kl = normal_kl(true_mean, true_log_var, output["mean"], output["log_variance"])
@@ -510,17 +540,19 @@ class GaussianDiffusionModel:
         return mean_flat(kl_prior) / np.log(2.0)
 
     def calc_total_vlb(self, x_0, model, args):
+        """GaussianDiffusion.py:445-478: T model calls; everything after each call (KL / decoder NLL, the two MSE
+        curves) is one fused launch, and `t` is the only host-built tensor per step."""
         vb, x_0_mse, mse = [], [], []
         for t in reversed(list(range(self.num_timesteps))):
             t_batch = torch.tensor([t] * args["Batch_Size"], device=x_0.device)
             noise = torch.randn_like(x_0)
             x_t = self.sample_q(x_0=x_0, t=t_batch, noise=noise)
             with torch.no_grad():
-                out = self.calc_vlb_xt(model, x_0=x_0, x_t=x_t, t=t_batch)
-            vb.append(out["output"])
-            x_0_mse.append(mean_flat((out["pred_x_0"] - x_0) ** 2))
-            eps = self.predict_eps_from_x_0(x_t, t_batch, out["pred_x_0"])
-            mse.append(mean_flat((eps - noise) ** 2))
+                eps = model(x_t, t_batch)
+                v, m0, me, _ = self.vlb_terms(x_0, x_t, t_batch, eps, noise=noise, want_pred=False)
+            vb.append(v)
+            x_0_mse.append(m0)
+            mse.append(me)
         vb = torch.stack(vb, dim=1)
         x_0_mse = torch.stack(x_0_mse, dim=1)
         mse = torch.stack(mse, dim=1)

@@ -375,6 +375,30 @@ typedef struct anoddpm_anomaly_args {
 
 int anoddpm_anomaly_map(const anoddpm_anomaly_args *a, void *stream);
 
+/* Variational-bound terms of one reverse step (GaussianDiffusion.py:384-397 calc_vlb_xt, and the two MSE curves of
+ * calc_total_vlb :445-478): per sample b
+ *   out[0*B + b] = mean_flat( t==0 ? -discretised_gaussian_log_likelihood(x_0; mean, 0.5*logvar)
+ *                                  : normal_kl(true_mean, post_logvar, mean, model_logvar) ) / ln 2
+ *   out[1*B + b] = mean_flat((pred_x_0 - x_0)^2)
+ *   out[2*B + b] = mean_flat((predict_eps_from_x_0(x_t, t, pred_x_0) - noise)^2)        (0 when noise == NULL)
+ * with pred_x_0 = clamp(c_recip[t]*x_t - c_recipm1[t]*eps, -1, 1) and mean = c_coef1[t]*pred_x_0 + c_coef2[t]*x_t.
+ * Tables are fp32 copies of the reference's fp64 tables (sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod,
+ * posterior_mean_coef1/2, posterior_log_variance_clipped, log(append(posterior_variance[1], betas[1:]))).
+ * workspace: >= 64 * B * 3 doubles [dev].  Deterministic. */
+typedef struct anoddpm_vlb_args {
+    const float *x0, *xt, *eps, *noise;
+    const int64_t *t;
+    const float *c_recip, *c_recipm1, *c_coef1, *c_coef2, *c_post_logvar, *c_model_logvar;
+    float *pred_x0;                 /* optional [B][n] */
+    float *out;                     /* [3][B] */
+    double *workspace;
+    int64_t workspace_doubles;
+    int64_t n;
+    int32_t B, T;
+} anoddpm_vlb_args;
+
+int anoddpm_vlb_terms(const anoddpm_vlb_args *a, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,3 +86,45 @@ def p_sample_update(tb, x_t, t, eps, noise):
     out = p_mean_variance_eps(tb, x_t, t, eps)
     mask = (t != 0).float().view(-1, *([1] * (x_t.dim() - 1)))
     return out["mean"] + mask * torch.exp(0.5 * out["log_variance"]) * noise, out["pred_x_0"]
+
+
+# ---------------------------------------------------------------------------- variational bound
+def _mean_flat(x):
+    return x.mean(dim=list(range(1, x.dim())))
+
+
+def _approx_cdf(x):
+    """GaussianDiffusion.py:56-61."""
+    return 0.5 * (1.0 + torch.tanh(np.sqrt(2.0 / np.pi) * (x + 0.044715 * torch.pow(x, 3))))
+
+
+def vlb_terms(tb, x0, x_t, t, eps, noise=None):
+    """calc_vlb_xt (GaussianDiffusion.py:384-397) with normal_kl (:43-53) and
+    discretised_gaussian_log_likelihood (:64-93), plus the two per-step MSE curves of calc_total_vlb (:463-466).
+    Returns (vlb bits/dim [B], mean((pred_x0-x0)^2) [B], mean((eps'-noise)^2) [B] or None, pred_x0)."""
+    s = x_t.shape
+    out = p_mean_variance_eps(tb, x_t, t, eps)
+    true_mean = gather(tb["posterior_mean_coef1"], t, s) * x0 + gather(tb["posterior_mean_coef2"], t, s) * x_t
+    lv1 = gather(tb["posterior_log_variance_clipped"], t, s)
+    lv2, mean = out["log_variance"], out["mean"]
+    kl = 0.5 * (-1 + lv2 - lv1 + torch.exp(lv1 - lv2) + ((true_mean - mean) ** 2) * torch.exp(-lv2))
+    kl = _mean_flat(kl) / np.log(2.0)
+    log_scales = 0.5 * lv2
+    centered = x0 - mean
+    inv_std = torch.exp(-log_scales)
+    cdf_plus = _approx_cdf(inv_std * (centered + 1.0 / 255.0))
+    cdf_min = _approx_cdf(inv_std * (centered - 1.0 / 255.0))
+    log_cdf_plus = torch.log(cdf_plus.clamp(min=1e-12))
+    log_one_minus_cdf_min = torch.log((1.0 - cdf_min).clamp(min=1e-12))
+    cdf_delta = cdf_plus - cdf_min
+    log_probs = torch.where(x0 < -0.999, log_cdf_plus,
+                            torch.where(x0 > 0.999, log_one_minus_cdf_min, torch.log(cdf_delta.clamp(min=1e-12))))
+    nll = _mean_flat(-log_probs) / np.log(2.0)
+    vlb = torch.where(t == 0, nll, kl)
+    pred = out["pred_x_0"]
+    x0_mse = _mean_flat((pred - x0) ** 2)
+    mse = None
+    if noise is not None:
+        eps_rec = (gather(tb["sqrt_recip_alphas_cumprod"], t, s) * x_t - pred) / gather(tb["sqrt_recipm1_alphas_cumprod"], t, s)
+        mse = _mean_flat((eps_rec - noise) ** 2)
+    return vlb, x0_mse, mse, pred

@@ -9,6 +9,7 @@ recipe from SURVEY.md 8c).  Outputs are DATA (inputs + expected outputs), never 
     diffusion_kat.npz    schedule tables (linear/cosine), sample_q / p_mean_variance / sample_p
     unet_<name>.npz      UNetModel.forward outputs (+ per-block activation probes)
     metrics_kat.npz      evaluation.py metrics + the mean / mse / threshold images of detection_A/B
+    vlb_kat.npz          calc_vlb_xt (KL and decoder-NLL branches) and the MSE curves of calc_total_vlb
 """
 import os
 import sys
@@ -271,8 +272,36 @@ def gen_metrics():
     print("metrics_kat.npz:", len(out), "arrays")
 
 
+def gen_vlb():
+    """calc_vlb_xt (incl. the t == 0 decoder-NLL branch and both |x_0| > 0.999 branches) and the per-step MSE
+    curves of calc_total_vlb, from the reference with injected eps / noise."""
+    g = torch.Generator().manual_seed(19)
+    B, H = 6, 16
+    x0 = torch.rand(B, 1, H, H, generator=g) * 2 - 1
+    x0[:, :, 0, :4] = -1.0                      # exact background value: the x < -0.999 branch
+    x0[:, :, 1, :4] = 1.0                       # the x > 0.999 branch
+    eps = torch.randn(B, 1, H, H, generator=g)
+    noise = torch.randn(B, 1, H, H, generator=g)
+    out = {"x0": x0.numpy(), "eps": eps.numpy(), "noise": noise.numpy()}
+    for name in ("linear", "cosine"):
+        d = ref_gd.GaussianDiffusionModel([H, H], ref_gd.get_beta_schedule(1000, name), noise="gauss")
+        for tag, t in (("mixed", torch.tensor([0, 1, 2, 500, 998, 999])), ("zero", torch.zeros(B, dtype=torch.int64))):
+            x_t = d.sample_q(x0, t, noise)
+            r = d.calc_vlb_xt(None, x0, x_t, t, estimate_noise=eps)
+            pred = r["pred_x_0"]
+            out[f"{name}_{tag}_t"] = t.numpy()
+            out[f"{name}_{tag}_x_t"] = x_t.numpy()
+            out[f"{name}_{tag}_vlb"] = r["output"].numpy()
+            out[f"{name}_{tag}_pred_x_0"] = pred.numpy()
+            out[f"{name}_{tag}_x_0_mse"] = ref_gd.mean_flat((pred - x0) ** 2).numpy()              # :463
+            e2 = d.predict_eps_from_x_0(x_t, t, pred)                                               # :464
+            out[f"{name}_{tag}_mse"] = ref_gd.mean_flat((e2 - noise) ** 2).numpy()                  # :465
+    np.savez_compressed(os.path.join(HERE, "vlb_kat.npz"), **out)
+    print("vlb_kat.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["simplex", "diffusion", "unet", "metrics"]
+    which = sys.argv[1:] or ["simplex", "diffusion", "unet", "metrics", "vlb"]
     torch.set_num_threads(8)
     if "simplex" in which:
         gen_simplex()
@@ -284,3 +313,5 @@ if __name__ == "__main__":
         gen_unet([w.split(":", 1)[1] for w in which if w.startswith("unet:")])
     if "metrics" in which:
         gen_metrics()
+    if "vlb" in which:
+        gen_vlb()
