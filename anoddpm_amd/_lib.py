@@ -135,7 +135,7 @@ _STRUCTS = [SimplexArgs, PUpdateArgs, IgemmArgs, GnArgs, SoftmaxArgs, ResampleAr
 SYMBOLS = [
     "anoddpm_abi_version", "anoddpm_last_error", "anoddpm_device_count", "anoddpm_debug_set", "anoddpm_struct_size",
     "anoddpm_simplex_perm_init", "anoddpm_simplex3_octaves_f64", "anoddpm_simplex3_octaves_f32",
-    "anoddpm_simplex3_grid_f64",
+    "anoddpm_simplex3_grid_f64", "anoddpm_simplex2_octaves_f64", "anoddpm_simplex2_grid_f64",
     "anoddpm_q_sample", "anoddpm_p_sample_update", "anoddpm_chain_advance",
     "anoddpm_igemm", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
     "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_conv_head", "anoddpm_nhwc_to_nchw",
@@ -189,6 +189,8 @@ def lib():
         getattr(L, name).argtypes = [POINTER(SimplexArgs), c_void_p]
     L.anoddpm_simplex3_grid_f64.argtypes = [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32,
                                             c_void_p, c_void_p]
+    L.anoddpm_simplex2_octaves_f64.argtypes = [c_void_p, c_int32, c_void_p, c_int32, c_double, c_double, c_void_p]
+    L.anoddpm_simplex2_grid_f64.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]
     L.anoddpm_q_sample.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int32, c_int64, c_int32, c_void_p]
     L.anoddpm_p_sample_update.argtypes = [POINTER(PUpdateArgs), c_void_p]

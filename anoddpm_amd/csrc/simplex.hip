@@ -224,6 +224,99 @@ __global__ __launch_bounds__(256) void simplex3_grid_kernel(double *out, const d
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 2-D OpenSimplex (simplex.py:194-199, 211-318; rand_2d_octaves :56-73).  Vertex = lattice offset (i, j), displacement
+// (d0 - i) - n*SQUISH2 with n = i + j (0 for the (1,-1) / (-1,1) extras); accumulation order (1,0), (0,1), base,
+// extra -- bit-identical to the reference's fp64 arithmetic (this file is compiled with -ffp-contract=off).
+constexpr double STRETCH2 = -0.211324865405187;
+constexpr double SQUISH2 = 0.366025403784439;
+constexpr double NORM2 = 47.0;
+__constant__ signed char kGrad2[16] = {5, 2, 2, 5, -5, 2, -2, 5, 5, -2, 2, -5, -5, -2, -2, -5};
+
+struct Tables2 {
+    unsigned char perm[256];
+    double grad[16];
+};
+
+__device__ __forceinline__ double term2(const Tables2 &T, long long xsb, long long ysb, double dx0, double dy0, int i, int j)
+{
+    const double sq = (double)(i + j) * SQUISH2;
+    const double dx = (dx0 - (double)i) - sq;
+    const double dy = (dy0 - (double)j) - sq;
+    double attn = 2 - dx * dx - dy * dy;
+    double r = 0.0;
+    if (attn > 0) {
+        const int h0 = T.perm[(int)((xsb + i) & 0xFF)];
+        const int idx = T.perm[(int)((h0 + ysb + j) & 0xFF)] & 0x0E;
+        attn *= attn;
+        r = attn * attn * (T.grad[idx] * dx + T.grad[idx + 1] * dy);
+    }
+    return r;
+}
+
+__device__ double noise2(const Tables2 &T, double x, double y)
+{
+    const double stretch = (x + y) * STRETCH2;
+    const double xs = x + stretch, ys = y + stretch;
+    const double fx = floor(xs), fy = floor(ys);
+    const long long xsb = (long long)fx, ysb = (long long)fy;
+    const double squish = (double)(xsb + ysb) * SQUISH2;
+    const double xins = xs - fx, yins = ys - fy;
+    const double in_sum = xins + yins;
+    const double dx0 = x - (fx + squish), dy0 = y - (fy + squish);
+    double value = 0.0;
+    value += term2(T, xsb, ysb, dx0, dy0, 1, 0);
+    value += term2(T, xsb, ysb, dx0, dy0, 0, 1);
+    int bi, bj, ei, ej;
+    if (in_sum <= 1) {
+        const double zins = 1 - in_sum;
+        bi = 0; bj = 0;
+        if (zins > xins || zins > yins) {
+            if (xins > yins) { ei = 1; ej = -1; } else { ei = -1; ej = 1; }
+        } else { ei = 1; ej = 1; }
+    } else {
+        const double zins = 2 - in_sum;
+        bi = 1; bj = 1;
+        if (zins < xins || zins < yins) {
+            if (xins > yins) { ei = 2; ej = 0; } else { ei = 0; ej = 2; }
+        } else { ei = 0; ej = 0; }
+    }
+    value += term2(T, xsb, ysb, dx0, dy0, bi, bj);
+    value += term2(T, xsb, ysb, dx0, dy0, ei, ej);
+    return value / NORM2;
+}
+
+__device__ __forceinline__ void load_tables2(Tables2 &T, const int16_t *tables)
+{
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) T.perm[i] = (unsigned char)tables[i];
+    if (threadIdx.x < 16) T.grad[threadIdx.x] = (double)kGrad2[threadIdx.x];
+    __syncthreads();
+}
+
+// X == nullptr: octave mode, out[i][j] = sum_o p^o * noise2(j / f_o, i / f_o)   (rand_2d_octaves on an n x n field)
+// X != nullptr: grid mode,   out[i][j] = noise2(X[j], Y[i])                      (_noise2a on a square grid)
+__global__ __launch_bounds__(256) void simplex2_kernel(double *out, const double *X, const double *Y, int n,
+                                                       const int16_t *tables, int octaves, double persistence, double frequency)
+{
+    __shared__ Tables2 T;
+    load_tables2(T, tables);
+    const long long total = (long long)n * n;
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < total; k += (long long)gridDim.x * 256) {
+        const int i = (int)(k / n), j = (int)(k % n);
+        if (X) {
+            out[k] = noise2(T, X[j], Y[i]);
+        } else {
+            double acc = 0.0, amp = 1.0, f = frequency;
+            for (int o = 0; o < octaves; ++o) {
+                acc = acc + amp * noise2(T, (double)j / f, (double)i / f);
+                f = f / 2;
+                amp = amp * persistence;
+            }
+            out[k] = acc;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int anoddpm_simplex3_grid_f64(double *out, const double *X, int32_t nx, const double *Y, int32_t ny,
@@ -282,4 +375,29 @@ extern "C" int anoddpm_simplex3_octaves_f64(const anoddpm_simplex_args *a, void 
 extern "C" int anoddpm_simplex3_octaves_f32(const anoddpm_simplex_args *a, void *stream)
 {
     return launch_simplex<float>(a, stream);
+}
+
+static int launch_simplex2(double *out, const double *X, const double *Y, int32_t n, const int16_t *tables, int32_t octaves,
+                           double persistence, double frequency, void *stream, const char *what)
+{
+    ANODDPM_REQUIRE(n >= 0 && octaves >= 0, "simplex2: negative size");
+    if (n == 0) return ANODDPM_OK;
+    ANODDPM_REQUIRE(out && tables, "simplex2: null pointer");
+    const long long blocks = ((long long)n * n + 255) / 256;
+    hipLaunchKernelGGL(simplex2_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0,
+                       anoddpm::as_stream(stream), out, X, Y, n, tables, octaves, persistence, frequency);
+    return anoddpm::check_launch(what);
+}
+
+extern "C" int anoddpm_simplex2_octaves_f64(double *out, int32_t n, const int16_t *tables, int32_t octaves,
+                                            double persistence, double frequency, void *stream)
+{
+    return launch_simplex2(out, nullptr, nullptr, n, tables, octaves, persistence, frequency, stream, "simplex2_octaves");
+}
+
+extern "C" int anoddpm_simplex2_grid_f64(double *out, const double *X, const double *Y, int32_t n, const int16_t *tables,
+                                         void *stream)
+{
+    ANODDPM_REQUIRE(n == 0 || (X && Y), "simplex2_grid: null coordinate vector");
+    return launch_simplex2(out, X, Y, n, tables, 0, 0.0, 1.0, stream, "simplex2_grid");
 }

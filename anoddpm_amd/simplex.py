@@ -151,10 +151,35 @@ class Simplex_CLASS:
         T = np.atleast_1d(np.asarray(T))
         return self._octaves_f64(T, 0, T.size, int(shape[0]), int(shape[1]), octaves, persistence, frequency)
 
-    # ------------------------------------------------------------------ 2-D path: not on the hot path
-    def _no_2d(self, *a, **k):
-        raise NotImplementedError(
-            "2-D OpenSimplex (simplex.py:211-318, 56-73) is dead code on the reference's hot path "
-            "(its call sites are commented out, GaussianDiffusion.py:115-118,127-130); SURVEY 8f rank 4")
+    # ------------------------------------------------------------------ reference API (2-D path)
+    # Dead code on the reference's hot path (its call sites are commented out, GaussianDiffusion.py:115-118,127-130)
+    # but part of Simplex_CLASS's surface (simplex.py:25-29, 56-73).  Upstream's _noise2a / rand_2d_octaves are
+    # only well defined for SQUARE grids (simplex.py:315-318 indexes noise[i * y.size + j]; :69 adds a (W,H) array to
+    # a (H,W) field, which numpy rejects), so non-square requests raise ValueError here too.
+    def noise2(self, x, y):
+        return self.noise2array(np.array([x], dtype=np.float64), np.array([y], dtype=np.float64))[0, 0]
 
-    noise2 = noise2array = rand_2d_octaves = _no_2d
+    def noise2array(self, x, y):
+        dev = _device()
+        X = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64).reshape(-1)).to(dev)
+        Y = torch.from_numpy(np.ascontiguousarray(y, dtype=np.float64).reshape(-1)).to(dev)
+        if X.numel() != Y.numel():
+            raise ValueError("noise2array: upstream's flat indexing (simplex.py:315-318) is only defined for square grids")
+        n = X.numel()
+        out = torch.empty((n, n), dtype=torch.float64, device=dev)
+        check(lib().anoddpm_simplex2_grid_f64(ptr(out), ptr(X), ptr(Y), n, ptr(self.device_tables(dev)), current_stream()),
+              "simplex2_grid_f64")
+        return out.cpu().numpy()
+
+    def rand_2d_octaves(self, shape, octaves=1, persistence=0.5, frequency=32):
+        """Layered fractal noise over a (Y, X) index grid -> float64[Y, X] (simplex.py:56-73)."""
+        assert len(shape) == 2
+        if int(shape[0]) != int(shape[1]):
+            raise ValueError("operands could not be broadcast together: upstream adds a "
+                             f"({shape[1]},{shape[0]}) array to a ({shape[0]},{shape[1]}) field (simplex.py:69)")
+        dev = _device()
+        n = int(shape[0])
+        out = torch.empty((n, n), dtype=torch.float64, device=dev)
+        check(lib().anoddpm_simplex2_octaves_f64(ptr(out), n, ptr(self.device_tables(dev)), int(octaves),
+                                                 float(persistence), float(frequency), current_stream()), "simplex2_octaves_f64")
+        return out.cpu().numpy()

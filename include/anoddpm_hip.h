@@ -78,6 +78,16 @@ int anoddpm_simplex3_octaves_f32(const anoddpm_simplex_args *a, void *stream);
 int anoddpm_simplex3_grid_f64(double *out, const double *X, int32_t nx, const double *Y, int32_t ny,
                               const double *Z, int32_t nz, const int16_t *tables, void *stream);
 
+/* 2-D OpenSimplex on a SQUARE n x n grid (upstream's _noise2a / rand_2d_octaves are only well defined for square
+ * shapes: simplex.py:315-318 indexes noise[i * y.size + j], :69 adds a (W,H) array to a (H,W) field).
+ *   octaves: out[i][j] = sum_o persistence^o * noise2(j / f_o, i / f_o), f_o = frequency / 2^o   (simplex.py:56-73)
+ *   grid:    out[i][j] = noise2(X[j], Y[i])                                                       (simplex.py:311-318)
+ * tables: the int16[512] table of anoddpm_simplex_perm_init (only perm[256] is used).  Bit-exact fp64. */
+int anoddpm_simplex2_octaves_f64(double *out, int32_t n, const int16_t *tables, int32_t octaves,
+                                 double persistence, double frequency, void *stream);
+int anoddpm_simplex2_grid_f64(double *out, const double *X, const double *Y, int32_t n, const int16_t *tables,
+                              void *stream);
+
 /* ------------------------------------------------------------------ diffusion ---------- */
 
 /* GaussianDiffusion.py:361-371 (sample_q) and :373-382 (sample_q_gradual):

@@ -257,3 +257,86 @@ void oracle_octaves(const int64_t *zvals, int64_t nz, int64_t height, int64_t wi
         amplitude *= persistence;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * 2-D OpenSimplex (simplex.py:194-199 _extrapolate2, :211-308 _noise2, :311-318 _noise2a,
+ * :56-73 rand_2d_octaves).  Same formulation as the 3-D restatement: a contributing vertex is
+ * its lattice offset (i, j); its displacement is (d0 - i) - n*SQUISH2 with n the number of
+ * squish units the reference subtracts for that vertex (i + j; 0 for the (1,-1) / (-1,1)
+ * extras, simplex.py:262-271).  Order of accumulation: (1,0), (0,1), base vertex, extra vertex.
+ */
+#define STRETCH2 (-0.211324865405187)   /* simplex.py:154 */
+#define SQUISH2  (0.366025403784439)    /* simplex.py:155 */
+#define NORM2    47.0                   /* simplex.py:161 */
+
+static const double GRAD2[16] = {5, 2, 2, 5, -5, 2, -2, 5, 5, -2, 2, -5, -5, -2, -2, -5};   /* :103-111 */
+
+static inline double term2(const int64_t *perm, int64_t xsb, int64_t ysb, double dx0, double dy0, int i, int j)
+{
+    const double sq = (double)(i + j) * SQUISH2;
+    const double dx = (dx0 - (double)i) - sq;
+    const double dy = (dy0 - (double)j) - sq;
+    double attn = 2 - dx * dx - dy * dy;
+    if (!(attn > 0)) return 0.0;
+    const int64_t idx = perm[(perm[(xsb + i) & 0xFF] + (ysb + j)) & 0xFF] & 0x0E;
+    attn *= attn;
+    return attn * attn * (GRAD2[idx] * dx + GRAD2[idx + 1] * dy);
+}
+
+double oracle_noise2(double x, double y, const int64_t *perm)
+{
+    const double stretch = (x + y) * STRETCH2;
+    const double xs = x + stretch, ys = y + stretch;
+    const double fx = floor(xs), fy = floor(ys);
+    const int64_t xsb = (int64_t)fx, ysb = (int64_t)fy;
+    const double squish = (double)(xsb + ysb) * SQUISH2;
+    const double xins = xs - fx, yins = ys - fy;
+    const double in_sum = xins + yins;
+    const double dx0 = x - (fx + squish), dy0 = y - (fy + squish);
+
+    double value = 0.0;
+    value += term2(perm, xsb, ysb, dx0, dy0, 1, 0);
+    value += term2(perm, xsb, ysb, dx0, dy0, 0, 1);
+    int bi, bj, ei, ej;                       /* base and extra vertex */
+    if (in_sum <= 1) {                        /* triangle at (0,0), simplex.py:260-277 */
+        const double zins = 1 - in_sum;
+        bi = 0; bj = 0;
+        if (zins > xins || zins > yins) {
+            if (xins > yins) { ei = 1; ej = -1; } else { ei = -1; ej = 1; }
+        } else { ei = 1; ej = 1; }
+    } else {                                  /* triangle at (1,1), simplex.py:278-297 */
+        const double zins = 2 - in_sum;
+        bi = 1; bj = 1;
+        if (zins < xins || zins < yins) {
+            if (xins > yins) { ei = 2; ej = 0; } else { ei = 0; ej = 2; }
+        } else { ei = 0; ej = 0; }
+    }
+    value += term2(perm, xsb, ysb, dx0, dy0, bi, bj);
+    value += term2(perm, xsb, ysb, dx0, dy0, ei, ej);
+    return value / NORM2;
+}
+
+/* simplex.py:311-318 for SQUARE grids (n x n): out[i][j] = noise2(X[j], Y[i]). */
+void oracle_noise2_grid(const double *X, const double *Y, int64_t n, const int64_t *perm, double *out)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < n; ++j)
+            out[i * n + j] = oracle_noise2(X[j], Y[i], perm);
+}
+
+/* simplex.py:56-73 for square shapes: noise[i][j] += amplitude * noise2(j / f, i / f). */
+void oracle_octaves2(int64_t n, int octaves, double persistence, double frequency, const int64_t *perm, double *out)
+{
+    for (int64_t k = 0; k < n * n; ++k) out[k] = 0.0;
+    double amplitude = 1.0;
+    for (int o = 0; o < octaves; ++o) {
+        const double f = frequency, a = amplitude;
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t j = 0; j < n; ++j)
+                out[i * n + j] = out[i * n + j] + a * oracle_noise2((double)j / f, (double)i / f, perm);
+        frequency /= 2;
+        amplitude *= persistence;
+    }
+}

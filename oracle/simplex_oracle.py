@@ -39,6 +39,12 @@ def lib():
         L.oracle_octaves.argtypes = [i64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                      ctypes.c_int, ctypes.c_double, ctypes.c_double, i64p, i64p, f64p]
         L.oracle_octaves.restype = None
+        L.oracle_noise2.argtypes = [ctypes.c_double, ctypes.c_double, i64p]
+        L.oracle_noise2.restype = ctypes.c_double
+        L.oracle_noise2_grid.argtypes = [f64p, f64p, ctypes.c_int64, i64p, f64p]
+        L.oracle_noise2_grid.restype = None
+        L.oracle_octaves2.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_double, i64p, f64p]
+        L.oracle_octaves2.restype = None
         _lib = L
     return _lib
 
@@ -97,3 +103,27 @@ class OracleSimplex:
     def rand_3d_fixed_T_octaves(self, shape, T, octaves=1, persistence=0.5, frequency=32):
         assert len(shape) == 2
         return self._octaves(np.atleast_1d(T), shape[0], shape[1], octaves, persistence, frequency)
+
+    # ---- 2-D (simplex.py:25-29, 56-73, 211-318)
+    def noise2(self, x, y):
+        return lib().oracle_noise2(float(x), float(y), _p(self._perm, ctypes.c_int64))
+
+    def noise2array(self, x, y):
+        X = np.ascontiguousarray(x, dtype=np.float64)
+        Y = np.ascontiguousarray(y, dtype=np.float64)
+        if X.size != Y.size:
+            raise ValueError("upstream's _noise2a indexes noise[i * y.size + j] and reshapes to (x.size, y.size): "
+                             "only square grids are well defined")
+        out = np.empty((Y.size, X.size), dtype=np.float64)
+        lib().oracle_noise2_grid(_p(X, ctypes.c_double), _p(Y, ctypes.c_double), X.size,
+                                 _p(self._perm, ctypes.c_int64), _p(out, ctypes.c_double))
+        return out
+
+    def rand_2d_octaves(self, shape, octaves=1, persistence=0.5, frequency=32):
+        assert len(shape) == 2
+        if shape[0] != shape[1]:
+            raise ValueError("upstream adds a (W,H) array to a (H,W) field: only square shapes work")
+        out = np.empty(tuple(shape), dtype=np.float64)
+        lib().oracle_octaves2(shape[0], int(octaves), float(persistence), float(frequency),
+                              _p(self._perm, ctypes.c_int64), _p(out, ctypes.c_double))
+        return out

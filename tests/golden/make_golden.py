@@ -9,6 +9,7 @@ recipe from SURVEY.md 8c).  Outputs are DATA (inputs + expected outputs), never 
     diffusion_kat.npz    schedule tables (linear/cosine), sample_q / p_mean_variance / sample_p
     unet_<name>.npz      UNetModel.forward outputs (+ per-block activation probes)
     metrics_kat.npz      evaluation.py metrics + the mean / mse / threshold images of detection_A/B
+    simplex2_kat.npz     2-D noise2 point KATs (bit patterns), a coordinate grid, octave fields
     vlb_kat.npz          calc_vlb_xt (KL and decoder-NLL branches) and the MSE curves of calc_total_vlb
 """
 import os
@@ -300,8 +301,27 @@ def gen_vlb():
     print("vlb_kat.npz:", len(out), "arrays")
 
 
+def gen_simplex2():
+    """2-D OpenSimplex (simplex.py:211-318, 56-73): point values as bit patterns, a coordinate grid, octave fields."""
+    out = {}
+    rng = np.random.RandomState(202)
+    pts = np.concatenate([rng.uniform(-40, 40, (1500, 2)), rng.uniform(-2, 2, (500, 2)),
+                          np.array([[0, 0], [0.5, 0.5], [1, 1], [-1.25, 3.5], [510.0, 510.0], [1e-9, -1e-9]])])
+    out["points"] = pts
+    for seed in (3, 12345, -9999999999):
+        s = ref_simplex.Simplex_CLASS()
+        s.newSeed(seed)
+        out[f"s{seed}_values"] = np.array([s.noise2(x, y) for x, y in pts], dtype=np.float64)
+        out[f"s{seed}_grid"] = s.noise2array(np.arange(12) / 3.0 - 1.0, np.arange(12) / 5.0 + 0.25)
+        out[f"s{seed}_oct_32_4_07_16"] = s.rand_2d_octaves((32, 32), 4, 0.7, 16)
+        out[f"s{seed}_oct_64_6_08_64"] = s.rand_2d_octaves((64, 64), 6, 0.8, 64)
+    out["grid_x"], out["grid_y"] = np.arange(12) / 3.0 - 1.0, np.arange(12) / 5.0 + 0.25
+    np.savez_compressed(os.path.join(HERE, "simplex2_kat.npz"), **out)
+    print("simplex2_kat.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["simplex", "diffusion", "unet", "metrics", "vlb"]
+    which = sys.argv[1:] or ["simplex", "diffusion", "unet", "metrics", "vlb", "simplex2"]
     torch.set_num_threads(8)
     if "simplex" in which:
         gen_simplex()
@@ -315,3 +335,5 @@ if __name__ == "__main__":
         gen_metrics()
     if "vlb" in which:
         gen_vlb()
+    if "simplex2" in which:
+        gen_simplex2()

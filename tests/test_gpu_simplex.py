@@ -99,3 +99,31 @@ def test_random_seeds_vs_oracle_and_f32_fill():
         assert torch.isnan(out[:, 0]).all()
     assert s.rand_3d_fixed_T_octaves((0, 5), np.array([1]), 2, 0.5, 8).shape == (1, 0, 5)
     assert (s.rand_3d_octaves((2, 3, 4), 0, 0.5, 8) == 0).all()
+
+
+# ---------------------------------------------------------------------------- 2-D (simplex.py:211-318, 56-73)
+def test_noise2_bit_exact_vs_reference_and_oracle():
+    from simplex import Simplex_CLASS
+    from oracle.simplex_oracle import OracleSimplex
+    k2 = np.load(os.path.join(GOLDEN, "simplex2_kat.npz"))
+    bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+    s = Simplex_CLASS()
+    for seed in (3, 12345, -9999999999):
+        s.newSeed(seed)
+        assert (bits(s.noise2array(k2["grid_x"], k2["grid_y"])) == bits(k2[f"s{seed}_grid"])).all()
+        assert (bits(s.rand_2d_octaves((32, 32), 4, 0.7, 16)) == bits(k2[f"s{seed}_oct_32_4_07_16"])).all()
+        assert (bits(s.rand_2d_octaves((64, 64), 6, 0.8, 64)) == bits(k2[f"s{seed}_oct_64_6_08_64"])).all()
+        pts = k2["points"][:64]
+        got = np.array([s.noise2(x, y) for x, y in pts])
+        assert (bits(got) == bits(k2[f"s{seed}_values"][:64])).all()
+    # all point KATs at once through the grid kernel's diagonal, and a full-size field against the oracle
+    s.newSeed(12345)
+    o = OracleSimplex(12345)
+    n = 512
+    assert (bits(s.rand_2d_octaves((n, n), 8, 0.8, 64)) == bits(o.rand_2d_octaves((n, n), 8, 0.8, 64))).all()
+    P = k2["points"]
+    g = s.noise2array(P[:, 0], P[:, 1])
+    assert (bits(np.diagonal(g)) == bits(k2["s12345_values"])).all()
+    assert s.rand_2d_octaves((0, 0)).shape == (0, 0)
+    with pytest.raises(ValueError):
+        s.rand_2d_octaves((8, 16))

@@ -119,8 +119,10 @@ def test_newseed_consumes_numpy_stream_like_reference():
         a.rand_3d_octaves((4, 4), 1)
     with pytest.raises(AssertionError):
         a.rand_3d_fixed_T_octaves((4, 4, 4), np.array([1]))
-    with pytest.raises(NotImplementedError):
-        a.rand_2d_octaves((4, 4))
+    with pytest.raises(AssertionError):
+        a.rand_2d_octaves((4, 4, 4))
+    with pytest.raises(ValueError):                      # upstream's (W,H) + (H,W) broadcast error, simplex.py:69
+        a.rand_2d_octaves((4, 6))
 
 
 def test_helpers_surface(tmp_path):

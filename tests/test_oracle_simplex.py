@@ -96,3 +96,27 @@ def test_live_reference_crosscheck():
     rng = np.random.RandomState(1)
     for p in rng.uniform(-9, 9, (500, 3)):
         assert bits(R.noise3(*p)) == bits(O.noise3(*p))
+
+
+# ---------------------------------------------------------------------------- 2-D (simplex.py:211-318, 56-73)
+@pytest.fixture(scope="module")
+def kat2():
+    return np.load(os.path.join(GOLDEN, "simplex2_kat.npz"))
+
+
+@pytest.mark.parametrize("seed", [3, 12345, -9999999999])
+def test_noise2_bit_exact(kat2, seed):
+    s = OracleSimplex(seed)
+    got = np.array([s.noise2(x, y) for x, y in kat2["points"]])
+    assert (bits(got) == bits(kat2[f"s{seed}_values"])).all()
+    assert (bits(s.noise2array(kat2["grid_x"], kat2["grid_y"])) == bits(kat2[f"s{seed}_grid"])).all()
+    assert (bits(s.rand_2d_octaves((32, 32), 4, 0.7, 16)) == bits(kat2[f"s{seed}_oct_32_4_07_16"])).all()
+    assert (bits(s.rand_2d_octaves((64, 64), 6, 0.8, 64)) == bits(kat2[f"s{seed}_oct_64_6_08_64"])).all()
+
+
+def test_noise2_square_only():
+    s = OracleSimplex(3)
+    with pytest.raises(ValueError):
+        s.rand_2d_octaves((4, 6))
+    with pytest.raises(ValueError):
+        s.noise2array(np.arange(3.0), np.arange(4.0))
