@@ -39,7 +39,7 @@ CONFIGS = {
                name="64x64 base64 batch1 (BASELINE config 1 shape, on GPU)"),
 }
 T_STEPS = 1000
-MEASURED_TRAFFIC_BYTES_PER_LAUNCH = 1.135e8      # profiles/r1e_pmc_hbm_by_kernel.csv, config c2 batch 4
+MEASURED_TRAFFIC_BYTES_PER_LAUNCH = 2.105e8      # wino_kernel, profiles/r1e_pmc_hbm_by_kernel.csv, config c2 batch 4
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
@@ -201,30 +201,47 @@ def main():
         cnt = (ctypes.c_int64 * 16)()
         _lib.check(L.anoddpm_prof_collect(ms, cnt), "prof_collect")
         L.anoddpm_prof_enable(0)
-        ig_ms, ig_n = ms[_lib.OP_IGEMM], cnt[_lib.OP_IGEMM]
-        flops_per_step = plan.igemm_flops                      # algorithmic (direct-convolution) FLOPs of all launches
-        achieved = flops_per_step * args.steps / (ig_ms / 1000.0) / 1e12 if ig_ms > 0 else 0.0
-        # FLOPs the matrix pipe actually executes: Winograd F(2x2,3x3) layers issue 4/9 of the direct count
-        exec_flops = sum(e["gflop"] * (4.0 / 9.0 if e["wino"] else 1.0) for e in plan.igemm_log) * 1e9
-        executed = exec_flops * args.steps / (ig_ms / 1000.0) / 1e12 if ig_ms > 0 else 0.0
+        WINO = 12                                              # profiler slot of the Winograd launches
+        w_ms, w_n = ms[WINO], cnt[WINO]
+        d_ms, d_n = ms[_lib.OP_IGEMM], cnt[_lib.OP_IGEMM]      # direct implicit-GEMM launches (1x1, small maps, attention)
+        ig_ms, ig_n = w_ms + d_ms, w_n + d_n
+        w_flops = sum(e["gflop"] for e in plan.igemm_log if e["wino"]) * 1e9      # algorithmic (direct-convolution) FLOPs
+        d_flops = sum(e["gflop"] for e in plan.igemm_log if not e["wino"]) * 1e9
+        flops_per_step = plan.igemm_flops
+
+        def tf(flops, msec):
+            return flops * args.steps / (msec / 1000.0) / 1e12 if msec > 0 else 0.0
+        # dominant kernel = wino_kernel when the plan uses it, else the direct kernel
+        dom_wino = w_ms >= d_ms
+        achieved = tf(w_flops, w_ms) if dom_wino else tf(d_flops, d_ms)
+        # FLOPs the matrix pipe actually executes: Winograd F(2x2,3x3) issues 4/9 of the direct count
+        executed = tf(w_flops * 4.0 / 9.0, w_ms) if dom_wino else achieved
         roofline = {"bound": "mfma",
-                    "kernel": "anoddpm_igemm launches: wino_kernel (Winograd F(2x2,3x3)) + igemm_kernel (direct conv / 1x1 / attention), v_mfma_f32_32x32x2_f32",
+                    "kernel": ("wino_kernel (Winograd F(2x2,3x3) 3x3 convolutions, v_mfma_f32_32x32x2_f32)" if dom_wino else
+                               "igemm_kernel (direct implicit-GEMM convolution, v_mfma_f32_32x32x2_f32)"),
                     "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
                     # HBM-side bytes per launch from the committed PMC passes (not collectable from inside this
-                    # process): (2*FETCH_SIZE + WRITE_SIZE) KB averaged over the launches of one step, with the
+                    # process): (2*FETCH_SIZE + WRITE_SIZE) KB averaged over the kernel's 63 launches per step, with the
                     # guide's gfx950 FETCH_SIZE x2 correction.  Only quoted for the workload it was measured on.
-                    "traffic": MEASURED_TRAFFIC_BYTES_PER_LAUNCH if (args.config == "c2" and B == 4) else None,
+                    "traffic": MEASURED_TRAFFIC_BYTES_PER_LAUNCH if (args.config == "c2" and B == 4 and dom_wino) else None,
                     "traffic_source": "profiles/r1e_pmc_hbm_by_kernel.csv",
-                    "achieved_is": "ALGORITHMIC direct-convolution FLOPs / HIP-event time of the launches (can exceed the executed rate: Winograd does 2.25x fewer multiplies)",
+                    "achieved_is": "ALGORITHMIC direct-convolution FLOPs of the kernel's launches / their HIP-event time (exceeds the executed rate: Winograd does 2.25x fewer multiplies)",
                     "executed_tflops": executed, "executed_frac": executed / PEAK_FP32_MATRIX_TFLOPS,
-                    "winograd_share_of_algorithmic_flops": sum(e["gflop"] for e in plan.igemm_log if e["wino"]) * 1e9 / max(flops_per_step, 1.0),
-                    "launches_per_step": ig_n / args.steps, "avg_launch_ms": ig_ms / max(ig_n, 1),
-                    "algorithmic_gflop_per_step": flops_per_step / 1e9,
+                    "launches_per_step": (w_n if dom_wino else d_n) / args.steps,
+                    "avg_launch_ms": (w_ms / max(w_n, 1)) if dom_wino else (d_ms / max(d_n, 1)),
+                    "algorithmic_gflop_per_launch": ((w_flops / 1e9) / max(w_n / args.steps, 1)) if dom_wino else ((d_flops / 1e9) / max(d_n / args.steps, 1)),
+                    "share_of_model_flops": (w_flops if dom_wino else d_flops) / max(flops_per_step, 1.0),
+                    "other_contraction_kernel": {"kernel": "igemm_kernel (direct: 1x1, pool-fused and 8x8 3x3, qkv/proj, attention)" if dom_wino else "wino_kernel",
+                                                 "achieved": tf(d_flops, d_ms) if dom_wino else tf(w_flops, w_ms),
+                                                 "launches_per_step": (d_n if dom_wino else w_n) / args.steps,
+                                                 "ms_per_step": (d_ms if dom_wino else w_ms) / args.steps},
+                    "all_contractions": {"achieved": tf(flops_per_step, ig_ms), "executed_tflops": tf(w_flops * 4.0 / 9.0 + d_flops, ig_ms),
+                                         "ms_per_step": ig_ms / args.steps, "algorithmic_gflop_per_step": flops_per_step / 1e9},
                     "class_ms_per_step": {name: ms[code] / args.steps for name, code in
-                                          (("igemm", 1), ("gn_stats", 2), ("softmax", 3), ("resample", 4), ("linear", 5),
+                                          (("winograd", 12), ("igemm_direct", 1), ("gn_stats", 2), ("softmax", 3), ("resample", 4), ("linear", 5),
                                            ("posemb", 6), ("stem", 7), ("layout", 8), ("chan_stats", 9),
-                                           ("gn_finalize", 10))},
+                                           ("gn_finalize", 10), ("head", 11))},
                     "instrumented_ms_per_step": prof_ms_per_step}
 
     out = {
