@@ -32,7 +32,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WKC = 16;            // channels per K iteration
-constexpr int WBN = 64;            // output channels per workgroup
 
 
 __device__ __forceinline__ f32x4 wld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
@@ -56,16 +55,20 @@ constexpr int DPITCH = 5;          // float4 per patch pixel in LDS: 4 quads + 1
 // WMW = wave rows: a workgroup is 4*WMW waves on an (8*WMW) x 16 output patch.  WMW = 1 (256 threads) lets TWO independent
 // workgroups share a CU, so one's prologue / epilogue (patch latency, LDS exchange, stores: ~20 % of a K = 128
 // workgroup's life) overlaps the other's MFMA stream; WMW = 2 is the original 512-thread shape (smaller halo).
-template <bool FAST, int WMW, bool PROBE = false>
-__global__ __launch_bounds__(256 * WMW, 2) void wino_kernel(const anoddpm_igemm_args a)
+// WNW = wave columns: 32 * WNW output channels per workgroup.  WNW = 4 (all 128 channels of the common layers in one
+// 512-thread workgroup) activates each patch element once instead of once per 64-channel workgroup.
+template <bool FAST, int WMW, int WNW, bool PROBE = false>
+__global__ __launch_bounds__(128 * WMW * WNW, 2) void wino_kernel(const anoddpm_igemm_args a)
 {
     // PROBE (tools/wino_phases.py only): wave 0 records s_memtime at the phase boundaries into a.ws[block][8]
     unsigned long long tstamp[5];
     if (PROBE) tstamp[0] = __builtin_amdgcn_s_memtime();
-    constexpr int NT = 256 * WMW;                                  // threads
+    constexpr int NT = 128 * WMW * WNW;                            // threads: waves (xh 2) x (wm WMW) x (wn WNW)
+    constexpr int WBN = 32 * WNW;                                  // output channels per workgroup
     constexpr int PROWS = 8 * WMW + 2;                             // patch rows (18 columns)
     constexpr int WPATCH = PROWS * 18;                             // input patch pixels
-    constexpr int SLOTPX = 192 * WMW;                              // pixel slots per buffer (3 * NT / 4 >= WPATCH)
+    constexpr int PJ = (WPATCH * 4 + NT - 1) / NT;                 // staging slots per thread (3, or 2 for 512 threads on 8x16)
+    constexpr int SLOTPX = PJ * NT / 4;                            // pixel slots per buffer (>= WPATCH)
     // LDS: only the activated input patch, double buffered: Dt[2][SLOTPX pixel slots][5 float4]  (30 KB * WMW; WPATCH
     // pixels are real, the rest absorbs the unconditional stores of the last staging slot).
     // Neither V (transformed input) nor U (transformed weights) ever touch LDS:
@@ -74,18 +77,18 @@ __global__ __launch_bounds__(256 * WMW, 2) void wino_kernel(const anoddpm_igemm_
     //     one coalesced 16-byte load per operand) through a two-deep register ring.
     // One barrier per 16-channel iteration; the exchange buffer of the epilogue re-uses the same LDS.
     constexpr int DT_F4 = SLOTPX * DPITCH;                         // float4 per buffer
-    constexpr int EX_FLOATS = (2 * WMW) * 2 * 8 * 4 * 64;          // exchange buffer of the epilogue: 32 KB * WMW
+    constexpr int EX_FLOATS = (WMW * WNW) * 2 * 8 * 4 * 64;        // exchange buffer of the epilogue: 16 KB per wave pair
     __shared__ __attribute__((aligned(16))) float lds[EX_FLOATS];
     static_assert(2 * DT_F4 * 4 <= EX_FLOATS, "patch buffers must fit the exchange buffer");
-    static_assert(3 * NT >= WPATCH * 4 && 3 * NT <= SLOTPX * 4, "staging slots");
+    static_assert(PJ * NT >= WPATCH * 4 && PJ * NT <= SLOTPX * 4, "staging slots");
     f32x4 *ldsD = reinterpret_cast<f32x4 *>(lds);
 
     // 4*WMW waves: wave = (xh, wm, wn).  (wm, wn) picks the 32 tiles x 32 channels wave tile; xh picks which half of
     // the transform rows (u = 2*xh, 2*xh+1 -> 8 of the 16 positions) the wave accumulates: 128 accumulators.
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int xh = __builtin_amdgcn_readfirstlane(wave / (2 * WMW));
-    const int wm = (wave >> 1) & (WMW - 1), wn = wave & 1;
+    const int xh = __builtin_amdgcn_readfirstlane(wave / (WMW * WNW));
+    const int wm = (wave / WNW) & (WMW - 1), wn = wave & (WNW - 1);
     const int h = lane >> 5, l31 = lane & 31;
 
     const int H = a.H, W = a.W;
@@ -110,7 +113,6 @@ __global__ __launch_bounds__(256 * WMW, 2) void wino_kernel(const anoddpm_igemm_
     const int nchunks = cbeg + cps < nchunks_all ? cbeg + cps : nchunks_all;   // end of this block's chunk range
 
     // ---- patch staging: slots of this thread (pixel = idx>>2, quad = idx&3), geometry fixed for the workgroup
-    constexpr int PJ = 3;                                           // 3 * NT slots >= WPATCH pixels * 4 quads
     int spix[PJ];
     const int pq = tid & 3;
 #pragma unroll
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(256 * WMW, 2) void wino_kernel(const anoddpm_igemm_
     }
     // exchange buffer (re-uses the V region; the loop's last barrier has passed): ex[pair][writer xh][8 rows][4][64 lanes]
     float *ex = lds;
-    const int pair = wave & (2 * WMW - 1);
+    const int pair = wave & (WMW * WNW - 1);
     if (xh == 0) {
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {                            // rows 8..15 are finalised by the xh = 1 wave
@@ -387,22 +389,31 @@ int launch_winograd(const anoddpm_igemm_args *a, hipStream_t s)
     const int cps = (K / WKC + a->ksplit - 1) / a->ksplit;
     ANODDPM_REQUIRE((a->ksplit - 1) * cps < K / WKC, "winograd: ksplit leaves a block without channels");
     ANODDPM_REQUIRE(a->ksplit == 1 || !a->stats || a->stats_rows >= 1, "winograd: split-K statistics need stats_rows");
-    // 256-thread workgroups (two per CU) by default; ANODDPM_DEBUG0=1 selects the 512-thread shape
-    const int wmw = anoddpm::g_debug[0] == 1 ? 2 : 1;
-    dim3 grid((unsigned)((a->H / (8 * wmw)) * (a->W / 16)), (unsigned)((a->N + WBN - 1) / WBN), (unsigned)(a->B * a->ksplit));
+    // Workgroup shape: 8x16 output patch; all 128 channels in one 512-thread workgroup when N is a multiple of 128
+    // (each patch element is activated once), else 64 channels in a 256-thread workgroup (two per CU).
+    // ANODDPM_DEBUG0: 1 = the 16x16-patch 512-thread shape, 2 = force the 64-channel shape.
+    const int dbg = anoddpm::g_debug[0];
+    const int wmw = dbg == 1 ? 2 : 1;
+    const bool fast = a->gn_scale && a->act;
+    const bool probe = anoddpm::g_debug[1] == 1 && fast && a->ksplit == 1 && a->ws && wmw == 1;   // tools/wino_phases.py
+    const int wnw = (wmw == 1 && dbg != 2 && !probe && a->N % 128 == 0) ? 4 : 2;
+    const int wbn = 32 * wnw;
+    dim3 grid((unsigned)((a->H / (8 * wmw)) * (a->W / 16)), (unsigned)((a->N + wbn - 1) / wbn), (unsigned)(a->B * a->ksplit));
     ANODDPM_REQUIRE(grid.y <= 65535 && (int64_t)a->B * a->ksplit <= 65535, "winograd: grid too large");
     ANODDPM_REQUIRE((int64_t)16 * K * a->N * 4 < ((int64_t)1 << 31), "winograd: transformed weights exceed 32-bit buffer offsets");
     ANODDPM_REQUIRE((int64_t)a->H * a->W * (a->a0_ld > a->a1_ld ? a->a0_ld : a->a1_ld) * 4 < ((int64_t)1 << 31),
                     "winograd: operand slice exceeds 32-bit buffer offsets");
-    const bool fast = a->gn_scale && a->act;
     if (wmw == 2) {
-        if (fast) hipLaunchKernelGGL((wino_kernel<true, 2>), grid, dim3(512), 0, s, *a);
-        else      hipLaunchKernelGGL((wino_kernel<false, 2>), grid, dim3(512), 0, s, *a);
-    } else if (anoddpm::g_debug[1] == 1 && fast && a->ksplit == 1 && a->ws) {
-        hipLaunchKernelGGL((wino_kernel<true, 1, true>), grid, dim3(256), 0, s, *a);     // phase probe (tools/wino_phases.py)
+        if (fast) hipLaunchKernelGGL((wino_kernel<true, 2, 2>), grid, dim3(512), 0, s, *a);
+        else      hipLaunchKernelGGL((wino_kernel<false, 2, 2>), grid, dim3(512), 0, s, *a);
+    } else if (probe) {
+        hipLaunchKernelGGL((wino_kernel<true, 1, 2, true>), grid, dim3(256), 0, s, *a);
+    } else if (wnw == 4) {
+        if (fast) hipLaunchKernelGGL((wino_kernel<true, 1, 4>), grid, dim3(512), 0, s, *a);
+        else      hipLaunchKernelGGL((wino_kernel<false, 1, 4>), grid, dim3(512), 0, s, *a);
     } else {
-        if (fast) hipLaunchKernelGGL((wino_kernel<true, 1>), grid, dim3(256), 0, s, *a);
-        else      hipLaunchKernelGGL((wino_kernel<false, 1>), grid, dim3(256), 0, s, *a);
+        if (fast) hipLaunchKernelGGL((wino_kernel<true, 1, 2>), grid, dim3(256), 0, s, *a);
+        else      hipLaunchKernelGGL((wino_kernel<false, 1, 2>), grid, dim3(256), 0, s, *a);
     }
     return check_launch("winograd");
 }
