@@ -57,7 +57,11 @@ constexpr int DPITCH = 5;          // float4 per patch pixel in LDS: 4 quads + 1
 // workgroup's life) overlaps the other's MFMA stream; WMW = 2 is the original 512-thread shape (smaller halo).
 // WNW = wave columns: 32 * WNW output channels per workgroup.  WNW = 4 (all 128 channels of the common layers in one
 // 512-thread workgroup) activates each patch element once instead of once per 64-channel workgroup.
-template <bool FAST, int WMW, int WNW, bool PROBE = false>
+// VSH (needs WNW = 4): the input transform is computed ONCE per workgroup (512 quarter-items = one per thread) one
+// K iteration ahead and shared through a double-buffered LDS array V[pos][quad][tile]; the MFMA operands are then
+// plain ds_read_b128s.  Without it each of the four wn waves repeats the transform of the tiles it multiplies
+// (VALU issue is not hidden by the fp32 MFMA, so that repetition costs ~9 % of the loop).
+template <bool FAST, int WMW, int WNW, bool PROBE = false, bool VSH = false>
 __global__ __launch_bounds__(128 * WMW * WNW, 2) void wino_kernel(const anoddpm_igemm_args a)
 {
     // PROBE (tools/wino_phases.py only): wave 0 records s_memtime at the phase boundaries into a.ws[block][8]
@@ -78,8 +82,10 @@ __global__ __launch_bounds__(128 * WMW * WNW, 2) void wino_kernel(const anoddpm_
     // One barrier per 16-channel iteration; the exchange buffer of the epilogue re-uses the same LDS.
     constexpr int DT_F4 = SLOTPX * DPITCH;                         // float4 per buffer
     constexpr int EX_FLOATS = (WMW * WNW) * 2 * 8 * 4 * 64;        // exchange buffer of the epilogue: 16 KB per wave pair
-    __shared__ __attribute__((aligned(16))) float lds[EX_FLOATS];
-    static_assert(2 * DT_F4 * 4 <= EX_FLOATS, "patch buffers must fit the exchange buffer");
+    constexpr int V_F4 = 16 * 4 * 32;                              // VSH: V[16 positions][4 quads][32 tiles] float4 = 32 KB
+    constexpr int LDS_FLOATS = VSH ? (2 * DT_F4 + 2 * V_F4) * 4 : EX_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    static_assert(VSH ? (EX_FLOATS <= LDS_FLOATS && WNW == 4 && WMW == 1) : (2 * DT_F4 * 4 <= EX_FLOATS), "LDS layout");
     static_assert(PJ * NT >= WPATCH * 4 && PJ * NT <= SLOTPX * 4, "staging slots");
     f32x4 *ldsD = reinterpret_cast<f32x4 *>(lds);
 
@@ -218,57 +224,137 @@ __global__ __launch_bounds__(128 * WMW * WNW, 2) void wino_kernel(const anoddpm_
     };
 
     const int last = nchunks - 1;
-    load_patch(cbeg);
-    store_patch(cbeg & 1);
-    load_patch(cbeg < last ? cbeg + 1 : last);
-    load_b(cbeg, 0, 0, 0);
-    load_b(cbeg, 0, 1, 1);
-    __syncthreads();
-    issue_reads(cbeg & 1, 0, 0, 0);
-    issue_reads(cbeg & 1, 0, 0, 1);
-    make_av(0);
-    if (PROBE) tstamp[1] = __builtin_amdgcn_s_memtime();
-    for (int chunk = cbeg; chunk < nchunks; ++chunk) {
-        const int nxt = chunk < last ? chunk + 1 : last;            // clamped: the tail re-loads valid memory, unused
-        const int nxt2 = chunk + 2 < nchunks ? chunk + 2 : last;
+    if constexpr (VSH) {
+        f32x4 *ldsV = ldsD + 2 * DT_F4;
+        // transform role of this thread: quarter-item (tile, quad, row u) of B^T d B -> 4 positions (u, v = 0..3)
+        const int ttile = tid & 31, tquad = (tid >> 5) & 3;
+        const int urow = __builtin_amdgcn_readfirstlane(tid >> 7);              // waves 2u, 2u+1
+        const int trX = urow == 0 ? 0 : (urow == 2 ? 2 : 1);                    // u: 0: d0-d2  1: d1+d2  2: d2-d1  3: d1-d3
+        const int trY = urow == 0 ? 2 : (urow == 1 ? 2 : (urow == 2 ? 1 : 3));
+        const float tsg = urow == 1 ? 1.f : -1.f;
+        const int tbase = ((2 * (ttile >> 3)) * 18 + 2 * (ttile & 7)) * DPITCH + tquad;
+        const int tX = tbase + trX * 18 * DPITCH, tY = tbase + trY * 18 * DPITCH;
+        const int vw = ((urow * 4) * 4 + tquad) * 32 + ttile;                   // + v * 128 float4 per position
+        f32x4 tX4[4], tY4[4];
+        auto t_reads = [&](int buf) {
+            const f32x4 *D = ldsD + buf * DT_F4;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int uu = g4 & 1;
-            // The next group's two patch rows are requested ahead of / in the middle of this group's MFMAs (the second
-            // row lands in registers the first half of the burst has released).  Group 3 reads the NEXT chunk's
-            // buffer: its stores were made during this iteration; the barrier publishes them and also retires
-            // every read of the buffer that iteration chunk+1 overwrites.
-            if (g4 == 3) __syncthreads();
-            const int rbuf = g4 < 3 ? (chunk & 1) : ((chunk + 1) & 1);
-            const int rkg = g4 < 3 ? (g4 + 1) >> 1 : 0, ruu = (g4 + 1) & 1;
-            issue_reads(rbuf, rkg, ruu, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 4; ++j) { tX4[j] = D[tX + j * DPITCH]; tY4[j] = D[tY + j * DPITCH]; }
+        };
+        auto t_write = [&](int vbuf) {
+            f32x4 t[4];
 #pragma unroll
-            for (int v = 0; v < 2; ++v)
+            for (int j = 0; j < 4; ++j) t[j] = tX4[j] + tsg * tY4[j];
+            f32x4 *V = ldsV + vbuf * V_F4 + vw;
+            V[0 * 128] = t[0] - t[2];
+            V[1 * 128] = t[1] + t[2];
+            V[2 * 128] = t[2] - t[1];
+            V[3 * 128] = t[1] - t[3];
+        };
+        // MFMA operands: A fragment of group (kg, uu): V[pos = (2xh+uu)*4 + v][quad = 2kg + h][tile = l31]
+        const int vr = ((xh * 8) * 4 + h) * 32 + l31;
+        f32x4 af[2][4];
+        auto a_reads = [&](int vbuf, int kg, int uu, int set) {
+            const f32x4 *V = ldsV + vbuf * V_F4 + vr + ((uu * 4) * 4 + 2 * kg) * 32;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    acc[uu * 4 + v] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v][kk], bvr[uu][v][kk], acc[uu * 4 + v], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            issue_reads(rbuf, rkg, ruu, 1);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int v = 0; v < 4; ++v) af[set][v] = V[v * 128];
+        };
+        // prologue: patch(cbeg) -> LDS, V(cbeg), patch(cbeg+1) -> LDS, patch(cbeg+2) in flight
+        const int c1 = cbeg < last ? cbeg + 1 : last, c2 = cbeg + 2 < nchunks ? cbeg + 2 : last;
+        load_patch(cbeg);
+        store_patch(cbeg & 1);
+        load_patch(c1);
+        load_b(cbeg, 0, 0, 0);
+        load_b(cbeg, 0, 1, 1);
+        __syncthreads();
+        t_reads(cbeg & 1);
+        store_patch((cbeg + 1) & 1);
+        load_patch(c2);
+        t_write(cbeg & 1);
+        __syncthreads();
+        a_reads(cbeg & 1, 0, 0, 0);
+        if (PROBE) tstamp[1] = __builtin_amdgcn_s_memtime();
+        for (int chunk = cbeg; chunk < nchunks; ++chunk) {
+            const int nxt = chunk < last ? chunk + 1 : last;        // clamped: the tail re-loads valid memory, unused
+            const int nxt3 = chunk + 3 < nchunks ? chunk + 3 : last;
 #pragma unroll
-            for (int v = 2; v < 4; ++v)
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int uu = g4 & 1, set = g4 & 1;
+                // One barrier per iteration, ahead of the last group: it publishes V(chunk+1) and patch(chunk+2), both
+                // written earlier in this iteration, and retires every read of the buffers iteration chunk+1 overwrites.
+                if (g4 == 3) __syncthreads();
+                if (g4 < 3) a_reads(chunk & 1, (g4 + 1) >> 1, (g4 + 1) & 1, set ^ 1);
+                else        a_reads((chunk + 1) & 1, 0, 0, set ^ 1);
+                if (g4 == 1) t_reads((chunk + 1) & 1);              // patch(chunk+1): stored last iteration
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    acc[uu * 4 + v] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v][kk], bvr[uu][v][kk], acc[uu * 4 + v], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // ring: the set just consumed is refilled with the operands of the group after next
-            if (g4 < 2) load_b(chunk, 1, uu, uu);
-            else        load_b(nxt, 0, uu, uu);
-            if (g4 == 0) {
-                // the next iteration's patch goes to the other buffer while this iteration's MFMAs are in flight
-                store_patch((chunk + 1) & 1);
-                load_patch(nxt2);
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        acc[uu * 4 + v] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][v][kk], bvr[uu][v][kk], acc[uu * 4 + v], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g4 < 2) load_b(chunk, 1, uu, uu);
+                else        load_b(nxt, 0, uu, uu);
+                // register budget: the staged patch (praw, asc, ash) lives across the bursts of groups 3 and 0, the raw
+                // transform rows across the burst of group 1 -- never both
+                if (g4 == 0) store_patch(chunk & 1);                // patch(chunk+2) replaces patch(chunk), consumed an iteration ago
+                if (g4 == 1) t_write((chunk + 1) & 1);              // V(chunk+1)
+                if (g4 == 2) load_patch(nxt3);
             }
-            make_av(ruu);
         }
-    }
+    } else {
+        load_patch(cbeg);
+        store_patch(cbeg & 1);
+        load_patch(cbeg < last ? cbeg + 1 : last);
+        load_b(cbeg, 0, 0, 0);
+        load_b(cbeg, 0, 1, 1);
+        __syncthreads();
+        issue_reads(cbeg & 1, 0, 0, 0);
+        issue_reads(cbeg & 1, 0, 0, 1);
+        make_av(0);
+        if (PROBE) tstamp[1] = __builtin_amdgcn_s_memtime();
+        for (int chunk = cbeg; chunk < nchunks; ++chunk) {
+            const int nxt = chunk < last ? chunk + 1 : last;            // clamped: the tail re-loads valid memory, unused
+            const int nxt2 = chunk + 2 < nchunks ? chunk + 2 : last;
+    #pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int uu = g4 & 1;
+                // The next group's two patch rows are requested ahead of / in the middle of this group's MFMAs (the second
+                // row lands in registers the first half of the burst has released).  Group 3 reads the NEXT chunk's
+                // buffer: its stores were made during this iteration; the barrier publishes them and also retires
+                // every read of the buffer that iteration chunk+1 overwrites.
+                if (g4 == 3) __syncthreads();
+                const int rbuf = g4 < 3 ? (chunk & 1) : ((chunk + 1) & 1);
+                const int rkg = g4 < 3 ? (g4 + 1) >> 1 : 0, ruu = (g4 + 1) & 1;
+                issue_reads(rbuf, rkg, ruu, 0);
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int v = 0; v < 2; ++v)
+    #pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        acc[uu * 4 + v] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v][kk], bvr[uu][v][kk], acc[uu * 4 + v], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_reads(rbuf, rkg, ruu, 1);
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int v = 2; v < 4; ++v)
+    #pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        acc[uu * 4 + v] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[v][kk], bvr[uu][v][kk], acc[uu * 4 + v], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // ring: the set just consumed is refilled with the operands of the group after next
+                if (g4 < 2) load_b(chunk, 1, uu, uu);
+                else        load_b(nxt, 0, uu, uu);
+                if (g4 == 0) {
+                    // the next iteration's patch goes to the other buffer while this iteration's MFMAs are in flight
+                    store_patch((chunk + 1) & 1);
+                    load_patch(nxt2);
+                }
+                make_av(ruu);
+            }
+        }
 
+    }
     if (PROBE) tstamp[2] = __builtin_amdgcn_s_memtime();
     // ---- epilogue.  The output transform Y = A^T M A is linear in M, so each wave forms the PARTIAL 2x2 outputs
     // of its 8 positions (A^T = [[1,1,1,0],[0,1,-1,-1]]: rows u=0,1 give tm0 = M0+M1, tm1 = M1; rows u=2,3 give
@@ -391,7 +477,7 @@ int launch_winograd(const anoddpm_igemm_args *a, hipStream_t s)
     ANODDPM_REQUIRE(a->ksplit == 1 || !a->stats || a->stats_rows >= 1, "winograd: split-K statistics need stats_rows");
     // Workgroup shape: 8x16 output patch; all 128 channels in one 512-thread workgroup when N is a multiple of 128
     // (each patch element is activated once), else 64 channels in a 256-thread workgroup (two per CU).
-    // ANODDPM_DEBUG0: 1 = the 16x16-patch 512-thread shape, 2 = force the 64-channel shape.
+    // ANODDPM_DEBUG0: 1 = the 16x16-patch 512-thread shape, 2 = force the 64-channel shape, 3 = per-wave transforms.
     const int dbg = anoddpm::g_debug[0];
     const int wmw = dbg == 1 ? 2 : 1;
     const bool fast = a->gn_scale && a->act;
@@ -408,6 +494,9 @@ int launch_winograd(const anoddpm_igemm_args *a, hipStream_t s)
         else      hipLaunchKernelGGL((wino_kernel<false, 2, 2>), grid, dim3(512), 0, s, *a);
     } else if (probe) {
         hipLaunchKernelGGL((wino_kernel<true, 1, 2, true>), grid, dim3(256), 0, s, *a);
+    } else if (wnw == 4 && dbg != 3) {                              // shared input transform (ANODDPM_DEBUG0=3 disables)
+        if (fast) hipLaunchKernelGGL((wino_kernel<true, 1, 4, false, true>), grid, dim3(512), 0, s, *a);
+        else      hipLaunchKernelGGL((wino_kernel<false, 1, 4, false, true>), grid, dim3(512), 0, s, *a);
     } else if (wnw == 4) {
         if (fast) hipLaunchKernelGGL((wino_kernel<true, 1, 4>), grid, dim3(512), 0, s, *a);
         else      hipLaunchKernelGGL((wino_kernel<false, 1, 4>), grid, dim3(512), 0, s, *a);
