@@ -9,19 +9,20 @@
 // (weights are pre-transformed on the host, the 1/2 factors live there), measured error vs the direct form
 // is ~1e-6 of the tensor's magnitude.
 //
-// Mapping to gfx950.  The limit is accumulator capacity: 16 transform positions of a 32 tiles x 32 channels
-// tile are 256 registers.  They are split over TWO waves (8 positions = 128 registers each), so a workgroup is
-// 8 waves = two per SIMD that cover each other's LDS / barrier stalls (a first version with one 256-accumulator
-// wave per SIMD left the matrix pipe < 50 % busy).  Workgroup = 64 Winograd tiles (a 16x16 output patch) x 64
-// output channels; K advances 16 channels per iteration:
-//   S1  activated 18x18 input patch (affine + SiLU, zero padding, nearest-x2 / concat on the load) -> LDS
-//       and the pre-transformed weight tile U[16][16 ch][64] -> LDS         (both prefetched into registers
-//       one iteration ahead, so their HBM/L2 latency sits behind the previous iteration's MFMAs)
-//   S2  input transform B^T d B: one thread per (tile, channel quad), 16 ds_read_b128 -> 32 float4 adds ->
-//       16 ds_write_b128 into V[16][64 tiles][16 ch] (XOR-swizzled by tile so the MFMA operand reads are
-//       bank-conflict free)
-//   S3  128 MFMAs per wave (16 positions x K=16), operands by ds_read_b128, K permuted as in igemm.hip
-// Epilogue: output transform A^T M A in registers, then bias / time embedding / residual / statistics.
+// Mapping to gfx950 (measured history in DESIGN.md 5b).  The limit is accumulator capacity: 16 transform positions of a
+// 32 tiles x 32 channels wave tile are 256 registers, so they are split over TWO waves (xh = 0/1: 8 positions = 128
+// accumulator VGPRs each) that exchange partial output transforms through LDS in the epilogue.  A workgroup covers an
+// 8x16 output patch (32 tiles) x 32*WNW channels; K advances 16 channels per iteration, each iteration ONE basic block:
+//   * the activated halo patch (GN-apply + SiLU, zero padding, nearest-x2 / concat resolved on the load) is the only
+//     staged operand: double-buffered in LDS, fetched two iterations ahead through buffer loads whose in-loop
+//     address parts are all scalar;
+//   * the B operands U[xi][k][n] stream from L2 straight into a two-deep register ring (every lane needs different
+//     words, LDS would only add traffic);
+//   * the A operands B^T d B are either transformed by each lane for exactly the values it multiplies (WNW = 2) or
+//     computed once per workgroup one iteration ahead and shared through LDS (VSH, WNW = 4);
+//   * 64 MFMAs per wave per iteration in four bursts of 16, operand reads for the next burst issued before each.
+// The fp32 MFMA does not hide VALU issue on this chip (tools/mfma_ubench.hip), so the design minimises VALU
+// instructions per MFMA: no 64-bit address arithmetic, no predicated loads, no repeated transforms.
 #include "common.h"
 
 using anoddpm::silu_f;
@@ -33,8 +34,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WKC = 16;            // channels per K iteration
 
-
-__device__ __forceinline__ f32x4 wld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 // Buffer loads: descriptor (SGPRs) + per-lane 32-bit byte offset (VGPR) + wave-uniform 32-bit byte offset (SGPR).
 // All address arithmetic that changes inside the K loop is then scalar -- VALU instructions are NOT hidden by the
 // fp32 MFMA on gfx950, 64-bit VALU pointer adds would come straight out of the matrix issue time.
