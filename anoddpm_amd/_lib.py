@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 
@@ -125,11 +125,20 @@ class VlbArgs(Structure):
                 ("n", c_int64), ("B", c_int32), ("T", c_int32)]
 
 
+class WgradArgs(Structure):
+    _fields_ = [("a0", c_void_p), ("a1", c_void_p), ("gn_scale", c_void_p), ("gn_shift", c_void_p), ("dy", c_void_p),
+                ("dw", c_void_p), ("ws", c_void_p), ("ws_floats", c_int64),
+                ("a0_bs", c_int64), ("a1_bs", c_int64), ("dy_bs", c_int64),
+                ("c0", c_int32), ("c1", c_int32), ("a0_ld", c_int32), ("a1_ld", c_int32), ("dy_ld", c_int32),
+                ("H", c_int32), ("W", c_int32), ("N", c_int32), ("B", c_int32),
+                ("a_mode", c_int32), ("act", c_int32), ("gn_ld", c_int32), ("band", c_int32), ("accumulate", c_int32)]
+
+
 ANOMALY_NCOUNTS = 12
 ANOMALY_BLOCKS = 64
 
 _STRUCTS = [SimplexArgs, PUpdateArgs, IgemmArgs, GnArgs, SoftmaxArgs, ResampleArgs, LinearArgs,
-            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, AnomalyArgs, VlbArgs]
+            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, AnomalyArgs, VlbArgs, WgradArgs]
 
 # every symbol include/anoddpm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -140,7 +149,7 @@ SYMBOLS = [
     "anoddpm_igemm", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
     "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_conv_head", "anoddpm_nhwc_to_nchw",
     "anoddpm_run_ops", "anoddpm_prof_enable", "anoddpm_prof_active", "anoddpm_prof_collect",
-    "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map", "anoddpm_vlb_terms",
+    "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map", "anoddpm_vlb_terms", "anoddpm_conv3x3_wgrad",
 ]
 
 _lib = None
@@ -213,6 +222,7 @@ def lib():
     L.anoddpm_sumsq.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
     L.anoddpm_anomaly_map.argtypes = [POINTER(AnomalyArgs), c_void_p]
     L.anoddpm_vlb_terms.argtypes = [POINTER(VlbArgs), c_void_p]
+    L.anoddpm_conv3x3_wgrad.argtypes = [POINTER(WgradArgs), c_void_p]
     for i in range(8):
         if os.environ.get(f"ANODDPM_DEBUG{i}"):
             L.anoddpm_debug_set(i, int(os.environ[f"ANODDPM_DEBUG{i}"], 0))

@@ -24,6 +24,7 @@ SOURCES = {
     "executor.hip": [],
     "optim.hip": [],
     "metrics.hip": ["-ffp-contract=off"],
+    "wgrad.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

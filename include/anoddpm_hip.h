@@ -410,6 +410,33 @@ typedef struct anoddpm_vlb_args {
 
 int anoddpm_vlb_terms(const anoddpm_vlb_args *a, void *stream);
 
+/* ------------------------------------------------------------------ backward twins (training, diffusion_training.py:102)
+ * Weight gradient of a 3x3 / stride 1 / pad 1 convolution whose input the forward consumed through the fused operand
+ * load of anoddpm_igemm (GroupNorm-apply + SiLU, nearest x2, two-source concat):
+ *   dw[co][ci][ky][kx] (OIHW) = sum_{b,y,x} dy[b][y][x][co] * A[b][y+ky-1][x+kx-1][ci]
+ * The data gradient needs no entry point of its own: it is anoddpm_igemm on dy with the spatially flipped,
+ * channel-transposed weights.  ws: [B * (W/TW) * ceil(H/band)][9][K][N] floats (TW = 32 when W % 32 == 0, else 16);
+ * the partial tiles are folded in a fixed order (deterministic).  accumulate != 0 adds into dw. */
+typedef struct anoddpm_wgrad_args {
+    const float *a0, *a1;           /* the conv's input sources (NHWC), a1 NULL when single source */
+    const float *gn_scale, *gn_shift; /* [B][gn_ld] per-sample per-channel affine or NULL */
+    const float *dy;                /* [B][H*W][dy_ld] gradient w.r.t. the conv output */
+    float *dw;                      /* [N][K][3][3] */
+    float *ws;
+    int64_t ws_floats;
+    int64_t a0_bs, a1_bs, dy_bs;    /* batch strides (floats) */
+    int32_t c0, c1, a0_ld, a1_ld, dy_ld;
+    int32_t H, W;                   /* OUTPUT image dims */
+    int32_t N, B;
+    int32_t a_mode;                 /* 0 same-res, 1 source is half-res (nearest x2) */
+    int32_t act;                    /* 1: SiLU after the affine */
+    int32_t gn_ld;
+    int32_t band;                   /* image rows per work item (split-K granularity) */
+    int32_t accumulate;
+} anoddpm_wgrad_args;
+
+int anoddpm_conv3x3_wgrad(const anoddpm_wgrad_args *a, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,3 +202,33 @@ def head(x, w, b, scale, shift):
     check(lib().anoddpm_conv_head(ctypes.byref(st), current_stream()), "conv_head")
     torch.cuda.synchronize()
     return out
+
+
+def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into=None):
+    """dW (OIHW) of a 3x3 conv whose input is the fused operand load of `conv_igemm` (anoddpm_conv3x3_wgrad).
+    srcs: NHWC sources; dy: NHWC [B,H,W,N]."""
+    from anoddpm_amd._lib import WgradArgs
+    dev = dy.device
+    B, H, W, N = dy.shape
+    c0 = srcs[0].shape[3]
+    c1 = srcs[1].shape[3] if len(srcs) > 1 else 0
+    K = c0 + c1
+    Pin = srcs[0].shape[1] * srcs[0].shape[2]
+    TW = 32 if W % 32 == 0 else 16
+    band = band or max(1, H // 4)
+    nitems = B * (W // TW) * (-(-H // band))
+    ws = torch.empty(nitems * 9 * K * N, device=dev)
+    dw = accumulate_into if accumulate_into is not None else torch.full((N, K, 3, 3), float("nan"), device=dev)
+    st = WgradArgs()
+    st.a0, st.a1 = srcs[0].data_ptr(), srcs[1].data_ptr() if c1 else None
+    st.gn_scale = gn[0].data_ptr() if gn else None
+    st.gn_shift = gn[1].data_ptr() if gn else None
+    st.dy, st.dw, st.ws, st.ws_floats = dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel()
+    st.a0_bs, st.a1_bs, st.dy_bs = Pin * c0, Pin * c1, H * W * N
+    st.c0, st.c1, st.a0_ld, st.a1_ld, st.dy_ld = c0, c1, c0, max(c1, 4), N
+    st.H, st.W, st.N, st.B = H, W, N, B
+    st.a_mode, st.act, st.gn_ld, st.band = a_mode, act, K, band
+    st.accumulate = 1 if accumulate_into is not None else 0
+    check(lib().anoddpm_conv3x3_wgrad(ctypes.byref(st), current_stream()), "conv3x3_wgrad")
+    torch.cuda.synchronize()
+    return dw

@@ -280,3 +280,68 @@ def test_winograd_conv(case):
         g2, b2 = 1 + 0.1 * rnd(N, seed=88), 0.1 * rnd(N, seed=89)
         sc, sh = hipops.gn_finalize(st, g2.to(dev()), b2.to(dev()), Hout * Hout)
         assert relerr(hipops.nchw(got * sc[:, None, None, :] + sh[:, None, None, :]), F.group_norm(ref, 32, g2, b2, eps=1e-5)) < 2e-4
+
+
+# ---------------------------------------------------------------------------- backward twins of the 3x3 convolution
+BWD_CASES = [
+    # B, (c0, c1), Cout, Hout, a_mode, gn+act
+    (2, (64, 0), 64, 32, 0, True),
+    (1, (128, 0), 128, 64, 0, True),
+    (2, (64, 64), 128, 16, 0, True),        # virtual concat
+    (1, (96, 32), 96, 32, 0, True),         # channel tails on both sides (96 = 64 + 32)
+    (1, (64, 0), 64, 32, 1, True),          # fused nearest x2
+    (1, (32, 0), 64, 48, 0, False),         # plain input, 16-pixel segments (W = 48), ragged bands
+]
+
+
+def _bwd_reference(case):
+    B, (c0, c1), N, Hout, a_mode, fused = case
+    C = c0 + c1
+    Hin = Hout if a_mode == 0 else Hout // 2
+    x = rnd(B, C, Hin, Hin, seed=91)
+    w = rnd(N, C, 3, 3, seed=92, scale=1.0 / math.sqrt(C * 9)).requires_grad_(True)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=93), 0.1 * rnd(C, seed=94)
+    dy = rnd(B, N, Hout, Hout, seed=95)
+    hh = x
+    if fused:
+        hh = F.silu(F.group_norm(hh, 32, gamma, beta, eps=1e-5))
+    if a_mode == 1:
+        hh = F.interpolate(hh, scale_factor=2, mode="nearest")
+    hh = hh.detach().requires_grad_(True)
+    y = F.conv2d(hh.double(), w.double(), None, padding=1)
+    y.backward(dy.double())
+    return x, w.detach(), gamma, beta, dy, w.grad.float(), hh.grad.float()
+
+
+@pytest.mark.parametrize("case", BWD_CASES)
+def test_conv3x3_wgrad(case):
+    """anoddpm_conv3x3_wgrad against autograd (fp64) of F.conv2d on the same fused input."""
+    import hipops
+    B, (c0, c1), N, Hout, a_mode, fused = case
+    x, w, gamma, beta, dy, dw_ref, _ = _bwd_reference(case)
+    xs = hipops.nhwc(x.to(dev()))
+    srcs = [xs[..., :c0].contiguous()] + ([xs[..., c0:].contiguous()] if c1 else [])
+    gn = hipops.gn_affine(srcs, gamma.to(dev()), beta.to(dev())) if fused else None
+    dyn = hipops.nhwc(dy.to(dev())).contiguous()
+    got = hipops.conv_wgrad(srcs, dyn, gn=gn, act=1 if fused else 0, a_mode=a_mode, band=7 if Hout == 48 else None)
+    assert got.shape == dw_ref.shape
+    assert relerr(got, dw_ref) < 2e-5, relerr(got, dw_ref)
+    # accumulate mode adds into an existing gradient (two micro-batches of the same data = 2x)
+    acc = got.clone()
+    hipops.conv_wgrad(srcs, dyn, gn=gn, act=1 if fused else 0, a_mode=a_mode, accumulate_into=acc)
+    assert relerr(acc, 2 * dw_ref) < 2e-5
+
+
+@pytest.mark.parametrize("case", [c for c in BWD_CASES if c[4] == 0])
+def test_conv3x3_dgrad_is_forward_kernel_on_flipped_weights(case):
+    """The data gradient w.r.t. the (activated) conv input is anoddpm_igemm on dY with the spatially flipped,
+    channel-transposed weights -- direct and Winograd kernels."""
+    import hipops
+    B, (c0, c1), N, Hout, a_mode, fused = case
+    x, w, gamma, beta, dy, _, da_ref = _bwd_reference(case)
+    wt = w.flip(2, 3).transpose(0, 1).contiguous()                      # [Cin][Cout][3][3]
+    dyn = hipops.nhwc(dy.to(dev())).contiguous()
+    pow2 = (Hout & (Hout - 1)) == 0                                     # the direct 3x3 kernel needs a power-of-two width
+    for cfg in ([1] if pow2 else []) + ([2] if Hout % 16 == 0 else []):
+        got = hipops.conv_igemm([dyn], wt.to(dev()), None, Hout=Hout, ks=3, cfg=cfg)
+        assert relerr(hipops.nchw(got), da_ref) < (1e-4 if cfg == 2 else 1e-5), (cfg, relerr(hipops.nchw(got), da_ref))
