@@ -100,11 +100,49 @@ def detection_chains(total_avg=5, t_distance=50):
             "chain_steps_per_s_batched": total_avg * t_distance / out["batched"]}
 
 
+def conv_backward_kernels():
+    """Weight- and data-gradient kernels of the big 3x3 layers of config 2 (batch 4), timed with device events."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import hipops
+    dev = torch.device("cuda:0")
+    out = []
+    for (H, K, N) in ((256, 128, 128), (256, 256, 128), (128, 128, 128), (64, 256, 256), (32, 256, 256), (16, 512, 512)):
+        B = 4
+        x = torch.randn(B, H, H, K, device=dev)
+        dy = torch.randn(B, H, H, N, device=dev)
+        gn = hipops.gn_affine([x], torch.ones(K, device=dev), torch.zeros(K, device=dev))
+        w = torch.randn(N, K, 3, 3, device=dev) / (3 * K ** 0.5)
+        wt = w.flip(2, 3).transpose(0, 1).contiguous()
+        tiles = (-(-K // 64)) * (-(-N // 64))
+        TW = 32 if H % 32 == 0 else 16
+        want_items = max(1, -(-768 // tiles))
+        band = max(1, min(H, (B * (H // TW) * H) // want_items))
+        flop = 2.0 * B * H * H * K * N * 9
+        res = {"layer": f"{H}x{H} {K}->{N} batch {B}", "wgrad_band": band}
+        for name, fn in (("wgrad", lambda: hipops.conv_wgrad([x], dy, gn=gn, act=1, band=band)),
+                         ("dgrad_winograd", lambda: hipops.conv_igemm([dy], wt, None, Hout=H, ks=3, cfg=2, ksplit=(1 if H >= 64 else 4)))):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3          # includes hipops' own allocation + sync per call: upper bound
+            res[name + "_ms"] = ms
+            res[name + "_TFLOPs"] = flop / ms / 1e9
+        out.append(res)
+    return {"what": "3x3 conv backward kernels (weight gradient: anoddpm_conv3x3_wgrad; data gradient: Winograd forward kernel on flipped weights)",
+            "layers": out}
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c4", "c3", "detect"]
+    which = sys.argv[1:] or ["c4", "c3", "detect", "bwd"]
     if "c4" in which:
         print(json.dumps(simplex_c4()), flush=True)
     if "c3" in which:
         print(json.dumps(train_step_c3()), flush=True)
     if "detect" in which:
         print(json.dumps(detection_chains()), flush=True)
+    if "bwd" in which:
+        print(json.dumps(conv_backward_kernels()), flush=True)
