@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 
@@ -61,7 +61,8 @@ class GnFinalizeArgs(Structure):
     _fields_ = [("stats0", c_void_p), ("stats1", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
                 ("scale", c_void_p), ("shift", c_void_p),
                 ("rows0", c_int32), ("rows1", c_int32), ("c0", c_int32), ("c1", c_int32),
-                ("P", c_int32), ("B", c_int32), ("groups", c_int32), ("eps", c_float)]
+                ("P", c_int32), ("B", c_int32), ("groups", c_int32), ("eps", c_float),
+                ("mean_out", c_void_p), ("rstd_out", c_void_p)]
 
 
 class HeadArgs(Structure):
@@ -134,11 +135,22 @@ class WgradArgs(Structure):
                 ("a_mode", c_int32), ("act", c_int32), ("gn_ld", c_int32), ("band", c_int32), ("accumulate", c_int32)]
 
 
+class GnBwdArgs(Structure):
+    _fields_ = [("x0", c_void_p), ("x1", c_void_p), ("da", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("mean", c_void_p), ("rstd", c_void_p), ("dx0", c_void_p), ("dx1", c_void_p),
+                ("dgamma", c_void_p), ("dbeta", c_void_p), ("partial", c_void_p), ("coef", c_void_p),
+                ("x0_bs", c_int64), ("x1_bs", c_int64), ("da_bs", c_int64), ("dx0_bs", c_int64), ("dx1_bs", c_int64),
+                ("c0", c_int32), ("c1", c_int32), ("x0_ld", c_int32), ("x1_ld", c_int32), ("da_ld", c_int32),
+                ("dx0_ld", c_int32), ("dx1_ld", c_int32), ("Hs", c_int32), ("Ws", c_int32),
+                ("B", c_int32), ("groups", c_int32), ("nslab", c_int32),
+                ("act", c_int32), ("a_mode", c_int32), ("acc_dx", c_int32)]
+
+
 ANOMALY_NCOUNTS = 12
 ANOMALY_BLOCKS = 64
 
 _STRUCTS = [SimplexArgs, PUpdateArgs, IgemmArgs, GnArgs, SoftmaxArgs, ResampleArgs, LinearArgs,
-            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, AnomalyArgs, VlbArgs, WgradArgs]
+            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, AnomalyArgs, VlbArgs, WgradArgs, GnBwdArgs]
 
 # every symbol include/anoddpm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -149,7 +161,7 @@ SYMBOLS = [
     "anoddpm_igemm", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
     "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_conv_head", "anoddpm_nhwc_to_nchw",
     "anoddpm_run_ops", "anoddpm_prof_enable", "anoddpm_prof_active", "anoddpm_prof_collect",
-    "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map", "anoddpm_vlb_terms", "anoddpm_conv3x3_wgrad",
+    "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map", "anoddpm_vlb_terms", "anoddpm_conv3x3_wgrad", "anoddpm_gn_silu_backward",
 ]
 
 _lib = None
@@ -223,6 +235,7 @@ def lib():
     L.anoddpm_anomaly_map.argtypes = [POINTER(AnomalyArgs), c_void_p]
     L.anoddpm_vlb_terms.argtypes = [POINTER(VlbArgs), c_void_p]
     L.anoddpm_conv3x3_wgrad.argtypes = [POINTER(WgradArgs), c_void_p]
+    L.anoddpm_gn_silu_backward.argtypes = [POINTER(GnBwdArgs), c_void_p]
     for i in range(8):
         if os.environ.get(f"ANODDPM_DEBUG{i}"):
             L.anoddpm_debug_set(i, int(os.environ[f"ANODDPM_DEBUG{i}"], 0))

@@ -25,6 +25,7 @@ SOURCES = {
     "optim.hip": [],
     "metrics.hip": ["-ffp-contract=off"],
     "wgrad.hip": [],
+    "gn_backward.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

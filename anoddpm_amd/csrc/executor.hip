@@ -58,7 +58,7 @@ extern "C" int anoddpm_debug_set(int32_t key, int32_t value)
     return ANODDPM_OK;
 }
 
-extern "C" int anoddpm_abi_version(void) { return 7; }
+extern "C" int anoddpm_abi_version(void) { return 8; }
 
 extern "C" const char *anoddpm_last_error(void) { return g_err; }
 
@@ -160,6 +160,7 @@ extern "C" int anoddpm_struct_size(int32_t which)
         case 15: return (int)sizeof(anoddpm_anomaly_args);
         case 16: return (int)sizeof(anoddpm_vlb_args);
         case 17: return (int)sizeof(anoddpm_wgrad_args);
+        case 18: return (int)sizeof(anoddpm_gn_bwd_args);
         default: return -1;
     }
 }

@@ -1,0 +1,210 @@
+// Backward of a = SiLU(GroupNorm32(x)) as the forward's fused operand load consumed it (UNet.py:170-171, 190-191, 113,
+// 409-411; reference: torch autograd of nn.GroupNorm + nn.SiLU, diffusion_training.py:102).  HBM-bound: the reduction
+// pass reads x and da once, the elementwise pass reads them again and writes dx.  Two concatenated sources, the
+// nearest-x2 / 2x2-average resampling between a and the conv, and gradient fan-in (acc_dx) are handled in place,
+// so neither the activated tensor nor a resampled gradient ever exists in HBM.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// gradient w.r.t. the activated value at SOURCE pixel (sy, sx), channel quad at `c`
+__device__ __forceinline__ f32x4 load_da(const anoddpm_gn_bwd_args &a, const float *da, int sy, int sx, int c)
+{
+    if (a.a_mode == 0) return *reinterpret_cast<const f32x4 *>(da + ((int64_t)sy * a.Ws + sx) * a.da_ld + c);
+    if (a.a_mode == 1) {                             // forward: nearest x2 -> sum of the four children
+        const int Wd = a.Ws * 2;
+        const float *p = da + ((int64_t)(2 * sy) * Wd + 2 * sx) * a.da_ld + c;
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(p), v1 = *reinterpret_cast<const f32x4 *>(p + a.da_ld);
+        const f32x4 v2 = *reinterpret_cast<const f32x4 *>(p + (int64_t)Wd * a.da_ld);
+        const f32x4 v3 = *reinterpret_cast<const f32x4 *>(p + (int64_t)Wd * a.da_ld + a.da_ld);
+        return (v0 + v1) + (v2 + v3);
+    }
+    const int Wd = a.Ws >> 1;                        // forward: 2x2 average -> a quarter of the parent
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(da + ((int64_t)(sy >> 1) * Wd + (sx >> 1)) * a.da_ld + c);
+    return v * 0.25f;
+}
+
+struct ChanParams { f32x4 sc, sh, mu, rs; };
+
+// y = sc*x + sh (sc = gamma*rstd);  dy = da * silu'(y);  xhat = (x - mu)*rs
+__device__ __forceinline__ void dy_xhat(const anoddpm_gn_bwd_args &a, const ChanParams &k, f32x4 x, f32x4 g, f32x4 &dy, f32x4 &xh)
+{
+    xh = (x - k.mu) * k.rs;
+    if (a.act) {
+        const f32x4 y = x * k.sc + k.sh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-y[e]));
+            dy[e] = g[e] * (s * (1.0f + y[e] * (1.0f - s)));
+        }
+    } else {
+        dy = g;
+    }
+}
+
+__device__ __forceinline__ ChanParams chan_params(const anoddpm_gn_bwd_args &a, int b, int c)
+{
+    const int C = a.c0 + a.c1, cpg = C / a.groups;
+    ChanParams k;
+    const f32x4 gm = *reinterpret_cast<const f32x4 *>(a.gamma + c), bt = *reinterpret_cast<const f32x4 *>(a.beta + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int g = (c + e) / cpg;
+        k.mu[e] = a.mean[(int64_t)b * a.groups + g];
+        k.rs[e] = a.rstd[(int64_t)b * a.groups + g];
+    }
+    k.sc = gm * k.rs;
+    k.sh = bt - k.mu * k.sc;
+    return k;
+}
+
+// pass 1: grid (nslab, B).  partial[b][slab][c] = { sum_p dy, sum_p dy*xhat } over the slab's pixels
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(anoddpm_gn_bwd_args a)
+{
+    __shared__ float lds_s[256 * 4];
+    __shared__ float lds_q[256 * 4];
+    const int C = a.c0 + a.c1, C4 = C >> 2, P = a.Hs * a.Ws;
+    const int TQ = C4 < 256 ? C4 : 256;
+    const int R = 256 / TQ;
+    const int npass = (C4 + TQ - 1) / TQ;
+    const int tid = threadIdx.x;
+    const int tq = tid % TQ, tr = tid / TQ;
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int sp = (P + a.nslab - 1) / a.nslab;
+    const int p0 = slab * sp, p1 = (p0 + sp < P) ? p0 + sp : P;
+    double *out = a.partial + ((int64_t)b * a.nslab + slab) * C * 2;
+    const float *da = a.da + (int64_t)b * a.da_bs;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int quad = pass * TQ + tq;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+        if (tr < R && quad < C4) {
+            const int c = quad * 4;
+            const ChanParams k = chan_params(a, b, c);
+            const bool first = c < a.c0;
+            const float *src = first ? a.x0 + (int64_t)b * a.x0_bs + c : a.x1 + (int64_t)b * a.x1_bs + (c - a.c0);
+            const int ld = first ? a.x0_ld : a.x1_ld;
+            for (int p = p0 + tr; p < p1; p += R) {
+                const f32x4 x = *reinterpret_cast<const f32x4 *>(src + (int64_t)p * ld);
+                const f32x4 g = load_da(a, da, p / a.Ws, p % a.Ws, c);
+                f32x4 dy, xh;
+                dy_xhat(a, k, x, g, dy, xh);
+                s += dy;
+                q += dy * xh;
+            }
+        }
+        if (tr < R) {
+            const int o = (tr * TQ + tq) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lds_s[o + e] = s[e]; lds_q[o + e] = q[e]; }
+        }
+        __syncthreads();
+        for (int cl = tid; cl < TQ * 4; cl += 256) {
+            const int c = pass * TQ * 4 + cl;
+            if (c < C) {
+                double ss = 0.0, qq = 0.0;
+                for (int r = 0; r < R; ++r) { ss += (double)lds_s[r * TQ * 4 + cl]; qq += (double)lds_q[r * TQ * 4 + cl]; }
+                out[c * 2] = ss;
+                out[c * 2 + 1] = qq;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// pass 2: grid (groups).  Folds the slabs in order; per image the group means, per channel dgamma / dbeta.
+// coef[b][c] = { rstd*gamma, rstd*mean_g(gamma*dy), rstd*mean_g(gamma*dy*xhat), unused }
+__global__ __launch_bounds__(64) void gn_bwd_fold_kernel(anoddpm_gn_bwd_args a)
+{
+    const int C = a.c0 + a.c1, cpg = C / a.groups;
+    const int g = blockIdx.x, t = threadIdx.x;
+    const double n = (double)a.Hs * a.Ws * cpg;
+    double dgam = 0.0, dbet = 0.0;
+    for (int b = 0; b < a.B; ++b) {
+        double s1 = 0.0, s2 = 0.0;
+        if (t < cpg) {
+            const int c = g * cpg + t;
+            for (int sl = 0; sl < a.nslab; ++sl) {
+                const double *p = a.partial + (((int64_t)b * a.nslab + sl) * C + c) * 2;
+                s1 += p[0];
+                s2 += p[1];
+            }
+            dbet += s1;
+            dgam += s2;
+            s1 *= (double)a.gamma[c];
+            s2 *= (double)a.gamma[c];
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        if (t < cpg) {
+            const int c = g * cpg + t;
+            const double r = (double)a.rstd[(int64_t)b * a.groups + g];
+            float *k = a.coef + ((int64_t)b * C + c) * 4;
+            k[0] = (float)(r * (double)a.gamma[c]);
+            k[1] = (float)(r * s1 / n);
+            k[2] = (float)(r * s2 / n);
+            k[3] = 0.f;
+        }
+    }
+    if (t < cpg) {
+        const int c = g * cpg + t;
+        a.dgamma[c] += (float)dgam;
+        a.dbeta[c] += (float)dbet;
+    }
+}
+
+// pass 3: dx = coef0*dy - coef1 - xhat*coef2, written (or added) to the source gradients
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(anoddpm_gn_bwd_args a)
+{
+    const int C = a.c0 + a.c1, C4 = C >> 2, P = a.Hs * a.Ws;
+    const int b = blockIdx.y;
+    const float *da = a.da + (int64_t)b * a.da_bs;
+    const int64_t total = (int64_t)P * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int quad = (int)(i % C4);
+        const int p = (int)(i / C4);
+        const int c = quad * 4;
+        const ChanParams k = chan_params(a, b, c);
+        const bool first = c < a.c0;
+        const float *src = first ? a.x0 + (int64_t)b * a.x0_bs + c : a.x1 + (int64_t)b * a.x1_bs + (c - a.c0);
+        const int ld = first ? a.x0_ld : a.x1_ld;
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(src + (int64_t)p * ld);
+        const f32x4 g = load_da(a, da, p / a.Ws, p % a.Ws, c);
+        f32x4 dy, xh;
+        dy_xhat(a, k, x, g, dy, xh);
+        const float *kc = a.coef + ((int64_t)b * C + c) * 4;
+        f32x4 dx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dx[e] = kc[e * 4 + 0] * dy[e] - kc[e * 4 + 1] - xh[e] * kc[e * 4 + 2];
+        float *dst = first ? a.dx0 + (int64_t)b * a.dx0_bs + (int64_t)p * a.dx0_ld + c
+                           : a.dx1 + (int64_t)b * a.dx1_bs + (int64_t)p * a.dx1_ld + (c - a.c0);
+        if (a.acc_dx) dx += *reinterpret_cast<const f32x4 *>(dst);
+        *reinterpret_cast<f32x4 *>(dst) = dx;
+    }
+}
+
+}  // namespace
+
+extern "C" int anoddpm_gn_silu_backward(const anoddpm_gn_bwd_args *a, void *stream)
+{
+    using namespace anoddpm;
+    ANODDPM_REQUIRE(a && a->x0 && a->da && a->gamma && a->beta && a->mean && a->rstd && a->dx0 && a->dgamma && a->dbeta && a->partial && a->coef,
+                    "gn_silu_backward: null pointer");
+    const int C = a->c0 + a->c1;
+    ANODDPM_REQUIRE(a->c0 > 0 && a->c0 % 4 == 0 && a->c1 >= 0 && a->c1 % 4 == 0 && (a->c1 == 0 || (a->x1 && a->dx1)), "gn_silu_backward: bad channel counts");
+    ANODDPM_REQUIRE(a->groups > 0 && C % a->groups == 0 && C / a->groups <= 64, "gn_silu_backward: bad group size");
+    ANODDPM_REQUIRE(a->B > 0 && a->B <= 65535 && a->Hs > 0 && a->Ws > 0 && a->nslab > 0 && a->nslab <= 65535, "gn_silu_backward: bad sizes");
+    ANODDPM_REQUIRE(a->a_mode >= 0 && a->a_mode <= 2 && (a->a_mode != 2 || (a->Hs % 2 == 0 && a->Ws % 2 == 0)), "gn_silu_backward: bad a_mode");
+    ANODDPM_REQUIRE(a->x0_ld % 4 == 0 && a->da_ld % 4 == 0 && a->dx0_ld % 4 == 0 && (a->c1 == 0 || (a->x1_ld % 4 == 0 && a->dx1_ld % 4 == 0)),
+                    "gn_silu_backward: pixel strides must be multiples of 4 floats");
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(a->nslab, a->B), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(a->groups), dim3(64), 0, s, *a);
+    const int64_t work = (int64_t)a->Hs * a->Ws * (C / 4);
+    const int64_t blocks = (work + 255) / 256;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks), a->B), dim3(256), 0, s, *a);
+    return check_launch("gn_silu_backward");
+}

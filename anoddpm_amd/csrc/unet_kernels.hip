@@ -228,6 +228,10 @@ __global__ __launch_bounds__(256) void gn_finalize2_kernel(anoddpm_gn_finalize_a
         a.scale[(int64_t)b * C + c] = (float)sc;
         a.shift[(int64_t)b * C + c] = (float)((double)a.beta[c] - mean * sc);
     }
+    if (tid == 0 && a.mean_out) {
+        a.mean_out[(int64_t)b * a.groups + g] = (float)mean;
+        a.rstd_out[(int64_t)b * a.groups + g] = (float)rstd;
+    }
 }
 
 // ---------------------------------------------------------------- softmax ---------------------
@@ -487,6 +491,7 @@ extern "C" int anoddpm_gn_finalize(const anoddpm_gn_finalize_args *a, void *stre
     const int C = a->c0 + a->c1;
     ANODDPM_REQUIRE(a->groups > 0 && a->groups <= 65535 && C % a->groups == 0 && C / a->groups <= 256, "gn_finalize: bad group size");
     ANODDPM_REQUIRE(a->B > 0 && a->B <= 65535 && a->P > 0 && a->rows0 > 0 && (a->c1 == 0 || a->rows1 > 0), "gn_finalize: bad sizes");
+    ANODDPM_REQUIRE((a->mean_out == nullptr) == (a->rstd_out == nullptr), "gn_finalize: mean_out and rstd_out go together");
     hipLaunchKernelGGL(gn_finalize2_kernel, dim3(a->groups, a->B), dim3(256), 0, anoddpm::as_stream(stream), *a);
     return anoddpm::check_launch("gn_finalize");
 }

@@ -232,6 +232,7 @@ typedef struct {
     int32_t rows0, rows1, c0, c1;
     int32_t P, B, groups;
     float eps;
+    float *mean_out, *rstd_out;     /* optional [B][groups]: saved for anoddpm_gn_silu_backward (training) */
 } anoddpm_gn_finalize_args;
 
 int anoddpm_gn_finalize(const anoddpm_gn_finalize_args *a, void *stream);
@@ -436,6 +437,35 @@ typedef struct anoddpm_wgrad_args {
 } anoddpm_wgrad_args;
 
 int anoddpm_conv3x3_wgrad(const anoddpm_wgrad_args *a, void *stream);
+
+/* Backward of a = SiLU(GroupNorm32(x)) (UNet.py:170-171,190-191,409-411; act == 0: GroupNorm alone, UNet.py:113) as the
+ * fused operand load of anoddpm_igemm consumed it, over up to two concatenated NHWC sources:
+ *   y = gamma*xhat + beta, xhat = (x - mean)*rstd;   dy = da * silu'(y);
+ *   dgamma[c] += sum_{b,p} dy*xhat;   dbeta[c] += sum_{b,p} dy;
+ *   dx = rstd * (gamma*dy - mean_g(gamma*dy) - xhat * mean_g(gamma*dy*xhat))          (means over the group, per image)
+ * `da` is the gradient w.r.t. the tensor the conv read: with a_mode 1 (forward nearest-x2 of a) it is at twice the
+ * source resolution and the four children are summed; with a_mode 2 (forward 2x2 average) it is at half resolution and
+ * each source pixel takes a quarter of its parent.  dx0 / dx1 receive the gradient w.r.t. the sources (acc_dx != 0:
+ * added to what is there -- gradient fan-in of skip connections and residuals).  Three launches: per-channel partial
+ * sums (deterministic two-stage fp64 fold), then the elementwise pass.
+ * partial: double[B][nslab][C][2]; coef: float[B][C][4] scratch. */
+typedef struct anoddpm_gn_bwd_args {
+    const float *x0, *x1;           /* forward sources (x1 NULL when single) */
+    const float *da;                /* [B][Pa][C] with row length da_ld */
+    const float *gamma, *beta;      /* [C] */
+    const float *mean, *rstd;       /* [B][groups] from anoddpm_gn_finalize */
+    float *dx0, *dx1;
+    float *dgamma, *dbeta;          /* [C], accumulated into */
+    double *partial;
+    float *coef;
+    int64_t x0_bs, x1_bs, da_bs, dx0_bs, dx1_bs;
+    int32_t c0, c1, x0_ld, x1_ld, da_ld, dx0_ld, dx1_ld;
+    int32_t Hs, Ws;                 /* SOURCE image dims (P = Hs*Ws) */
+    int32_t B, groups, nslab;
+    int32_t act, a_mode, acc_dx;
+} anoddpm_gn_bwd_args;
+
+int anoddpm_gn_silu_backward(const anoddpm_gn_bwd_args *a, void *stream);
 
 #ifdef __cplusplus
 }

@@ -47,8 +47,8 @@ def chan_stats(x, nslab):
     return stats
 
 
-def gn_finalize(stats, gamma, beta, P):
-    """stats: list of 1-2 tensors [B][rows][c][2] -> scale, shift [B][Ctot]."""
+def gn_finalize(stats, gamma, beta, P, want_mean_rstd=False):
+    """stats: list of 1-2 tensors [B][rows][c][2] -> scale, shift [B][Ctot] (+ mean, rstd [B][32])."""
     B = stats[0].shape[0]
     c0 = stats[0].shape[2]
     c1 = stats[1].shape[2] if len(stats) > 1 else 0
@@ -59,8 +59,13 @@ def gn_finalize(stats, gamma, beta, P):
     st.stats1, st.rows1 = (stats[1].data_ptr(), stats[1].shape[1]) if c1 else (None, 0)
     st.gamma, st.beta, st.scale, st.shift = gamma.data_ptr(), beta.data_ptr(), scale.data_ptr(), shift.data_ptr()
     st.c0, st.c1, st.P, st.B, st.groups, st.eps = c0, c1, P, B, 32, 1e-5
+    mean = rstd = None
+    if want_mean_rstd:
+        mean = torch.full((B, 32), float("nan"), device=stats[0].device)
+        rstd = torch.full((B, 32), float("nan"), device=stats[0].device)
+        st.mean_out, st.rstd_out = mean.data_ptr(), rstd.data_ptr()
     check(lib().anoddpm_gn_finalize(ctypes.byref(st), current_stream()), "gn_finalize")
-    return scale, shift
+    return (scale, shift, mean, rstd) if want_mean_rstd else (scale, shift)
 
 
 def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=None, res=None, cfg=0, ksplit=1,
@@ -232,3 +237,31 @@ def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into
     check(lib().anoddpm_conv3x3_wgrad(ctypes.byref(st), current_stream()), "conv3x3_wgrad")
     torch.cuda.synchronize()
     return dw
+
+
+def gn_silu_backward(srcs, da, gamma, beta, mean, rstd, *, act=1, a_mode=0, acc_into=None, nslab=None):
+    """anoddpm_gn_silu_backward.  srcs: 1-2 NHWC sources; da: NHWC gradient w.r.t. the tensor the conv read.
+    Returns (dx list, dgamma, dbeta)."""
+    from anoddpm_amd._lib import GnBwdArgs
+    dev = srcs[0].device
+    B, Hs, Ws, c0 = srcs[0].shape
+    c1 = srcs[1].shape[3] if len(srcs) > 1 else 0
+    C, P = c0 + c1, Hs * Ws
+    nslab = nslab or max(1, min(64, P // 64))
+    dx = acc_into if acc_into is not None else [torch.full_like(s_, float("nan")) for s_ in srcs]
+    dgamma, dbeta = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    part = torch.empty(B * nslab * C * 2, dtype=torch.float64, device=dev)
+    coef = torch.empty(B * C * 4, device=dev)
+    st = GnBwdArgs()
+    st.x0, st.x1 = srcs[0].data_ptr(), srcs[1].data_ptr() if c1 else None
+    st.da, st.gamma, st.beta, st.mean, st.rstd = da.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    st.dx0, st.dx1 = dx[0].data_ptr(), dx[1].data_ptr() if c1 else None
+    st.dgamma, st.dbeta, st.partial, st.coef = dgamma.data_ptr(), dbeta.data_ptr(), part.data_ptr(), coef.data_ptr()
+    Pa = da.shape[1] * da.shape[2]
+    st.x0_bs, st.x1_bs, st.da_bs, st.dx0_bs, st.dx1_bs = P * c0, P * c1, Pa * C, P * c0, P * c1
+    st.c0, st.c1, st.x0_ld, st.x1_ld, st.da_ld, st.dx0_ld, st.dx1_ld = c0, c1, c0, max(c1, 4), C, c0, max(c1, 4)
+    st.Hs, st.Ws, st.B, st.groups, st.nslab = Hs, Ws, B, 32, nslab
+    st.act, st.a_mode, st.acc_dx = act, a_mode, 1 if acc_into is not None else 0
+    check(lib().anoddpm_gn_silu_backward(ctypes.byref(st), current_stream()), "gn_silu_backward")
+    torch.cuda.synchronize()
+    return dx, dgamma, dbeta

@@ -345,3 +345,52 @@ def test_conv3x3_dgrad_is_forward_kernel_on_flipped_weights(case):
     for cfg in ([1] if pow2 else []) + ([2] if Hout % 16 == 0 else []):
         got = hipops.conv_igemm([dyn], wt.to(dev()), None, Hout=Hout, ks=3, cfg=cfg)
         assert relerr(hipops.nchw(got), da_ref) < (1e-4 if cfg == 2 else 1e-5), (cfg, relerr(hipops.nchw(got), da_ref))
+
+
+GN_BWD_CASES = [
+    # B, (c0, c1), Hs, act, a_mode
+    (2, (64, 0), 16, 1, 0),
+    (1, (128, 0), 32, 1, 0),
+    (2, (96, 32), 8, 1, 0),          # concat, group straddles nothing (cpg 4)
+    (1, (256, 128), 8, 1, 0),        # concat where groups of 12 channels straddle the two sources
+    (2, (64, 0), 8, 1, 1),           # forward upsampled the activation: da at 2x resolution
+    (2, (64, 0), 16, 1, 2),          # forward average-pooled the activation: da at half resolution
+    (1, (64, 0), 16, 0, 0),          # GroupNorm alone (attention blocks)
+]
+
+
+@pytest.mark.parametrize("case", GN_BWD_CASES)
+def test_gn_silu_backward(case):
+    """anoddpm_gn_silu_backward against autograd (fp64) of [resample](silu(group_norm(cat(x))))."""
+    import hipops
+    B, (c0, c1), Hs, act, a_mode = case
+    C = c0 + c1
+    x = rnd(B, C, Hs, Hs, seed=101)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=102), 0.1 * rnd(C, seed=103)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    a = F.group_norm(xd, 32, gd, bd, eps=1e-5)
+    if act:
+        a = F.silu(a)
+    if a_mode == 1:
+        a = F.interpolate(a, scale_factor=2, mode="nearest")
+    elif a_mode == 2:
+        a = F.avg_pool2d(a, 2)
+    da = rnd(*a.shape, seed=104)
+    a.backward(da.double())
+    xs = hipops.nhwc(x.to(dev()))
+    srcs = [xs[..., :c0].contiguous()] + ([xs[..., c0:].contiguous()] if c1 else [])
+    nslab = 4
+    stats = [hipops.chan_stats(s_, nslab) for s_ in srcs]
+    sc, sh, mean, rstd = hipops.gn_finalize(stats, gamma.to(dev()), beta.to(dev()), Hs * Hs, want_mean_rstd=True)
+    ref_mean = x.reshape(B, 32, -1).double().mean(dim=2)
+    assert relerr(mean, ref_mean.float()) < 1e-5
+    dan = hipops.nhwc(da.to(dev())).contiguous()
+    dx, dgamma, dbeta = hipops.gn_silu_backward(srcs, dan, gamma.to(dev()), beta.to(dev()), mean, rstd, act=act, a_mode=a_mode)
+    got = hipops.nchw(torch.cat(dx, dim=3))
+    assert relerr(got, xd.grad.float()) < 2e-5, relerr(got, xd.grad.float())
+    assert relerr(dgamma, gd.grad.float()) < 2e-5 and relerr(dbeta, bd.grad.float()) < 2e-5
+    # fan-in: accumulate into an existing gradient
+    base = [torch.ones_like(d) for d in dx]
+    dx2, _, _ = hipops.gn_silu_backward(srcs, dan, gamma.to(dev()), beta.to(dev()), mean, rstd, act=act, a_mode=a_mode, acc_into=base)
+    assert relerr(hipops.nchw(torch.cat(dx2, dim=3)), xd.grad.float() + 1.0) < 2e-5
