@@ -23,7 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int CT = 64;              // channel tile (ci and co)
 constexpr int AP = CT + 4;          // floats per pixel in the LDS rows (pad: keeps float4 stores 16-byte aligned)
 
-template <int TW>                    // output pixels per row segment (16 or 32)
+template <int TW>                    // output pixels per row segment (2 ... 32)
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const anoddpm_wgrad_args a, const int nseg, const int nband)
 {
     constexpr int AW = TW + 2;                                       // staged input row incl. halo
@@ -66,18 +66,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const anoddpm_wgrad_args 
     const int Ws = a.a_mode == 1 ? (W >> 1) : W;
 
     f32x4 areg[AJ], dreg[DJ];
-    auto load_act_row = [&](int gy) {                                // raw input row gy (cols x0-1 .. x0+TW) -> registers
+    auto activate = [&](f32x4 v) {
+        if (affine) v = v * asc + ash;
+        if (act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+        return v;
+    };
+    auto load_act_row = [&](int gy) {                                // activated input row gy (cols x0-1 .. x0+TW) -> registers
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int idx = tid + j * 256;
             const int gx = x0 - 1 + (idx >> 4);
             const bool ok = cok && idx < A_F4 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const int sy = a.a_mode == 1 ? (gy >> 1) : gy, sx = a.a_mode == 1 ? (gx >> 1) : gx;
-            const int64_t off = ok ? ((int64_t)sy * Ws + sx) * ald : 0;
-            f32x4 v = *reinterpret_cast<const f32x4 *>(asrc + off);
-            if (affine) v = v * asc + ash;
-            if (act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            f32x4 v;
+            if (a.a_mode == 2) {                                     // forward: 2x2 average of four ACTIVATED source pixels
+                const int64_t o = ok ? ((int64_t)(2 * gy) * (2 * W) + 2 * gx) * ald : 0;
+                const int64_t down = ok ? (int64_t)(2 * W) * ald : 0, right = ok ? ald : 0;
+                v = activate(*reinterpret_cast<const f32x4 *>(asrc + o)) + activate(*reinterpret_cast<const f32x4 *>(asrc + o + right));
+                v += activate(*reinterpret_cast<const f32x4 *>(asrc + o + down)) + activate(*reinterpret_cast<const f32x4 *>(asrc + o + down + right));
+                v *= 0.25f;
+            } else {
+                const int sy = a.a_mode == 1 ? (gy >> 1) : gy, sx = a.a_mode == 1 ? (gx >> 1) : gx;
+                const int64_t off = ok ? ((int64_t)sy * Ws + sx) * ald : 0;
+                v = activate(*reinterpret_cast<const f32x4 *>(asrc + off));
+            }
             areg[j] = ok ? v : zero;                                 // zero padding AFTER the transform
         }
     };
@@ -187,21 +199,24 @@ extern "C" int anoddpm_conv3x3_wgrad(const anoddpm_wgrad_args *a, void *stream)
     ANODDPM_REQUIRE(a && a->a0 && a->dy && a->dw && a->ws, "wgrad: null pointer");
     const int K = a->c0 + a->c1;
     ANODDPM_REQUIRE(a->c0 > 0 && a->c0 % 4 == 0 && a->c1 >= 0 && a->c1 % 4 == 0 && (a->c1 == 0 || a->a1), "wgrad: channel counts must be multiples of 4");
-    ANODDPM_REQUIRE(a->N >= 1 && a->N % 4 == 0 && a->B >= 1 && a->H >= 1 && a->W >= 16 && a->band >= 1, "wgrad: bad sizes");
-    ANODDPM_REQUIRE(a->a_mode == 0 || (a->a_mode == 1 && a->H % 2 == 0 && a->W % 2 == 0), "wgrad: a_mode must be 0 or 1");
+    ANODDPM_REQUIRE(a->N >= 1 && a->N % 4 == 0 && a->B >= 1 && a->H >= 1 && a->W >= 2 && a->band >= 1, "wgrad: bad sizes");
+    ANODDPM_REQUIRE(a->a_mode == 0 || a->a_mode == 2 || (a->a_mode == 1 && a->H % 2 == 0 && a->W % 2 == 0), "wgrad: a_mode must be 0, 1 or 2");
     ANODDPM_REQUIRE(a->a0_ld % 4 == 0 && (a->c1 == 0 || a->a1_ld % 4 == 0) && a->dy_ld % 4 == 0 && (a->a0_bs | a->a1_bs | a->dy_bs) % 4 == 0,
                     "wgrad: strides must be multiples of 4 floats");
     ANODDPM_REQUIRE(!a->gn_scale || (a->gn_shift && a->gn_ld % 4 == 0), "wgrad: bad GroupNorm affine");
-    const int TW = a->W % 32 == 0 ? 32 : 16;
-    ANODDPM_REQUIRE(a->W % TW == 0, "wgrad: W must be a multiple of 16");
+    const int TW = a->W % 32 == 0 ? 32 : (a->W % 16 == 0 ? 16 : (a->W % 8 == 0 ? 8 : (a->W % 4 == 0 ? 4 : 2)));
+    ANODDPM_REQUIRE(a->W % TW == 0, "wgrad: W must be even");
     const int nseg = a->W / TW, nband = (a->H + a->band - 1) / a->band;
     const int64_t nitems = (int64_t)a->B * nseg * nband;
     ANODDPM_REQUIRE(nitems <= 65535, "wgrad: too many work items (raise band)");
     ANODDPM_REQUIRE(a->ws_floats >= nitems * 9 * K * a->N, "wgrad: workspace too small");
     const int tiles = ((K + CT - 1) / CT) * ((a->N + CT - 1) / CT);
     hipStream_t s = as_stream(stream);
-    if (TW == 32) hipLaunchKernelGGL(wgrad_kernel<32>, dim3(tiles, (unsigned)nitems), dim3(256), 0, s, *a, nseg, nband);
-    else          hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles, (unsigned)nitems), dim3(256), 0, s, *a, nseg, nband);
+    if (TW == 32)      hipLaunchKernelGGL(wgrad_kernel<32>, dim3(tiles, (unsigned)nitems), dim3(256), 0, s, *a, nseg, nband);
+    else if (TW == 16) hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles, (unsigned)nitems), dim3(256), 0, s, *a, nseg, nband);
+    else if (TW == 8)  hipLaunchKernelGGL(wgrad_kernel<8>, dim3(tiles, (unsigned)nitems), dim3(256), 0, s, *a, nseg, nband);
+    else if (TW == 4)  hipLaunchKernelGGL(wgrad_kernel<4>, dim3(tiles, (unsigned)nitems), dim3(256), 0, s, *a, nseg, nband);
+    else               hipLaunchKernelGGL(wgrad_kernel<2>, dim3(tiles, (unsigned)nitems), dim3(256), 0, s, *a, nseg, nband);
     const int64_t kn = (int64_t)K * a->N;
     hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, s, *a, (int)nitems);
     return check_launch("conv3x3_wgrad");

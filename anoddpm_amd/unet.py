@@ -290,8 +290,33 @@ class UNetModel(nn.Module):
         temb = F.linear(temb, P("time_embedding.1.weight"), P("time_embedding.1.bias"))
         temb = F.linear(F.silu(temb), P("time_embedding.3.weight"), P("time_embedding.3.bias"))
 
+        # Hand-written forward + backward for the 3x3 blocks (95 % of the FLOPs) is opt-in for now: on config 3 it is
+        # numerically equivalent (tests/test_gpu_training.py) and needs 30 % less memory, but at 121 ms per step it
+        # is not yet faster than the MIOpen-backed path (97 ms) -- per-step weight re-packing and the first-version
+        # weight-gradient kernel are the known costs.
+        native = (not (self.dropout > 0 and self.training)) and os.environ.get("ANODDPM_NATIVE_BACKWARD", "0") == "1"
+        if native:
+            from .train_ops import fused_gn_silu_conv3x3
+
         def res(p, h, resample):
             xs = h
+            if native:
+                # the two GN -> SiLU -> [resample] -> conv3x3 stages run on hand-written forward AND backward kernels
+                # (train_ops.FusedGNSiLUConv3x3); the embedding add and the residual ride in the conv epilogues
+                e = F.linear(F.silu(temb), P(p + ".embed_layers.1.weight"), P(p + ".embed_layers.1.bias"))
+                am = {"down": 2, "up": 1}.get(resample, 0)
+                h = fused_gn_silu_conv3x3(h, P(p + ".in_layers.0.weight"), P(p + ".in_layers.0.bias"),
+                                          P(p + ".in_layers.2.weight"), P(p + ".in_layers.2.bias"), temb=e, a_mode=am,
+                                          epoch=self._weights_epoch)
+                if resample == "down":
+                    xs = F.avg_pool2d(xs, 2, 2)
+                elif resample == "up":
+                    xs = F.interpolate(xs, scale_factor=2, mode="nearest")
+                if (p + ".skip_connection.weight") in sd:
+                    xs = F.conv2d(xs, P(p + ".skip_connection.weight"), P(p + ".skip_connection.bias"))
+                return fused_gn_silu_conv3x3(h, P(p + ".out_layers.0.weight"), P(p + ".out_layers.0.bias"),
+                                             P(p + ".out_layers.3.weight"), P(p + ".out_layers.3.bias"), res=xs,
+                                             epoch=self._weights_epoch)
             h = F.silu(gn(p + ".in_layers.0", h))
             if resample == "down":
                 h, xs = F.avg_pool2d(h, 2, 2), F.avg_pool2d(xs, 2, 2)
@@ -333,6 +358,8 @@ class UNetModel(nn.Module):
 
         down, middle, up = self._blocks
         h = x.float()
+        if native:
+            h = h.contiguous(memory_format=torch.channels_last)      # NHWC in memory: what the fused blocks consume
         skips = []
         for blk in down:
             h = run(blk, h)

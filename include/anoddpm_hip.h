@@ -416,7 +416,7 @@ int anoddpm_vlb_terms(const anoddpm_vlb_args *a, void *stream);
  * load of anoddpm_igemm (GroupNorm-apply + SiLU, nearest x2, two-source concat):
  *   dw[co][ci][ky][kx] (OIHW) = sum_{b,y,x} dy[b][y][x][co] * A[b][y+ky-1][x+kx-1][ci]
  * The data gradient needs no entry point of its own: it is anoddpm_igemm on dy with the spatially flipped,
- * channel-transposed weights.  ws: [B * (W/TW) * ceil(H/band)][9][K][N] floats (TW = 32 when W % 32 == 0, else 16);
+ * channel-transposed weights.  ws: [B * (W/TW) * ceil(H/band)][9][K][N] floats (TW = the largest of 32, 16, 8, 4, 2 dividing W);
  * the partial tiles are folded in a fixed order (deterministic).  accumulate != 0 adds into dw. */
 typedef struct anoddpm_wgrad_args {
     const float *a0, *a1;           /* the conv's input sources (NHWC), a1 NULL when single source */
@@ -429,7 +429,7 @@ typedef struct anoddpm_wgrad_args {
     int32_t c0, c1, a0_ld, a1_ld, dy_ld;
     int32_t H, W;                   /* OUTPUT image dims */
     int32_t N, B;
-    int32_t a_mode;                 /* 0 same-res, 1 source is half-res (nearest x2) */
+    int32_t a_mode;                 /* 0 same-res, 1 source is half-res (nearest x2), 2 source is double-res (2x2 average) */
     int32_t act;                    /* 1: SiLU after the affine */
     int32_t gn_ld;
     int32_t band;                   /* image rows per work item (split-K granularity) */

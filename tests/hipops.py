@@ -219,7 +219,7 @@ def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into
     c1 = srcs[1].shape[3] if len(srcs) > 1 else 0
     K = c0 + c1
     Pin = srcs[0].shape[1] * srcs[0].shape[2]
-    TW = 32 if W % 32 == 0 else 16
+    TW = next(t for t in (32, 16, 8, 4, 2) if W % t == 0)
     band = band or max(1, H // 4)
     nitems = B * (W // TW) * (-(-H // band))
     ws = torch.empty(nitems * 9 * K * N, device=dev)

@@ -291,13 +291,16 @@ BWD_CASES = [
     (1, (96, 32), 96, 32, 0, True),         # channel tails on both sides (96 = 64 + 32)
     (1, (64, 0), 64, 32, 1, True),          # fused nearest x2
     (1, (32, 0), 64, 48, 0, False),         # plain input, 16-pixel segments (W = 48), ragged bands
+    (2, (64, 0), 64, 16, 2, True),          # fused 2x2 average of the activated input (down blocks)
+    (2, (128, 0), 64, 8, 0, True),          # 8x8 map: 8-pixel segments
+    (2, (64, 0), 128, 4, 0, True),          # 4x4 map (bottom of the 32x32 models)
 ]
 
 
 def _bwd_reference(case):
     B, (c0, c1), N, Hout, a_mode, fused = case
     C = c0 + c1
-    Hin = Hout if a_mode == 0 else Hout // 2
+    Hin = Hout if a_mode == 0 else (Hout // 2 if a_mode == 1 else Hout * 2)
     x = rnd(B, C, Hin, Hin, seed=91)
     w = rnd(N, C, 3, 3, seed=92, scale=1.0 / math.sqrt(C * 9)).requires_grad_(True)
     gamma, beta = 1 + 0.1 * rnd(C, seed=93), 0.1 * rnd(C, seed=94)
@@ -307,6 +310,8 @@ def _bwd_reference(case):
         hh = F.silu(F.group_norm(hh, 32, gamma, beta, eps=1e-5))
     if a_mode == 1:
         hh = F.interpolate(hh, scale_factor=2, mode="nearest")
+    elif a_mode == 2:
+        hh = F.avg_pool2d(hh, 2)
     hh = hh.detach().requires_grad_(True)
     y = F.conv2d(hh.double(), w.double(), None, padding=1)
     y.backward(dy.double())
