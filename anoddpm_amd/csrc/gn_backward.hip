@@ -113,46 +113,59 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(anoddpm_gn_bwd_args 
     }
 }
 
-// pass 2: grid (groups).  Folds the slabs in order; per image the group means, per channel dgamma / dbeta.
+// pass 2: grid (groups), 256 threads.  Folds the slabs (thread = (channel, slab lane), fixed order); per image the
+// group means, per channel dgamma / dbeta.
 // coef[b][c] = { rstd*gamma, rstd*mean_g(gamma*dy), rstd*mean_g(gamma*dy*xhat), unused }
-__global__ __launch_bounds__(64) void gn_bwd_fold_kernel(anoddpm_gn_bwd_args a)
+__global__ __launch_bounds__(256) void gn_bwd_fold_kernel(anoddpm_gn_bwd_args a)
 {
-    const int C = a.c0 + a.c1, cpg = C / a.groups;
-    const int g = blockIdx.x, t = threadIdx.x;
+    __shared__ double red[256][2];
+    const int C = a.c0 + a.c1, cpg = C / a.groups;                  // cpg <= 64 (launcher)
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int S = 256 / cpg;                                         // slab lanes
+    const int cl = tid % cpg, sl = tid / cpg;
+    const int c = g * cpg + cl;
     const double n = (double)a.Hs * a.Ws * cpg;
     double dgam = 0.0, dbet = 0.0;
     for (int b = 0; b < a.B; ++b) {
         double s1 = 0.0, s2 = 0.0;
-        if (t < cpg) {
-            const int c = g * cpg + t;
-            for (int sl = 0; sl < a.nslab; ++sl) {
-                const double *p = a.partial + (((int64_t)b * a.nslab + sl) * C + c) * 2;
+        if (sl < S)
+            for (int k = sl; k < a.nslab; k += S) {
+                const double *p = a.partial + (((int64_t)b * a.nslab + k) * C + c) * 2;
                 s1 += p[0];
                 s2 += p[1];
             }
-            dbet += s1;
-            dgam += s2;
-            s1 *= (double)a.gamma[c];
-            s2 *= (double)a.gamma[c];
+        red[tid][0] = s1;
+        red[tid][1] = s2;
+        __syncthreads();
+        double c1 = 0.0, c2 = 0.0;                                   // per-channel sums (threads of the first wave)
+        if (tid < 64 && tid < cpg)
+            for (int k = 0; k < S; ++k) { c1 += red[k * cpg + tid][0]; c2 += red[k * cpg + tid][1]; }
+        double g1 = 0.0, g2 = 0.0;
+        if (tid < 64) {
+            const double gm = tid < cpg ? (double)a.gamma[g * cpg + tid] : 0.0;
+            g1 = c1 * gm;
+            g2 = c2 * gm;
+            for (int o = 32; o > 0; o >>= 1) {
+                g1 += __shfl_xor(g1, o);
+                g2 += __shfl_xor(g2, o);
+            }
+            if (tid < cpg) {
+                dbet += c1;
+                dgam += c2;
+                const int cc = g * cpg + tid;
+                const double r = (double)a.rstd[(int64_t)b * a.groups + g];
+                float *k = a.coef + ((int64_t)b * C + cc) * 4;
+                k[0] = (float)(r * gm);
+                k[1] = (float)(r * g1 / n);
+                k[2] = (float)(r * g2 / n);
+                k[3] = 0.f;
+            }
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            s1 += __shfl_xor(s1, o);
-            s2 += __shfl_xor(s2, o);
-        }
-        if (t < cpg) {
-            const int c = g * cpg + t;
-            const double r = (double)a.rstd[(int64_t)b * a.groups + g];
-            float *k = a.coef + ((int64_t)b * C + c) * 4;
-            k[0] = (float)(r * (double)a.gamma[c]);
-            k[1] = (float)(r * s1 / n);
-            k[2] = (float)(r * s2 / n);
-            k[3] = 0.f;
-        }
+        __syncthreads();
     }
-    if (t < cpg) {
-        const int c = g * cpg + t;
-        a.dgamma[c] += (float)dgam;
-        a.dbeta[c] += (float)dbet;
+    if (tid < 64 && tid < cpg) {
+        a.dgamma[g * cpg + tid] += (float)dgam;
+        a.dbeta[g * cpg + tid] += (float)dbet;
     }
 }
 
@@ -202,7 +215,7 @@ extern "C" int anoddpm_gn_silu_backward(const anoddpm_gn_bwd_args *a, void *stre
                     "gn_silu_backward: pixel strides must be multiples of 4 floats");
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(a->nslab, a->B), dim3(256), 0, s, *a);
-    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(a->groups), dim3(64), 0, s, *a);
+    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(a->groups), dim3(256), 0, s, *a);
     const int64_t work = (int64_t)a->Hs * a->Ws * (C / 4);
     const int64_t blocks = (work + 255) / 256;
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks), a->B), dim3(256), 0, s, *a);

@@ -191,6 +191,41 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const anoddpm_wgrad_arg
     for (int t = 0; t < 9; ++t) o[t] = a.accumulate ? o[t] + s[t] : s[t];
 }
 
+// Weight packing for the 3x3 kernels on the device (training re-packs after every optimizer step): OIHW ->
+//   mode 0: direct layout  [9 taps][I/4][O][4]                    (unet.py:_pack_conv)
+//   mode 1: Winograd       [16 xi = 4u+v][I/4][O][4], U = G g G^T  (unet.py:_pack_wino; fp64 like the host version)
+// bwd != 0 packs the data-gradient weights W'[o=k][i=n][a][b] = w[n][k][2-a][2-b].  Thread = (o, i).
+__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float *__restrict__ w, float *__restrict__ out,
+                                                           int N, int K, int mode, int bwd)
+{
+    const int O = bwd ? K : N, I = bwd ? N : K;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)O * I) return;
+    const int o = (int)(idx % O), i = (int)(idx / O);
+    const float *src = bwd ? w + ((int64_t)i * K + o) * 9 : w + ((int64_t)o * K + i) * 9;
+    double g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = (double)src[bwd ? 8 - t : t];
+    float *dst = out + (((int64_t)(i >> 2)) * O + o) * 4 + (i & 3);
+    const int64_t plane = (int64_t)(I >> 2) * O * 4;
+    if (mode == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dst[t * plane] = (float)g[t / 3][t % 3];
+    } else {
+        const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+        double t1[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int b2 = 0; b2 < 3; ++b2) t1[u][b2] = G[u][0] * g[0][b2] + G[u][1] * g[1][b2] + G[u][2] * g[2][b2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                dst[(u * 4 + v) * plane] = (float)(t1[u][0] * G[v][0] + t1[u][1] * G[v][1] + t1[u][2] * G[v][2]);
+    }
+}
+
 }  // namespace
 
 extern "C" int anoddpm_conv3x3_wgrad(const anoddpm_wgrad_args *a, void *stream)
@@ -220,4 +255,15 @@ extern "C" int anoddpm_conv3x3_wgrad(const anoddpm_wgrad_args *a, void *stream)
     const int64_t kn = (int64_t)K * a->N;
     hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, s, *a, (int)nitems);
     return check_launch("conv3x3_wgrad");
+}
+
+extern "C" int anoddpm_pack_conv3x3(const float *w, float *out, int32_t N, int32_t K, int32_t mode, int32_t bwd, void *stream)
+{
+    using namespace anoddpm;
+    ANODDPM_REQUIRE(w && out, "pack_conv3x3: null pointer");
+    ANODDPM_REQUIRE(N >= 1 && K >= 1 && (mode == 0 || mode == 1), "pack_conv3x3: bad arguments");
+    ANODDPM_REQUIRE((bwd ? N : K) % 4 == 0, "pack_conv3x3: input channel count must be a multiple of 4");
+    const int64_t total = (int64_t)N * K;
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), w, out, N, K, mode, bwd);
+    return check_launch("pack_conv3x3");
 }

@@ -44,7 +44,6 @@ class _Cache:
     @classmethod
     def packed(cls, w, kind, epoch):
         import weakref
-        from .unet import _pack_conv, _pack_wino
         key = id(w)
         ent = cls.packs.get(key)
         if ent is None or ent["ref"]() is not w:
@@ -54,10 +53,14 @@ class _Cache:
         hit = ent["kinds"].get(kind)
         if hit is not None and hit[0] == stamp:
             return hit[1]
+        N, K = w.shape[0], w.shape[1]
+        wino, bwd = kind.endswith("wino"), kind.startswith("bwd")
         src = w.detach()
-        if kind.startswith("bwd"):
-            src = src.flip(2, 3).transpose(0, 1).contiguous()            # data gradient = conv with W^T, taps reversed
-        buf = _pack_wino(src) if kind.endswith("wino") else _pack_conv(src)
+        if src.dtype != torch.float32 or not src.is_contiguous():
+            src = src.float().contiguous()
+        buf = hit[1] if hit is not None else torch.empty((16 if wino else 9) * N * K, device=w.device, dtype=torch.float32)
+        check(lib().anoddpm_pack_conv3x3(src.data_ptr(), buf.data_ptr(), N, K, 1 if wino else 0, 1 if bwd else 0,
+                                         current_stream()), "pack_conv3x3")
         ent["kinds"][kind] = (stamp, buf)
         return buf
 

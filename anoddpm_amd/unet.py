@@ -290,11 +290,9 @@ class UNetModel(nn.Module):
         temb = F.linear(temb, P("time_embedding.1.weight"), P("time_embedding.1.bias"))
         temb = F.linear(F.silu(temb), P("time_embedding.3.weight"), P("time_embedding.3.bias"))
 
-        # Hand-written forward + backward for the 3x3 blocks (95 % of the FLOPs) is opt-in for now: on config 3 it is
-        # numerically equivalent (tests/test_gpu_training.py) and needs 30 % less memory, but at 121 ms per step it
-        # is not yet faster than the MIOpen-backed path (97 ms) -- per-step weight re-packing and the first-version
-        # weight-gradient kernel are the known costs.
-        native = (not (self.dropout > 0 and self.training)) and os.environ.get("ANODDPM_NATIVE_BACKWARD", "0") == "1"
+        # Hand-written forward + backward for the 3x3 blocks (95 % of the FLOPs): train_ops.FusedGNSiLUConv3x3.
+        # ANODDPM_TORCH_BACKWARD=1 keeps the all-torch (MIOpen) expression, which is also what runs with dropout > 0.
+        native = (not (self.dropout > 0 and self.training)) and os.environ.get("ANODDPM_TORCH_BACKWARD", "0") != "1"
         if native:
             from .train_ops import fused_gn_silu_conv3x3
 

@@ -438,6 +438,11 @@ typedef struct anoddpm_wgrad_args {
 
 int anoddpm_conv3x3_wgrad(const anoddpm_wgrad_args *a, void *stream);
 
+/* Device-side weight packing for the 3x3 kernels (training re-packs after every optimizer step).  w: OIHW [N][K][3][3].
+ * mode 0: direct layout [9][I/4][O][4]; mode 1: Winograd U = G g G^T as [16][I/4][O][4].  bwd != 0 packs the
+ * data-gradient weights W'[o=k][i=n][a][b] = w[n][k][2-a][2-b] (I = N, O = K), else I = K, O = N. */
+int anoddpm_pack_conv3x3(const float *w, float *out, int32_t N, int32_t K, int32_t mode, int32_t bwd, void *stream);
+
 /* Backward of a = SiLU(GroupNorm32(x)) (UNet.py:170-171,190-191,409-411; act == 0: GroupNorm alone, UNet.py:113) as the
  * fused operand load of anoddpm_igemm consumed it, over up to two concatenated NHWC sources:
  *   y = gamma*xhat + beta, xhat = (x - mean)*rstd;   dy = da * silu'(y);

@@ -399,3 +399,21 @@ def test_gn_silu_backward(case):
     base = [torch.ones_like(d) for d in dx]
     dx2, _, _ = hipops.gn_silu_backward(srcs, dan, gamma.to(dev()), beta.to(dev()), mean, rstd, act=act, a_mode=a_mode, acc_into=base)
     assert relerr(hipops.nchw(torch.cat(dx2, dim=3)), xd.grad.float() + 1.0) < 2e-5
+
+
+@pytest.mark.parametrize("N,K", [(64, 32), (128, 256), (96, 36)])
+def test_device_weight_packing_matches_host_packers(N, K):
+    """anoddpm_pack_conv3x3 (training re-packs on the device) against the host packers used by the inference plan."""
+    from anoddpm_amd.unet import _pack_conv, _pack_wino
+    from anoddpm_amd._lib import check, current_stream, lib
+    w = rnd(N, K, 3, 3, seed=111).to(dev())
+    for bwd in (0, 1):
+        src = w.flip(2, 3).transpose(0, 1).contiguous() if bwd else w
+        if (N if bwd else K) % 4:
+            continue
+        for mode, host in ((0, _pack_conv), (1, _pack_wino)):
+            out = torch.full(((16 if mode else 9) * N * K,), float("nan"), device=dev())
+            check(lib().anoddpm_pack_conv3x3(w.data_ptr(), out.data_ptr(), N, K, mode, bwd, current_stream()), "pack")
+            ref = host(src).reshape(-1)
+            assert out.shape == ref.shape
+            assert torch.allclose(out, ref, rtol=1e-6, atol=1e-7), (mode, bwd, (out - ref).abs().max().item())

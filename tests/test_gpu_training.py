@@ -88,7 +88,7 @@ def test_native_backward_matches_torch_autograd(kw, monkeypatch):
     tgt = torch.randn(2, 1, S, S, device=DEV)
 
     def run(torch_only):
-        monkeypatch.setenv("ANODDPM_NATIVE_BACKWARD", "0" if torch_only else "1")
+        monkeypatch.setenv("ANODDPM_TORCH_BACKWARD", "1" if torch_only else "0")
         m.zero_grad(set_to_none=True)
         if x.grad is not None:
             x.grad = None
