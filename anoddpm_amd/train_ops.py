@@ -75,29 +75,9 @@ class _Cache:
 
 
 def _conv_cfg(H, W, K, N, B, a_mode):
-    """Tile configuration and split-K of one 3x3 launch (same policy as the inference plan, unet.py:_Plan.igemm)."""
-    from .unet import _use_winograd
-    if (a_mode in (0, 1) and H % 16 == 0 and W % 16 == 0 and K % 16 == 0 and N >= 32 and N % 4 == 0 and _use_winograd()):
-        blocks = (H // 16) * (W // 16) * -(-N // 64) * B
-        if blocks >= 200:
-            return 2, 1
-        wch = K // 16
-        ks = int(min(max(1, wch // 4), -(-256 // blocks)))
-        if blocks * ks >= 128:
-            cps = -(-wch // ks)
-            return 2, -(-wch // cps)
-    P = H * W
-    tw = min(W, 32)
-    ok128 = P % 128 == 0 and (128 // tw) <= H and H % (128 // tw) == 0
-    blocks128 = (P // 128) * -(-N // 128) * B if ok128 else 0
-    cfg = 0 if (blocks128 >= 256 and N >= 96) else 1
-    bm = 128 if cfg == 0 else 64
-    blocks = -(-P // bm) * -(-N // bm) * B
-    nchunks = -(-K // 32)
-    ksplit = 1
-    if blocks < 512 and nchunks > 1 and N % 4 == 0:
-        ksplit = int(min(nchunks, 16, max(1, -(-512 // blocks))))
-    return cfg, ksplit
+    """Tile configuration and split-K of one 3x3 launch: the inference plan's policy (unet.choose_conv_cfg)."""
+    from .unet import choose_conv_cfg
+    return choose_conv_cfg(H, W, K, N, B, ks=3, a_mode=a_mode)
 
 
 def _launch_conv(x, K, Hs, Ws, w, kind, epoch, *, H, W, N, a_mode, gn, act, bias, temb, res):

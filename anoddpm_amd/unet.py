@@ -402,6 +402,49 @@ def _use_winograd():
     return os.environ.get("ANODDPM_NO_WINOGRAD", "0") != "1"
 
 
+def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None, c1=0, wino=True):
+    """Tile configuration (0: 128x128 direct, 1: 64x64 direct, 2: Winograd F(2x2,3x3)) and split-K of one
+    anoddpm_igemm launch; shared by the inference plan and the training operators (train_ops).  Policy: fill the 256
+    CUs -- >= 512 workgroups for the direct kernels when K allows it, one full round of >= 4-chunk workgroups for
+    Winograd on small maps."""
+    c0 = K if c0 is None else c0
+    P = H * W
+
+    def ok128():
+        if P % 128:
+            return False
+        if ks == 1:
+            return True
+        tw = min(W, 32)
+        th = 128 // tw
+        return th <= H and H % th == 0
+    blocks128 = (P // 128) * ((N + 127) // 128) * Z if ok128() else 0
+    cfg = 0 if (blocks128 >= 256 and N >= 96) else 1
+    wino_blocks = (H // 16) * (W // 16) * ((N + 63) // 64) * Z
+    wino_ksplit = 1
+    wino_ok = (wino and ks == 3 and b_mode == 0 and heads == 1 and a_mode in (0, 1) and H % 16 == 0 and W % 16 == 0
+               and K % 16 == 0 and (c1 == 0 or c0 % 16 == 0) and N >= 32 and _use_winograd())
+    if wino_ok and wino_blocks < 200:
+        # small maps: split K over 16-channel chunks until one round of workgroups fills the 256 CUs, keeping
+        # >= 4 chunks per workgroup (the prologue / epilogue of a workgroup cost about two chunks)
+        wch = K // 16
+        wino_ksplit = int(min(max(1, wch // 4), -(-256 // wino_blocks)))
+        if N % 4 or wino_blocks * wino_ksplit < 128 or os.environ.get("ANODDPM_NO_WINOGRAD_SPLITK"):
+            wino_ok = False
+        else:
+            cps = -(-wch // wino_ksplit)
+            wino_ksplit = -(-wch // cps)                   # no empty trailing block
+    if wino_ok:
+        return 2, wino_ksplit
+    bm = 128 if cfg == 0 else 64
+    blocks = -(-P // bm) * ((N + bm - 1) // bm) * Z
+    nchunks = (K + 31) // 32
+    ksplit = 1
+    if blocks < 512 and nchunks > 1 and N % 4 == 0:
+        ksplit = int(min(nchunks, 16, max(1, -(-512 // blocks))))
+    return cfg, ksplit
+
+
 class _Plan:
     """Compiled forward for one (batch, size, device): buffers + packed weights + flat op list."""
 
@@ -550,41 +593,10 @@ class _Plan:
         st.H, st.W, st.ks, st.a_mode, st.act = H, W, ks, a_mode, act
         st.b_mode, st.ldb, st.N = b_mode, ldb, N
         st.B, st.heads, st.alpha = B, heads, alpha
-        # tile configuration + split-K: fill the 256 CUs (>= 512 workgroups when K allows it)
         Z = B * heads
-
-        def ok128():
-            if P % 128:
-                return False
-            if ks == 1:
-                return True
-            tw = min(W, 32)
-            th = 128 // tw
-            return th <= H and H % th == 0
-        blocks128 = (P // 128) * ((N + 127) // 128) * Z if ok128() else 0
-        cfg = 0 if (blocks128 >= 256 and N >= 96) else 1
-        wino_blocks = (H // 16) * (W // 16) * ((N + 63) // 64) * Z
-        wino_ksplit = 1
-        wino_ok = (wino and ks == 3 and b_mode == 0 and heads == 1 and a_mode in (0, 1) and H % 16 == 0 and W % 16 == 0
-                   and K % 16 == 0 and (c1 == 0 or c0 % 16 == 0) and N >= 32 and _use_winograd())
-        if wino_ok and wino_blocks < 200:
-            # small maps: split K over 16-channel chunks until one round of workgroups fills the 256 CUs, keeping
-            # >= 4 chunks per workgroup (the prologue / epilogue of a workgroup cost about two chunks)
-            wch = K // 16
-            wino_ksplit = int(min(max(1, wch // 4), -(-256 // wino_blocks)))
-            if N % 4 or wino_blocks * wino_ksplit < 128 or os.environ.get("ANODDPM_NO_WINOGRAD_SPLITK"):
-                wino_ok = False
-            else:
-                cps = -(-wch // wino_ksplit)
-                wino_ksplit = -(-wch // cps)                   # no empty trailing block
-        if wino_ok:
-            cfg = 2
+        cfg, ksplit = choose_conv_cfg(H, W, K, N, Z, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads, c0=c0, c1=c1,
+                                      wino=bool(wino))
         bm = 128 if cfg == 0 else 64
-        blocks = -(-P // bm) * ((N + bm - 1) // bm) * Z
-        nchunks = (K + 31) // 32
-        ksplit = wino_ksplit if cfg == 2 else 1
-        if cfg != 2 and blocks < 512 and nchunks > 1 and N % 4 == 0:
-            ksplit = int(min(nchunks, 16, max(1, -(-512 // blocks))))
         st.cfg, st.ksplit = cfg, ksplit
         _st, _bmat, _wino = self._pending_bmat
         if cfg == 2:

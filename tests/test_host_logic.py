@@ -145,3 +145,21 @@ def test_helpers_surface(tmp_path):
         assert HP.load_checkpoint("28", False, "cpu")["n_epoch"] == 1
     finally:
         os.chdir(cwd)
+
+
+def test_conv_launch_policy_on_config2_shapes():
+    """unet.choose_conv_cfg (shared by the inference plan and the training operators): the configurations the round-1
+    measurements were taken with (profiles/r1e_igemm_by_layer.csv)."""
+    from anoddpm_amd.unet import choose_conv_cfg as pick
+    Z = 4
+    assert pick(256, 256, 128, 128, Z) == (2, 1)                    # Winograd, one K slice
+    assert pick(64, 64, 256, 256, Z) == (2, 1)
+    assert pick(32, 32, 256, 256, Z) == (2, 4)                      # small map: Winograd split-K
+    assert pick(16, 16, 512, 512, Z) == (2, 8)
+    assert pick(8, 8, 512, 512, Z) == (1, 16)                       # H % 16 != 0: direct kernel, split-K
+    assert pick(128, 128, 128, 128, Z, a_mode=2) == (0, 1)          # pool-fused operand: direct 128x128 tiles
+    assert pick(256, 256, 256, 128, Z, ks=1) == (0, 1)              # 1x1 skip convolution
+    assert pick(16, 16, 512, 1536, Z, ks=1) == (1, 2)               # qkv projection
+    assert pick(256, 256, 128, 128, Z, wino=False)[0] in (0, 1)
+    cfg, ks = pick(32, 32, 768, 256, Z)
+    assert cfg == 2 and (768 // 16) % 1 == 0 and (ks - 1) * -(-(768 // 16) // ks) < 768 // 16      # no empty K slice
