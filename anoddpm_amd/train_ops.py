@@ -173,10 +173,12 @@ class FusedGNSiLUConv3x3(torch.autograd.Function):
             d_bias = d_temb.sum(dim=0)
         dW = None
         if need[3]:
+            # split-K granularity: whole rounds of the 512 resident workgroups (2 per CU), as few as fill the chip
             tiles = -(-K // 64) * -(-N // 64)
             TW = next(t for t in (32, 16, 8, 4, 2) if W % t == 0)
-            want_items = max(1, -(-768 // tiles))
-            band = max(1, min(H, (B * (W // TW) * H) // want_items))
+            per_band = tiles * B * (W // TW)
+            nband = max(1, min(H, round(512 / per_band)))
+            band = -(-H // nband)
             nitems = B * (W // TW) * -(-H // band)
             ws = _Cache.buf("wgrad", nitems * 9 * K * N, torch.float32, dev)
             dW = torch.empty((N, K, 3, 3), device=dev, dtype=torch.float32)
