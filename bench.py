@@ -39,7 +39,7 @@ CONFIGS = {
                name="64x64 base64 batch1 (BASELINE config 1 shape, on GPU)"),
 }
 T_STEPS = 1000
-MEASURED_TRAFFIC_BYTES_PER_LAUNCH = 2.105e8      # wino_kernel, profiles/r1e_pmc_hbm_by_kernel.csv, config c2 batch 4
+MEASURED_TRAFFIC_BYTES_PER_LAUNCH = 1.674e8      # wino_kernel, profiles/r1f_pmc_hbm_by_kernel.csv, config c2 batch 4
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
@@ -225,7 +225,7 @@ def main():
                     # process): (2*FETCH_SIZE + WRITE_SIZE) KB averaged over the kernel's 63 launches per step, with the
                     # guide's gfx950 FETCH_SIZE x2 correction.  Only quoted for the workload it was measured on.
                     "traffic": MEASURED_TRAFFIC_BYTES_PER_LAUNCH if (args.config == "c2" and B == 4 and dom_wino) else None,
-                    "traffic_source": "profiles/r1e_pmc_hbm_by_kernel.csv",
+                    "traffic_source": "profiles/r1f_pmc_hbm_by_kernel.csv",
                     "achieved_is": "ALGORITHMIC direct-convolution FLOPs of the kernel's launches / their HIP-event time (exceeds the executed rate: Winograd does 2.25x fewer multiplies)",
                     "executed_tflops": executed, "executed_frac": executed / PEAK_FP32_MATRIX_TFLOPS,
                     "launches_per_step": (w_n if dom_wino else d_n) / args.steps,
