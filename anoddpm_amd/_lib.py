@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 
@@ -132,7 +132,8 @@ class WgradArgs(Structure):
                 ("a0_bs", c_int64), ("a1_bs", c_int64), ("dy_bs", c_int64),
                 ("c0", c_int32), ("c1", c_int32), ("a0_ld", c_int32), ("a1_ld", c_int32), ("dy_ld", c_int32),
                 ("H", c_int32), ("W", c_int32), ("N", c_int32), ("B", c_int32),
-                ("a_mode", c_int32), ("act", c_int32), ("gn_ld", c_int32), ("band", c_int32), ("accumulate", c_int32)]
+                ("a_mode", c_int32), ("act", c_int32), ("gn_ld", c_int32), ("band", c_int32), ("accumulate", c_int32),
+                ("colsum", c_void_p)]
 
 
 class GnBwdArgs(Structure):

@@ -112,11 +112,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const anoddpm_wgrad_args 
             dreg[j] = ok ? v : zero;
         }
     };
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};                               // column sums of dY over this item's pixels (bias / temb gradient)
     auto store_dy_row = [&](int gy) {
 #pragma unroll
         for (int j = 0; j < DJ; ++j) {
             const int idx = tid + j * 256;
-            if (idx < D_F4) *reinterpret_cast<f32x4 *>(&ldsD[gy & 1][idx >> 4][q * 4]) = dreg[j];
+            if (idx < D_F4) {
+                *reinterpret_cast<f32x4 *>(&ldsD[gy & 1][idx >> 4][q * 4]) = dreg[j];
+                csum += dreg[j];
+            }
         }
     };
 
@@ -156,6 +160,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const anoddpm_wgrad_args 
                     const float av = Ar[dy][(2 * kp + dx) * AP];     // pixel x0 + 2kp + h + (dx - 1): halo index +1
                     acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[dy * 3 + dx], 0, 0, 0);
                 }
+        }
+    }
+
+    // ---- column sums: the ci-tile-0 workgroups publish sum_p dY[p][co] of their item (16 threads share a channel quad)
+    if (a.colsum && ci0 == 0) {
+        __syncthreads();
+        float *red = &ldsA[0][0][0];                                 // 256 x 4 floats of scratch
+        *reinterpret_cast<f32x4 *>(red + tid * 4) = csum;
+        __syncthreads();
+        if (tid < CT) {
+            const int qq = tid >> 2, e = tid & 3;
+            float s = 0.f;
+            for (int k = 0; k < 16; ++k) s += red[(k * 16 + qq) * 4 + e];
+            if (co0 + tid < N) a.colsum[(int64_t)item * N + co0 + tid] = s;
         }
     }
 

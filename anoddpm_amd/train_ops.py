@@ -167,7 +167,8 @@ class FusedGNSiLUConv3x3(torch.autograd.Function):
         need = ctx.needs_input_grad
         has_bias, has_temb, has_res = ctx.has
         d_bias = d_temb = None
-        if (has_bias and need[4]) or (has_temb and need[5]):
+        want_sums = (has_bias and need[4]) or (has_temb and need[5])
+        if want_sums and not need[3]:
             stats, _ = _column_sums(dy, N, H * W)
             d_temb = stats[..., 0].double().sum(dim=1).float()               # [B][N]
             d_bias = d_temb.sum(dim=0)
@@ -189,7 +190,12 @@ class FusedGNSiLUConv3x3(torch.autograd.Function):
             wa.c0, wa.c1, wa.a0_ld, wa.a1_ld, wa.dy_ld = K, 0, K, 4, N
             wa.H, wa.W, wa.N, wa.B = H, W, N, B
             wa.a_mode, wa.act, wa.gn_ld, wa.band, wa.accumulate = a_mode, 1, K, band, 0
+            colsum = torch.empty((B, nitems // B, N), device=dev, dtype=torch.float32) if want_sums else None
+            wa.colsum = colsum.data_ptr() if want_sums else None
             check(lib().anoddpm_conv3x3_wgrad(ctypes.byref(wa), current_stream()), "conv3x3_wgrad")
+            if want_sums:                                                    # the kernel summed dy over each item's pixels
+                d_temb = colsum.double().sum(dim=1).float()                  # [B][N]
+                d_bias = d_temb.sum(dim=0)
         dx = dgamma = dbeta = None
         if need[0] or need[1] or need[2]:
             # data gradient w.r.t. the tensor the conv read (conv-output resolution): forward kernels on flipped weights

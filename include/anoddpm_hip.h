@@ -434,6 +434,8 @@ typedef struct anoddpm_wgrad_args {
     int32_t gn_ld;
     int32_t band;                   /* image rows per work item (split-K granularity) */
     int32_t accumulate;
+    float *colsum;                  /* optional [items][N]: per work item sum over its pixels of dy (items of one image are
+                                       consecutive: item = (b * nband + band) * nseg + segment) -> bias / embedding gradients */
 } anoddpm_wgrad_args;
 
 int anoddpm_conv3x3_wgrad(const anoddpm_wgrad_args *a, void *stream);

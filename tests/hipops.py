@@ -209,7 +209,7 @@ def head(x, w, b, scale, shift):
     return out
 
 
-def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into=None):
+def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into=None, colsum_out=None):
     """dW (OIHW) of a 3x3 conv whose input is the fused operand load of `conv_igemm` (anoddpm_conv3x3_wgrad).
     srcs: NHWC sources; dy: NHWC [B,H,W,N]."""
     from anoddpm_amd._lib import WgradArgs
@@ -234,6 +234,10 @@ def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into
     st.H, st.W, st.N, st.B = H, W, N, B
     st.a_mode, st.act, st.gn_ld, st.band = a_mode, act, K, band
     st.accumulate = 1 if accumulate_into is not None else 0
+    if colsum_out is not None:
+        cs = torch.full((B, nitems // B, N), float("nan"), device=dev)
+        st.colsum = cs.data_ptr()
+        colsum_out.append(cs)
     check(lib().anoddpm_conv3x3_wgrad(ctypes.byref(st), current_stream()), "conv3x3_wgrad")
     torch.cuda.synchronize()
     return dw

@@ -328,8 +328,11 @@ def test_conv3x3_wgrad(case):
     srcs = [xs[..., :c0].contiguous()] + ([xs[..., c0:].contiguous()] if c1 else [])
     gn = hipops.gn_affine(srcs, gamma.to(dev()), beta.to(dev())) if fused else None
     dyn = hipops.nhwc(dy.to(dev())).contiguous()
-    got = hipops.conv_wgrad(srcs, dyn, gn=gn, act=1 if fused else 0, a_mode=a_mode, band=7 if Hout == 48 else None)
+    cs = []
+    got = hipops.conv_wgrad(srcs, dyn, gn=gn, act=1 if fused else 0, a_mode=a_mode, band=7 if Hout == 48 else None, colsum_out=cs)
     assert got.shape == dw_ref.shape
+    # the fused column sums of dY (bias / embedding gradients): per image sum over pixels
+    assert relerr(cs[0].sum(dim=1), dy.sum(dim=(2, 3))) < 1e-5
     assert relerr(got, dw_ref) < 2e-5, relerr(got, dw_ref)
     # accumulate mode adds into an existing gradient (two micro-batches of the same data = 2x)
     acc = got.clone()
