@@ -58,3 +58,30 @@ def test_perm_init_matches_reference_tables():
         assert (tab[:256] == p).all() and (tab[256:] == g).all()
     # python ints outside int64 wrap like c_int64 (simplex.py:166-171)
     assert (perm_tables(2 ** 64 + 3) == perm_tables(3)).all()
+
+
+def test_header_is_plain_c_and_declares_what_the_library_exports(tmp_path):
+    """include/anoddpm_hip.h must compile as C99 (it is the drop-in boundary: plain pointers and sizes, no C++ / torch
+    types), and a C translation unit that references every declared entry point must link against the library."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "anoddpm_hip.h")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], check=True)
+    names = header_symbols()
+    assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
+    src = tmp_path / "use_all.c"
+    src.write_text('#include "anoddpm_hip.h"\n#include <stdio.h>\nint main(void) {\n  void *p[] = {\n' +
+                   "".join(f"    (void *)&{n},\n" for n in names) +
+                   '  };\n  printf("%d %d\\n", (int)(sizeof p / sizeof p[0]), anoddpm_abi_version());\n  return 0;\n}\n')
+    exe = tmp_path / "use_all"
+    libdir = os.path.dirname(_lib.SO_PATH)
+    if not os.path.exists(_lib.SO_PATH):
+        pytest.skip("library not built")
+    r = subprocess.run([gcc, "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-lanoddpm_hip", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
