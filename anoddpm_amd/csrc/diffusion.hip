@@ -18,7 +18,12 @@ __global__ __launch_bounds__(256) void q_sample_kernel(float *__restrict__ out, 
     const int b = blockIdx.y;
     long long ti = t[b];
     ti = ti < 0 ? ti + T : ti;                       // python-style negative index
-    const float a = ca[ti], c = cb[ti];
+    // the reference's extract() raises IndexError for t outside [-T, T); a kernel cannot raise, so it never reads out
+    // of bounds and poisons the sample with NaN instead (the host wrappers validate host-built t, see diffusion.py)
+    const bool bad = ti < 0 || ti >= T;
+    ti = bad ? 0 : ti;
+    const float qnan = __builtin_nanf("");
+    const float a = bad ? qnan : ca[ti], c = bad ? qnan : cb[ti];
     const int64_t base = (int64_t)b * n;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC; i < n; i += (int64_t)gridDim.x * 256 * VEC) {
         if (VEC == 4) {
@@ -57,8 +62,10 @@ __global__ __launch_bounds__(256) void p_update_kernel(anoddpm_p_update_args a)
     long long ti = a.t[b];
     const bool nonzero = (ti != 0);
     ti = ti < 0 ? ti + a.T : ti;
+    const bool bad = ti < 0 || ti >= a.T;            // out of range: no out-of-bounds read, NaN result (see q_sample_kernel)
+    ti = bad ? 0 : ti;
     StepCoef k;
-    k.recip = a.c_recip[ti];
+    k.recip = bad ? __builtin_nanf("") : a.c_recip[ti];
     k.recipm1 = a.c_recipm1[ti];
     k.coef1 = a.c_coef1[ti];
     k.coef2 = a.c_coef2[ti];
@@ -117,7 +124,9 @@ __global__ __launch_bounds__(256) void vlb_kernel(anoddpm_vlb_args a, double *__
     long long ti = a.t[b];
     const bool t0 = (ti == 0);
     ti = ti < 0 ? ti + a.T : ti;
-    const float recip = a.c_recip[ti], recipm1 = a.c_recipm1[ti], coef1 = a.c_coef1[ti], coef2 = a.c_coef2[ti];
+    const bool bad = ti < 0 || ti >= a.T;            // out of range: no out-of-bounds read, NaN result (see q_sample_kernel)
+    ti = bad ? 0 : ti;
+    const float recip = bad ? __builtin_nanf("") : a.c_recip[ti], recipm1 = a.c_recipm1[ti], coef1 = a.c_coef1[ti], coef2 = a.c_coef2[ti];
     const float lv1 = a.c_post_logvar[ti], lv2 = a.c_model_logvar[ti];
     const float kbase = (-1.0f + lv2) - lv1;                    // -1 + logvar2 - logvar1
     const float e1 = expf(lv1 - lv2), e2 = expf(-lv2);

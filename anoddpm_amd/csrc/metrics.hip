@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void anomaly_kernel(anoddpm_anomaly_args a, do
     double c[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i) c[i] = 0.0;
+    c[10] = -INFINITY;                                  // running max(real): images may be all-negative
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
         // torch.mean over dim 0: sequential fp32 sum in index order, then one multiply by 1/navg would differ from
         // ATen's sum/N by an ulp for non-power-of-two N, so divide like ATen does.

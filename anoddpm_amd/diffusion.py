@@ -140,15 +140,13 @@ class ReverseChain:
 
     def __init__(self, owner, model, x, t_distance, denoise_fn, use_graph=None):
         _lib.require_cuda(x, "ReverseChain")
+        if not 0 <= int(t_distance) <= owner.num_timesteps:
+            # extract() of the reference indexes the T-entry tables with t_distance - 1 and raises for anything else
+            raise IndexError(f"t_distance {t_distance} is out of range for a {owner.num_timesteps}-step schedule")
         self.owner, self.model, self.denoise_fn = owner, model, denoise_fn
-        # HIP-graph replay of the step: on by default for the built-in UNetModel (every launch of a step
-        # is stream-ordered, allocation-free C-ABI work); ANODDPM_NO_GRAPH=1 forces eager launches.
         import os
         self.graph = None
         self._graph_state = 0          # 0: next step eager (warm-up), 1: capture, 2: replay
-        if use_graph is None:
-            use_graph = hasattr(model, "forward_hip") and os.environ.get("ANODDPM_NO_GRAPH", "0") != "1"
-        self.use_graph = bool(use_graph)
         self.B = x.shape[0]
         self.x = owner._f32(x.detach()).clone()
         self.t = torch.full((self.B,), t_distance - 1, device=x.device, dtype=torch.int64)
@@ -157,10 +155,29 @@ class ReverseChain:
         self.hip_model = hasattr(model, "forward_hip")
         self.noise = None
         self.tables = None
+        # Which noise sources may run inside a captured HIP graph: device-side philox draws ("gauss" / "random":
+        # torch.randn_like registers its generator state with the capture) and SimplexNoiseFn, whose per-step seeds are
+        # drawn up front and whose tables are selected by the device-resident step counter.  Anything else -- a plain
+        # callable, a user-replaced `noise_fn`, the randParam / random mixtures -- draws from numpy / `random` on the
+        # host every step (newSeed(), GaussianDiffusion.py:102) and uploads a table: captured once, every replay
+        # would reuse the first step's seed.  Those run eagerly.
         fn = denoise_fn
-        if type(fn) == str and fn not in ("gauss", "noise_fn", "random"):
-            fn = SimplexNoiseFn(owner.simplex, in_channels=owner.img_channels)      # :310 defaults
+        capture_safe = False
+        if type(fn) == str:
+            if fn in ("gauss", "random"):
+                capture_safe = True
+            elif fn == "noise_fn":
+                nf = owner.noise_fn
+                if isinstance(nf, SimplexNoiseFn):
+                    fn = nf
+                elif nf is getattr(owner, "_default_noise_fn", None) and owner.noise_kind == "gauss":
+                    capture_safe = True                                      # torch.randn_like
+                elif nf is getattr(owner, "_default_noise_fn", None) and owner.noise_kind not in ("simplex_randParam", "random"):
+                    fn = SimplexNoiseFn(owner.simplex, in_channels=owner.img_channels)      # :179-181 defaults
+            else:
+                fn = SimplexNoiseFn(owner.simplex, in_channels=owner.img_channels)          # :310 defaults
         if isinstance(fn, SimplexNoiseFn):
+            capture_safe = True
             # draw every seed of the chain now, in the order the per-step newSeed() calls would
             C = fn.in_channels
             tabs = np.empty((self.remaining * C, 512), dtype=np.int16)
@@ -172,6 +189,16 @@ class ReverseChain:
             self.tables = torch.from_numpy(tabs).to(x.device)
             self.simplex_fn = fn
             self.noise = torch.empty_like(self.x)
+        self.capture_safe = capture_safe
+        # HIP-graph replay of the step: on by default for the built-in UNetModel (every launch of a step is
+        # stream-ordered, allocation-free C-ABI work) with a capture-safe noise source; ANODDPM_NO_GRAPH=1 forces
+        # eager launches.  An explicit use_graph=True with an unsafe noise source is refused, not silently wrong.
+        if use_graph is None:
+            use_graph = self.hip_model and capture_safe and os.environ.get("ANODDPM_NO_GRAPH", "0") != "1"
+        elif use_graph and not capture_safe:
+            raise ValueError("ReverseChain(use_graph=True): this denoise_fn draws host-side random numbers every step "
+                             "and cannot be replayed from a captured graph; pass a SimplexNoiseFn or 'gauss'")
+        self.use_graph = bool(use_graph)
 
     def step(self):
         if self.use_graph and lib().anoddpm_prof_active() == 0:
@@ -252,6 +279,7 @@ class GaussianDiffusionModel:
             else:
                 self.noise_fn = lambda x, t: generate_simplex_noise(self.simplex, x, t, False, in_channels=img_channels)
         self.noise_kind = noise
+        self._default_noise_fn = self.noise_fn      # lets the reverse chain tell a user-replaced noise_fn from this one
 
         self.img_size = img_size
         self.img_channels = img_channels
@@ -567,7 +595,9 @@ class GaussianDiffusionModel:
         output = torch.empty((6 * end_freq, 1, *args["img_size"]), device=x_0.device)
         for i in range(1, end_freq + 1):
             freq = 2 ** i
-            noise_fn = lambda x, t: generate_simplex_noise(self.simplex, x, t, False, frequency=freq).float()
+            # == lambda x, t: generate_simplex_noise(self.simplex, x, t, False, frequency=freq).float()   (:602), as an
+            # object the reverse chain recognises (per-step seeds pre-drawn in the same numpy-stream order)
+            noise_fn = SimplexNoiseFn(self.simplex, frequency=freq)
             t_tensor = torch.tensor([t_distance - 1], device=x_0.device).repeat(x_0.shape[0])
             x = self.sample_q(x_0, t_tensor, noise_fn(x_0, t_tensor).float())
             x_noised = x.clone().detach()
@@ -637,10 +667,7 @@ class GaussianDiffusionModel:
         self.last_detection = []
         for i in range(7, 0, -1):
             freq = 2 ** i
-            self.noise_fn = lambda x, t: generate_simplex_noise(
-                    self.simplex, x, t, False, frequency=freq,
-                    in_channels=self.img_channels
-                    )
+            self.noise_fn = SimplexNoiseFn(self.simplex, frequency=freq, in_channels=self.img_channels)     # :491-494
             for t_distance in range(50, int(args["T"] * 0.6), 50):
                 output = self._avg_chains(model, x_0, t_distance, total_avg)
                 rec, maps = self._detection_record(x_0, output, mask, {"freq": i, "t_distance": t_distance})
@@ -662,10 +689,7 @@ class GaussianDiffusionModel:
             self._figure_dirs([base, f"{base}/{file[1]}", f"{base}/{file[1]}/{denoise_fn}"])
         if denoise_fn == "octave":
             end = int(args["T"] * 0.6)
-            self.noise_fn = lambda x, t: generate_simplex_noise(
-                    self.simplex, x, t, False, frequency=64, octave=6,
-                    persistence=0.8
-                    ).float()
+            self.noise_fn = SimplexNoiseFn(self.simplex, octave=6, persistence=0.8, frequency=64)           # :547-550
         else:
             end = int(args["T"] * 0.8)
             self.noise_fn = lambda x, t: torch.randn_like(x)

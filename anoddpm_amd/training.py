@@ -45,6 +45,8 @@ class FlatBuffers:
     so state_dict / load_state_dict / checkpoints keep working unchanged."""
 
     def __init__(self, module):
+        self.module = module          # owner: told when a raw kernel rewrites the flat buffer (mark_weights_changed)
+        self.names = [k for k, p in module.named_parameters() if p.requires_grad]
         self.params = [p for p in module.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("module has no trainable parameters")
@@ -143,9 +145,18 @@ class FusedAdamWEMA:
                  ema_decay=0.9999, max_norm=1.0, notify=()):
         _lib.require_cuda(flat.flat_param, "FusedAdamWEMA")
         self.flat, self.ema_flat = flat, ema_flat
+        if ema_flat is not None and (ema_flat.numel != flat.numel or ema_flat.offsets != flat.offsets):
+            # the kernel walks both flat buffers with ONE index: a differently laid-out EMA copy (e.g. frozen
+            # parameters on one side) would be updated at the wrong offsets or out of bounds
+            raise ValueError("FusedAdamWEMA: the EMA module's flat layout differs from the trained module's")
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.ema_decay, self.max_norm = ema_decay, max_norm
-        self.notify = list(notify)          # modules whose packed-weight caches must be refreshed (UNetModel)
+        # modules whose packed-weight caches must be refreshed after the raw kernel wrote their parameters behind
+        # autograd's back: the owners of both flat buffers, plus anything the caller adds
+        self.notify = []
+        for mod in [flat.module, ema_flat.module if ema_flat is not None else None, *notify]:
+            if mod is not None and hasattr(mod, "mark_weights_changed") and all(mod is not m for m in self.notify):
+                self.notify.append(mod)
         self.m = torch.zeros_like(flat.flat_param)
         self.v = torch.zeros_like(flat.flat_param)
         self.step_count = 0
@@ -176,6 +187,51 @@ class FusedAdamWEMA:
         for mod in self.notify:                 # the raw kernel bypasses autograd's version counters
             mod.mark_weights_changed()
         return self.last_norm
+
+    # -- checkpoint format of the reference: torch.optim.AdamW's state_dict (diffusion_training.py:77,173,184) --------
+    def state_dict(self):
+        """The layout `torch.optim.AdamW.state_dict()` produces for the same parameter list: per-parameter `step`,
+        `exp_avg`, `exp_avg_sq` sliced out of the flat moment buffers, one param group."""
+        f = self.flat
+        state = {}
+        if self.step_count > 0:
+            for i, (p, o) in enumerate(zip(f.params, f.offsets)):
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.m[o:o + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.v[o:o + n].view(p.shape).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": True, "params": list(range(len(f.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        """Accepts a `torch.optim.AdamW` state_dict (e.g. `resume["optimizer_state_dict"]` of a reference checkpoint)."""
+        f = self.flat
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(f.params):
+            raise ValueError("FusedAdamWEMA.load_state_dict: expected one param group covering every parameter")
+        g = groups[0]
+        if g.get("amsgrad") or g.get("maximize"):
+            raise ValueError("FusedAdamWEMA.load_state_dict: amsgrad / maximize are not supported")
+        self.lr, self.betas, self.eps, self.wd = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        self.m.zero_()
+        self.v.zero_()
+        steps = set()
+        for idx, pid in enumerate(g["params"]):
+            st = sd["state"].get(pid)
+            if st is None:
+                continue
+            p, o = f.params[idx], f.offsets[idx]
+            n = p.numel()
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"FusedAdamWEMA.load_state_dict: moment shape mismatch for parameter {idx}")
+            self.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("FusedAdamWEMA.load_state_dict: parameters carry different step counts")
+        self.step_count = steps.pop() if steps else 0
 
 
 def train_step(model, diffusion, x, args, flat, reducer, optim):

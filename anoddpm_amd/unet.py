@@ -460,6 +460,7 @@ class _Plan:
         self._ws_need = 0
         self.stats_of = {}
         self.igemm_log = []
+        self.block_out = {}      # block prefix -> (NHWC buffer [B][H*W][C], C, H): layer-wise parity tests read these
         with torch.no_grad():
             self._build()
         n = len(self.ops)
@@ -780,6 +781,7 @@ class _Plan:
                 else:
                     h = attn_block(prefix, srcs[0][0], Hc, cin)
                     srcs = [(h, cin)]
+                self.block_out[prefix] = (srcs[0][0], srcs[0][1], Hc)
             return srcs, Hc
 
         Hc = S

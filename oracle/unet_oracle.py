@@ -200,19 +200,20 @@ def attention_block(sd, p, x, n_heads, n_head_channels):
     return (xf + a).reshape(b, c, hh, ww)
 
 
-@torch.no_grad()
-def forward(sd, x, t, img_size, base_channels, channel_mults="", num_res_blocks=2,
-            attention_resolutions="32,16,8", in_channels=1, n_heads=1, n_head_channels=-1,
-            record=None):
+def forward_autograd(sd, x, t, img_size, base_channels, channel_mults="", num_res_blocks=2,
+                     attention_resolutions="32,16,8", in_channels=1, n_heads=1, n_head_channels=-1,
+                     record=None):
     """Returns the model output; if `record` is a dict it receives per-block activations
-    keyed by block prefix (NCHW fp32) for layer-wise parity checks."""
+    keyed by block prefix (NCHW fp32) for layer-wise parity checks.  Autograd is left on: with
+    `requires_grad` leaves in `sd` this is the CPU checker for the training gradients
+    (diffusion_training.py:102, pinned by tests/golden/train_*.npz)."""
     lay = layout(img_size, base_channels, channel_mults, num_res_blocks, attention_resolutions,
                  in_channels)
     temb = timestep_features(t, base_channels)
     temb = F.linear(temb, sd["time_embedding.1.weight"], sd["time_embedding.1.bias"])
     temb = F.linear(F.silu(temb), sd["time_embedding.3.weight"], sd["time_embedding.3.bias"])
     if record is not None:
-        record["time_embed"] = temb.clone()
+        record["time_embed"] = temb.detach().clone()
 
     def run(blocks, h):
         for (p, kind, cin, cout, resample) in blocks:
@@ -223,7 +224,7 @@ def forward(sd, x, t, img_size, base_channels, channel_mults="", num_res_blocks=
             else:
                 h = attention_block(sd, p, h, n_heads, n_head_channels)
             if record is not None:
-                record[p] = h.clone()
+                record[p] = h.detach().clone()
         return h
 
     h = x.float()
@@ -236,6 +237,22 @@ def forward(sd, x, t, img_size, base_channels, channel_mults="", num_res_blocks=
         h = run(blk, torch.cat([h, skips.pop()], dim=1))
     h = F.silu(_gn(sd, "out.0", h))
     return F.conv2d(h, sd["out.2.weight"], sd["out.2.bias"], padding=1)
+
+
+@torch.no_grad()
+def forward(sd, x, t, *a, **k):
+    """Inference form of `forward_autograd` (no autograd graph)."""
+    return forward_autograd(sd, x, t, *a, **k)
+
+
+def perturb(sd, scale=0.02, salt="train"):
+    """Deterministic perturbation of a filled state-dict (RandomState(crc32(key + salt))): moves every tensor off
+    special values so that each parameter receives a non-trivial gradient in the training fixtures."""
+    out = {}
+    for key, v in sd.items():
+        rs = np.random.RandomState(zlib.crc32((key + salt).encode()) & 0xFFFFFFFF)
+        out[key] = v + torch.from_numpy((scale * rs.standard_normal(tuple(v.shape))).astype(np.float32))
+    return out
 
 
 def flops_per_image(img_size, base_channels, channel_mults="", num_res_blocks=2,

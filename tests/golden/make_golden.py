@@ -11,6 +11,11 @@ recipe from SURVEY.md 8c).  Outputs are DATA (inputs + expected outputs), never 
     metrics_kat.npz      evaluation.py metrics + the mean / mse / threshold images of detection_A/B
     simplex2_kat.npz     2-D noise2 point KATs (bit patterns), a coordinate grid, octave fields
     vlb_kat.npz          calc_vlb_xt (KL and decoder-NLL branches) and the MSE curves of calc_total_vlb
+    train_<name>.npz     two optimiser steps of the reference loop body (diffusion_training.py:99-107): p_loss scalars,
+                         gradient probes / norms of every parameter, parameter + EMA probes after each step
+    detection_fixedT.npz detection_A_fixedT (GaussianDiffusion.py:596-623) on a 32^2 model, seeded numpy stream
+    mri_loader.npz       MRIDataset normalisation + slice (dataset.py:585-594, 621-625) and the deterministic part of
+                         its transform (centre-crop 235, bilinear resize, scale; torchvision -> PIL) on a synthetic volume
 """
 import os
 import sys
@@ -242,6 +247,108 @@ def gen_unet(only=None):
     print("unet_c2_256_b128.npz params", int(out["n_params"]), "|y| mean", float(np.abs(out["y"]).mean()))
 
 
+def gen_unet_c5():
+    """BASELINE config 5: 512^2, base 128, mults (1,1,2,2,4,4), attention at 32/16/8, two heads; batch 1."""
+    kw = dict(img_size=512, base_channels=128, n_heads=2, channel_mults=(1, 1, 2, 2, 4, 4), attention_resolutions="32,16,8")
+    out = run_unet_case("c5_512_b128", kw, 1, [777], probes=True)
+    out.pop("keys"); out.pop("key_shapes")
+    out["x"] = out["x"].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "unet_c5_512_b128.npz"), **out)
+    print("unet_c5_512_b128.npz params", int(out["n_params"]), "|y| mean", float(np.abs(out["y"]).mean()))
+
+
+TRAIN_CASES = {
+    # name: (ctor kwargs, batch, optimiser kwargs, [t per step])
+    # base 64 -> two channels per GroupNorm group at the first level: no parameter has an identically-zero gradient
+    "i64_b64_h2": (dict(img_size=64, base_channels=64, n_heads=2, attention_resolutions="16,8"), 2,
+                   dict(lr=1e-4, weight_decay=0.0), [[17, 640], [799, 3]]),
+    "i128_b32_hc32": (dict(img_size=128, base_channels=32, n_head_channels=32, attention_resolutions="16,8"), 2,
+                      dict(lr=2e-4, weight_decay=0.01), [[250, 0], [31, 555]]),
+}
+
+
+def _probe(v, n=256):
+    f = v.detach().flatten()
+    stride = max(1, f.numel() // n)
+    return f[::stride][:n].numpy().copy()
+
+
+def gen_training(only=None):
+    """The reference training loop body, run by the reference's own classes (diffusion_training.py:99-107):
+       loss, est = diffusion.p_loss(model, x, args); optimiser.zero_grad(); loss.backward();
+       clip_grad_norm_(model.parameters(), 1); optimiser.step(); update_ema_params(ema, model)
+    with the three random draws injected: `t` (torch.randint inside p_loss is patched), the forward noise
+    (diffusion.noise_fn) and the data batch."""
+    import copy
+    from unittest import mock
+    for name, (kw, B, okw, tsteps) in TRAIN_CASES.items():
+        if only and name not in only:
+            continue
+        S = kw["img_size"]
+        model = ref_unet.UNetModel(**kw)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        sd = unet_oracle.perturb(unet_oracle.fill_deterministic(shapes))
+        model.load_state_dict(sd)
+        model.train()
+        ema = copy.deepcopy(model)
+        opt = torch.optim.AdamW(model.parameters(), betas=(0.9, 0.999), **okw)          # diffusion_training.py:75
+        diff = ref_gd.GaussianDiffusionModel([S, S], ref_gd.get_beta_schedule(1000, "linear"), loss_type="l2", noise="gauss")
+        args = {"train_start": True, "sample_distance": 800, "Batch_Size": B}
+        g = torch.Generator().manual_seed(zlib.crc32(("train" + name).encode()))
+        out = {"lr": np.float64(okw["lr"]), "weight_decay": np.float64(okw["weight_decay"]),
+               "keys": np.array(list(shapes.keys()))}
+        for step, ts in enumerate(tsteps):
+            x0 = torch.rand(B, 1, S, S, generator=g) * 2 - 1
+            noise = torch.randn(B, 1, S, S, generator=g)
+            t = torch.tensor(ts)
+            diff.noise_fn = lambda a, b, _n=noise: _n
+            with mock.patch.object(torch, "randint", lambda *a, **k: t.clone()):
+                loss, est = diff.p_loss(model, x0, args)
+            opt.zero_grad()
+            loss.backward()
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+            norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1)
+            opt.step()
+            ref_unet.update_ema_params(ema, model)
+            out[f"s{step}/x0"], out[f"s{step}/noise"], out[f"s{step}/t"] = x0.numpy(), noise.numpy(), t.numpy()
+            out[f"s{step}/loss"] = np.float64(loss.item())
+            out[f"s{step}/x_t"] = _probe(est[1], 1024)
+            out[f"s{step}/eps"] = _probe(est[2], 1024)
+            out[f"s{step}/grad_norm"] = np.float64(norm.item())
+            out[f"s{step}/gnorm"] = np.array([grads[k].double().norm().item() for k in shapes], dtype=np.float64)
+            out[f"s{step}/gprobe"] = np.stack([np.resize(_probe(grads[k]), 256) for k in shapes])
+            params, emas = dict(model.named_parameters()), dict(ema.named_parameters())
+            out[f"s{step}/pprobe"] = np.stack([np.resize(_probe(params[k]), 256) for k in shapes])
+            out[f"s{step}/eprobe"] = np.stack([np.resize(_probe(emas[k]), 256) for k in shapes])
+            out[f"s{step}/psum"] = np.array([params[k].detach().double().sum().item() for k in shapes], dtype=np.float64)
+            print(f"train_{name} step {step}: loss {loss.item():.6f} |g| {norm.item():.4f}")
+        out["p0probe"] = np.stack([np.resize(_probe(sd[k]), 256) for k in shapes])
+        np.savez_compressed(os.path.join(HERE, f"train_{name}.npz"), **out)
+        print(f"train_{name}.npz", len(out), "arrays")
+
+
+def gen_detection():
+    """detection_A_fixedT (GaussianDiffusion.py:596-623) run by the reference on a 32^2 model: 250-step chains with
+    simplex noise at frequencies 2 and 4 in both directions; every random draw comes from the seeded global numpy
+    stream (Simplex_CLASS.newSeed), so the routine is reproducible draw for draw."""
+    kw = dict(img_size=32, base_channels=32, n_heads=2, attention_resolutions="16,8")
+    model = ref_unet.UNetModel(**kw)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(unet_oracle.fill_deterministic(shapes))
+    model.eval()
+    d = ref_gd.GaussianDiffusionModel([32, 32], ref_gd.get_beta_schedule(1000, "linear"), noise="simplex")
+    g = torch.Generator().manual_seed(4242)
+    x0 = (torch.rand(1, 1, 32, 32, generator=g) * 2 - 1)
+    mask = (torch.rand(1, 1, 32, 32, generator=g) > 0.8).float()
+    np.random.seed(20260927)
+    out = d.detection_A_fixedT(model, x0, {"img_size": [32, 32]}, mask, end_freq=2)
+    after = np.random.randint(-10000000000, 10000000000)          # position of the numpy stream after the call
+    np.savez_compressed(os.path.join(HERE, "detection_fixedT.npz"), x0=x0.numpy(), mask=mask.numpy(),
+                        output=out.numpy(), np_seed=np.int64(20260927), end_freq=np.int64(2),
+                        next_randint=np.int64(after))
+    print("detection_fixedT.npz", out.shape, float(out.abs().mean()))
+
+
 def gen_metrics():
     """Anomaly-map arithmetic and segmentation metrics: the reference's evaluation.py functions (called) and the
     inline tensor expressions of GaussianDiffusion.py:572, 581-583 / detection.py:229-232 (evaluated with torch CPU)."""
@@ -321,7 +428,8 @@ def gen_simplex2():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["simplex", "diffusion", "unet", "metrics", "vlb", "simplex2"]
+    which = sys.argv[1:] or ["simplex", "diffusion", "unet", "metrics", "vlb", "simplex2", "unet_c5", "training",
+                             "detection", "loader"]
     torch.set_num_threads(8)
     if "simplex" in which:
         gen_simplex()
@@ -337,3 +445,13 @@ if __name__ == "__main__":
         gen_vlb()
     if "simplex2" in which:
         gen_simplex2()
+    if "unet_c5" in which:
+        gen_unet_c5()
+    if "training" in which:
+        gen_training()
+    if any(w.startswith("training:") for w in which):
+        gen_training([w.split(":", 1)[1] for w in which if w.startswith("training:")])
+    if "detection" in which:
+        gen_detection()
+    if "loader" in which:
+        gen_loader()

@@ -103,3 +103,74 @@ def test_detection_A_frequency_sweep(tmp_path, monkeypatch):
     assert all(torch.isfinite(r["output"]).all() and r["output"].abs().max() <= 1.0 + 1e-6 for r in recs)
     with pytest.raises(ValueError):
         d._avg_chains(m, x_0.repeat(2, 1, 1, 1), 5, 2)
+
+
+def test_detection_A_fixedT_matches_reference_fixture():
+    """detection_A_fixedT (GaussianDiffusion.py:596-623) against the reference's own output on CPU
+    (tests/golden/detection_fixedT.npz): two frequencies x (forward simplex noise + a 250-step simplex reverse chain),
+    every draw from the seeded numpy stream.  250 steps amplify the fp32 differences between the HIP UNet and ATen's CPU
+    kernels, so images are compared to 2e-3 and the thresholded map only away from its discontinuity."""
+    from conftest import GOLDEN
+    import GaussianDiffusion as GD
+    g = np.load(os.path.join(GOLDEN, "detection_fixedT.npz"))
+    _, m, _ = tiny()
+    d = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(1000, "linear"), noise="simplex")
+    x0, mask = torch.from_numpy(g["x0"]).to(DEV), torch.from_numpy(g["mask"]).to(DEV)
+    np.random.seed(int(g["np_seed"]))
+    out = d.detection_A_fixedT(m, x0, {"img_size": [32, 32]}, mask, end_freq=int(g["end_freq"]))
+    assert np.random.randint(-10000000000, 10000000000) == int(g["next_randint"])      # same numpy-stream consumption
+    ref = torch.from_numpy(g["output"])
+    out = out.cpu()
+    assert out.shape == ref.shape
+    for f in range(int(g["end_freq"])):
+        o, r = out[6 * f:6 * f + 6], ref[6 * f:6 * f + 6]
+        assert torch.equal(o[0], r[0]) and torch.equal(o[5], r[5])                      # x_0, mask
+        assert torch.equal(o[1], r[1]), "x_noised: sample_q of bit-exact simplex noise is bit-exact"
+        assert (o[2] - r[2]).abs().max() < 2e-3, float((o[2] - r[2]).abs().max())       # reconstruction after 250 steps
+        assert (o[3] - r[3]).abs().max() < 1e-2                                         # mse image (2*sq - 1)
+        away = r[3].abs() > 2e-2
+        assert torch.equal(o[4][away], r[4][away])                                      # threshold image
+
+
+def test_graph_capture_only_for_capture_safe_noise():
+    """Only device-side / pre-drawn noise sources may be replayed from a captured graph; host-RNG callables run eagerly
+    (a captured newSeed() + table upload would repeat the first step's seed on every replay)."""
+    GD, m, _ = tiny()
+    d = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(1000, "linear"), noise="simplex")
+    x = torch.rand(1, 1, 32, 32, device=DEV) * 2 - 1
+    lam = lambda xx, tt: GD.generate_simplex_noise(d.simplex, xx, tt, False, frequency=8).float()
+    assert GD.ReverseChain(d, m, x, 4, lam).use_graph is False
+    assert GD.ReverseChain(d, m, x, 4, "gauss").use_graph is True
+    assert GD.ReverseChain(d, m, x, 4, "simplex").use_graph is True
+    assert GD.ReverseChain(d, m, x, 4, "noise_fn").use_graph is True               # default simplex noise_fn -> SimplexNoiseFn
+    d.noise_fn = lam                                                                # user-replaced noise_fn: host RNG
+    assert GD.ReverseChain(d, m, x, 4, "noise_fn").use_graph is False
+    with pytest.raises(ValueError):
+        GD.ReverseChain(d, m, x, 4, lam, use_graph=True)
+    d2 = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(1000, "linear"), noise="simplex_randParam")
+    assert GD.ReverseChain(d2, m, x, 4, "noise_fn").use_graph is False
+    # "noise_fn" on a simplex diffusion: graph replay == eager launches == the per-step callable, draw for draw
+    d = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(1000, "linear"), noise="simplex")
+    outs = []
+    for mode in ("graph", "eager", "callable"):
+        np.random.seed(21)
+        fn = "noise_fn" if mode != "callable" else (lambda xx, tt: GD.generate_simplex_noise(d.simplex, xx, tt, False).float())
+        ch = GD.ReverseChain(d, m, x, 6, fn, use_graph=(True if mode == "graph" else False))
+        for _ in range(6):
+            ch.step()
+        ch.finish()
+        outs.append((ch.x.clone(), np.random.randint(0, 1 << 30)))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[2][0])
+    assert outs[0][1] == outs[1][1] == outs[2][1]
+
+
+def test_out_of_range_t_distance_raises_like_extract():
+    GD, m, d = tiny()                                                # 100-step schedule
+    x = torch.rand(1, 1, 32, 32, device=DEV)
+    with pytest.raises(IndexError):
+        GD.ReverseChain(d, m, x, 101, "gauss")
+    # the kernels themselves never read past the tables: out-of-range t poisons the sample instead
+    bad = d.sample_q(x, torch.tensor([100], device=DEV), torch.zeros_like(x))
+    assert torch.isnan(bad).all()
+    ok = d.sample_q(x, torch.tensor([-1], device=DEV), torch.zeros_like(x))       # python-style negative index, as numpy
+    assert torch.equal(ok, d.sample_q(x, torch.tensor([99], device=DEV), torch.zeros_like(x)))

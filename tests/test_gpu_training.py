@@ -36,6 +36,75 @@ def test_fused_adamw_ema_matches_torch_reference():
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
 
 
+def test_optimizer_state_dict_is_torch_adamw_layout():
+    """FusedAdamWEMA.state_dict() loads into torch.optim.AdamW and vice versa (the reference checkpoints store
+    optimiser.state_dict(), diffusion_training.py:173,184, and resume from it, :77): after the exchange both
+    optimisers take the same next step."""
+    from anoddpm_amd.training import FlatBuffers, FusedAdamWEMA
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(19, 32), torch.nn.SiLU(), torch.nn.Linear(32, 3)).to(DEV)
+    flat = FlatBuffers(net)
+    opt = FusedAdamWEMA(flat, None, lr=1e-3, weight_decay=0.01, max_norm=None)
+    xs = [torch.randn(8, 19, device=DEV) for _ in range(4)]
+    for x in xs[:2]:
+        flat.zero_grad()
+        net(x).square().mean().backward()
+        opt.step()
+    sd = opt.state_dict()
+    ref = copy.deepcopy(net)
+    opt_ref = torch.optim.AdamW(ref.parameters(), lr=5.0)            # hyper-parameters come from the loaded state
+    opt_ref.load_state_dict(sd)
+    assert opt_ref.param_groups[0]["lr"] == 1e-3 and opt_ref.param_groups[0]["weight_decay"] == 0.01
+    flat.zero_grad()
+    net(xs[2]).square().mean().backward()
+    opt.step()
+    opt_ref.zero_grad()
+    ref(xs[2]).square().mean().backward()
+    opt_ref.step()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    # and back: torch's state into a fresh fused optimiser
+    net2 = copy.deepcopy(ref)
+    flat2 = FlatBuffers(net2)
+    opt2 = FusedAdamWEMA(flat2, None, lr=7.0, max_norm=None)
+    opt2.load_state_dict(opt_ref.state_dict())
+    assert opt2.step_count == 3 and opt2.lr == 1e-3
+    flat2.zero_grad()
+    net2(xs[3]).square().mean().backward()
+    opt2.step()
+    opt_ref.zero_grad()
+    ref(xs[3]).square().mean().backward()
+    opt_ref.step()
+    for a, b in zip(net2.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_fused_optimizer_refreshes_owners_without_notify_and_checks_layout():
+    import GaussianDiffusion as GD
+    from UNet import UNetModel
+    from anoddpm_amd.training import FlatBuffers, FusedAdamWEMA, train_step
+    torch.manual_seed(2)
+    model = UNetModel(32, 32, n_heads=2, attention_resolutions="16,8").to(DEV)
+    ema = copy.deepcopy(model)
+    flat, flat_ema = FlatBuffers(model), FlatBuffers(ema)
+    opt = FusedAdamWEMA(flat, flat_ema, lr=5e-3, ema_decay=0.5)             # no notify=: the owners are found from the flats
+    diff = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(1000, "linear"), noise="gauss")
+    x = torch.rand(2, 1, 32, 32, device=DEV) * 2 - 1
+    t = torch.tensor([5, 300], device=DEV)
+    with torch.no_grad():
+        y0, e0 = model(x, t).clone(), ema(x, t).clone()                      # plans + packed weights now cached
+    train_step(model, diff, x, {"train_start": False}, flat, None, opt)
+    with torch.no_grad():
+        y1, e1 = model(x, t), ema(x, t)
+    assert not torch.equal(y0, y1) and not torch.equal(e0, e1), "stale packed weights after the raw optimiser kernel"
+    yg = model(x, t)                                                         # differentiable path reads the parameters directly
+    assert ((yg.detach() - y1).abs().max() / y1.abs().max().clamp_min(1e-6)) < 1e-3
+    frozen = copy.deepcopy(model)
+    next(frozen.parameters()).requires_grad_(False)
+    with pytest.raises(ValueError):
+        FusedAdamWEMA(flat, FlatBuffers(frozen))
+
+
 def test_train_step_decreases_loss_and_refreshes_hip_plan():
     import GaussianDiffusion as GD
     from UNet import UNetModel
@@ -66,9 +135,56 @@ def test_train_step_decreases_loss_and_refreshes_hip_plan():
     assert ((yg.detach() - yt).abs().max() / yt.abs().max().clamp_min(1e-6)) < 1e-3
 
 
-@pytest.mark.parametrize("kw", [dict(img_size=32, base_channels=32, n_heads=2, attention_resolutions="16,8"),
-                                dict(img_size=64, base_channels=32, n_heads=1)])
-def test_native_backward_matches_torch_autograd(kw, monkeypatch):
+@pytest.mark.parametrize("name", ["i64_b64_h2", "i128_b32_hc32"])
+def test_train_step_matches_reference_fixture(name, monkeypatch):
+    """Two optimiser steps of the reference's own loop body (diffusion_training.py:99-107, run by the reference's classes
+    on CPU: tests/golden/train_*.npz) against `p_loss` -> backward (hand-written kernels) -> FusedAdamWEMA on the device,
+    with the same injected draws: loss, every parameter's gradient, the clip norm, parameters and EMA after each step."""
+    import os
+    import GaussianDiffusion as GD
+    from UNet import UNetModel
+    from anoddpm_amd.training import FlatBuffers, FusedAdamWEMA
+    from conftest import GOLDEN
+    from oracle import unet_oracle as uo
+    from test_oracle_training import CASES, check_against_fixture
+    g = np.load(os.path.join(GOLDEN, f"train_{name}.npz"))
+    kw = CASES[name]
+    S = kw["img_size"]
+    model = UNetModel(**kw)
+    keys = [str(k) for k in g["keys"]]
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert keys == list(shapes)
+    model.load_state_dict(uo.perturb(uo.fill_deterministic(shapes)))
+    model.to(DEV).train()
+    ema = copy.deepcopy(model)
+    flat, flat_ema = FlatBuffers(model), FlatBuffers(ema)
+    lr = float(g["lr"])
+    opt = FusedAdamWEMA(flat, flat_ema, lr=lr, weight_decay=float(g["weight_decay"]), notify=(model, ema))
+    diff = GD.GaussianDiffusionModel([S, S], GD.get_beta_schedule(1000, "linear"), loss_type="l2", noise="gauss")
+    args = {"train_start": True, "sample_distance": 800, "Batch_Size": int(g["s0/x0"].shape[0])}
+    real_randint = torch.randint
+    for step in range(2):
+        x0, noise, t = (torch.from_numpy(g[f"s{step}/{n}"]).to(DEV) for n in ("x0", "noise", "t"))
+        diff.noise_fn = lambda a, b, _n=noise: _n
+        monkeypatch.setattr(torch, "randint", lambda *a, **k: t.clone())
+        loss, (ld, x_t, eps) = diff.p_loss(model, x0, args)
+        monkeypatch.setattr(torch, "randint", real_randint)
+        flat.zero_grad()
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        norm = opt.step()
+        from test_oracle_training import probe
+        assert np.abs(probe(x_t, 1024) - g[f"s{step}/x_t"]).max() == 0           # sample_q is bit-exact
+        assert np.abs(probe(eps, 1024) - g[f"s{step}/eps"]).max() < 1e-3 * np.abs(g[f"s{step}/eps"]).max()
+        check_against_fixture(g, step, keys, loss.item(), grads, norm.item(), dict(model.named_parameters()),
+                              dict(ema.named_parameters()), lr)
+
+
+@pytest.mark.parametrize("kw,B", [(dict(img_size=32, base_channels=32, n_heads=2, attention_resolutions="16,8"), 2),
+                                  (dict(img_size=64, base_channels=32, n_heads=1), 2),
+                                  # BASELINE config 3's per-GPU share: 256^2, base 128, attention at 16/8, batch 4
+                                  (dict(img_size=256, base_channels=128, n_heads=2, attention_resolutions="16,8"), 4)])
+def test_native_backward_matches_torch_autograd(kw, B, monkeypatch):
     """The training forward/backward with the hand-written fused 3x3 blocks (train_ops.FusedGNSiLUConv3x3: Winograd /
     direct forward, wgrad, dgrad, GroupNorm+SiLU backward kernels) against the all-torch differentiable path:
     same output, same gradient for every parameter and for the input."""
@@ -83,9 +199,9 @@ def test_native_backward_matches_torch_autograd(kw, monkeypatch):
     m.load_state_dict(sd)
     m.to(DEV).train()
     S = kw["img_size"]
-    x = (torch.rand(2, 1, S, S, device=DEV) * 2 - 1).requires_grad_(True)
-    t = torch.tensor([17, 640], device=DEV)
-    tgt = torch.randn(2, 1, S, S, device=DEV)
+    x = (torch.rand(B, 1, S, S, device=DEV) * 2 - 1).requires_grad_(True)
+    t = torch.tensor([17, 640, 3, 999][:B], device=DEV)
+    tgt = torch.randn(B, 1, S, S, device=DEV)
 
     def run(torch_only):
         monkeypatch.setenv("ANODDPM_TORCH_BACKWARD", "1" if torch_only else "0")

@@ -23,6 +23,9 @@ CASES = {
     "c5like_i128_b32": dict(img_size=128, base_channels=32, n_heads=2, channel_mults=(1, 1, 2, 2, 4, 4),
                             attention_resolutions="32,16,8"),
     "c2_256_b128": dict(img_size=256, base_channels=128, n_heads=2, attention_resolutions="16,8"),
+    # BASELINE config 5: 512^2, explicit mults (1,1,2,2,4,4), attention at 32/16/8 (sequence lengths 256 / 1024 / 4096)
+    "c5_512_b128": dict(img_size=512, base_channels=128, n_heads=2, channel_mults=(1, 1, 2, 2, 4, 4),
+                        attention_resolutions="32,16,8"),
 }
 
 
@@ -55,8 +58,43 @@ def test_forward_matches_reference_output(name):
     assert torch.equal(y, y2) and y2.data_ptr() != y.data_ptr()
 
 
-def test_layerwise_against_oracle():
-    """Per-block activations of the HIP plan (NHWC buffers) vs the CPU oracle's recorded activations."""
+@pytest.mark.parametrize("name", ["i64_b32_hc32", "c5like_i128_b32", "c2_256_b128", "c5_512_b128"])
+def test_layerwise_against_reference_probes(name):
+    """Every per-block activation the fixture recorded from the REFERENCE model (forward hooks on each module of
+    down / middle / up, tests/golden/make_golden.py:run_unet_case) against the HIP plan's NHWC buffer of that block."""
+    g = np.load(os.path.join(GOLDEN, f"unet_{name}.npz"))
+    m, sd, kw = build(name)
+    x, t = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["t"]).to(DEV)
+    with torch.no_grad():
+        m(x, t)
+    plan = next(iter(m._plans.values()))
+    B = x.shape[0]
+    probes = [k[len("probe/"):] for k in g.files if k.startswith("probe/")]
+    blocks = [k for k in probes if k != "time_embed"]
+    assert len(blocks) == len(plan.block_out) and set(blocks) == set(plan.block_out), "every block of the plan is probed"
+    te = plan.temb.cpu().flatten()
+    ref = g["probe/time_embed"]
+    assert np.abs(te[::max(1, te.numel() // 256)][:256].numpy() - ref).max() < 1e-5 * np.abs(ref).max()
+    worst = (0.0, "")
+    for k in blocks:
+        buf, C, Hc = plan.block_out[k]
+        shape = tuple(int(v) for v in g["shape/" + k])
+        assert shape == (B, C, Hc, Hc), (k, shape, (B, C, Hc, Hc))
+        got = buf.view(B, Hc, Hc, C).permute(0, 3, 1, 2).contiguous().cpu().flatten()
+        stride = max(1, got.numel() // 256)
+        ref = g["probe/" + k]
+        mean, absmean, std = g["stat/" + k]
+        scale = max(np.abs(ref).max(), absmean)
+        err = np.abs(got[::stride][:256].numpy() - ref).max() / scale
+        worst = max(worst, (float(err), k))
+        # whole-tensor statistics as well: a block that is wrong away from the 256 probe points still moves these
+        assert abs(got.double().mean().item() - mean) < 1e-3 * max(absmean, 1e-6), k
+        assert abs(got.double().abs().mean().item() - absmean) < 1e-3 * absmean, k
+        assert abs(got.double().std().item() - std) < 1e-3 * std, k
+    assert worst[0] < 1e-3, worst
+
+
+def test_time_embedding_matches_oracle():
     from oracle import unet_oracle as uo
     name = "i64_b32_hc32"
     g = np.load(os.path.join(GOLDEN, f"unet_{name}.npz"))
@@ -101,6 +139,24 @@ def test_batch_invariance_and_training_path_agree():
     assert ((yt.detach() - y).abs().max() / y.abs().max()) < REL
     yt.square().mean().backward()
     assert m.out["2"].weight.grad is not None and torch.isfinite(m.out["2"].weight.grad).all()
+
+
+def test_config2_batch4_equals_four_single_image_forwards():
+    """BASELINE config 2 runs at batch 4 per GPU; the reference fixture pins batch 1.  Images are independent, so the
+    batch-4 forward (different split-K / tiling choices than batch 1) must reproduce four batch-1 forwards, the first of
+    which is the reference-pinned input."""
+    name = "c2_256_b128"
+    g = np.load(os.path.join(GOLDEN, f"unet_{name}.npz"))
+    m, sd, kw = build(name)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.cat([torch.from_numpy(g["x"]), torch.rand(3, 1, 256, 256, generator=gen) * 2 - 1]).to(DEV)
+    t = torch.tensor([int(g["t"][0]), 0, 500, 999], device=DEV)
+    with torch.no_grad():
+        y4 = m(x, t)
+        y1 = torch.cat([m(x[i:i + 1], t[i:i + 1]) for i in range(4)])
+    ref = torch.from_numpy(g["y"])
+    assert ((y4[:1].cpu() - ref).abs().max() / ref.abs().max()).item() < 5e-5
+    assert ((y4 - y1).abs().max() / y1.abs().max()).item() < 2e-5
 
 
 def test_packed_weights_are_not_repacked_every_forward():
