@@ -9,9 +9,12 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
+(OP_WGRAD3, OP_WGRAD1, OP_GN_BWD, OP_PACK, OP_SOFTMAX_BWD, OP_TRANSPOSE, OP_LINEAR_BWD, OP_STEM_BWD, OP_HEAD_BWD,
+ OP_COLSUM_FOLD) = range(16, 26)
+OP_MAX = 32
 
 
 class SimplexArgs(Structure):
@@ -76,7 +79,7 @@ class SoftmaxArgs(Structure):
 
 class ResampleArgs(Structure):
     _fields_ = [("inp", c_void_p), ("out", c_void_p), ("B", c_int32), ("H", c_int32), ("W", c_int32),
-                ("C", c_int32), ("mode", c_int32)]
+                ("C", c_int32), ("mode", c_int32), ("scale", c_float), ("accumulate", c_int32)]
 
 
 class LinearArgs(Structure):
@@ -144,14 +147,59 @@ class GnBwdArgs(Structure):
                 ("c0", c_int32), ("c1", c_int32), ("x0_ld", c_int32), ("x1_ld", c_int32), ("da_ld", c_int32),
                 ("dx0_ld", c_int32), ("dx1_ld", c_int32), ("Hs", c_int32), ("Ws", c_int32),
                 ("B", c_int32), ("groups", c_int32), ("nslab", c_int32),
-                ("act", c_int32), ("a_mode", c_int32), ("acc_dx", c_int32)]
+                ("act", c_int32), ("a_mode", c_int32), ("acc_dx", c_int32),
+                ("dres", c_void_p), ("dres_bs", c_int64), ("dres_ld", c_int32)]
+
+
+class Wgrad1Args(Structure):
+    _fields_ = [("a0", c_void_p), ("a1", c_void_p), ("gn_scale", c_void_p), ("gn_shift", c_void_p), ("dy", c_void_p),
+                ("dw", c_void_p), ("dbias", c_void_p), ("ws", c_void_p), ("ws_floats", c_int64),
+                ("a0_bs", c_int64), ("a1_bs", c_int64), ("dy_bs", c_int64),
+                ("c0", c_int32), ("c1", c_int32), ("a0_ld", c_int32), ("a1_ld", c_int32), ("dy_ld", c_int32),
+                ("P", c_int32), ("N", c_int32), ("B", c_int32), ("act", c_int32), ("gn_ld", c_int32),
+                ("span", c_int32), ("accumulate", c_int32)]
+
+
+class PackArgs(Structure):
+    _fields_ = [("w", c_void_p), ("out", c_void_p), ("N", c_int32), ("K", c_int32), ("kind", c_int32),
+                ("bwd", c_int32), ("k0", c_int32), ("kc", c_int32)]
+
+
+class SoftmaxBwdArgs(Structure):
+    _fields_ = [("p", c_void_p), ("dp", c_void_p), ("rows", c_int64), ("L", c_int32)]
+
+
+class TransposeArgs(Structure):
+    _fields_ = [("inp", c_void_p), ("out", c_void_p), ("Z", c_int32), ("L", c_int32)]
+
+
+class LinearBwdArgs(Structure):
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("db", c_void_p), ("dx", c_void_p),
+                ("B", c_int32), ("K", c_int32), ("N", c_int32), ("act_in", c_int32), ("acc_w", c_int32), ("acc_x", c_int32)]
+
+
+class StemBwdArgs(Structure):
+    _fields_ = [("x", c_void_p), ("w", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("db", c_void_p), ("dx", c_void_p),
+                ("ws", c_void_p), ("ws_floats", c_int64),
+                ("B", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32)]
+
+
+class HeadBwdArgs(Structure):
+    _fields_ = [("x", c_void_p), ("gn_scale", c_void_p), ("gn_shift", c_void_p), ("w", c_void_p), ("dy", c_void_p),
+                ("da", c_void_p), ("dw", c_void_p), ("db", c_void_p), ("ws", c_void_p), ("ws_floats", c_int64),
+                ("B", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32), ("Cout", c_int32)]
+
+
+class ColsumFoldArgs(Structure):
+    _fields_ = [("colsum", c_void_p), ("dimg", c_void_p), ("dbias", c_void_p), ("B", c_int32), ("ipb", c_int32), ("N", c_int32)]
 
 
 ANOMALY_NCOUNTS = 12
 ANOMALY_BLOCKS = 64
 
 _STRUCTS = [SimplexArgs, PUpdateArgs, IgemmArgs, GnArgs, SoftmaxArgs, ResampleArgs, LinearArgs,
-            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, AnomalyArgs, VlbArgs, WgradArgs, GnBwdArgs]
+            PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, AnomalyArgs, VlbArgs, WgradArgs, GnBwdArgs,
+            Wgrad1Args, PackArgs, SoftmaxBwdArgs, TransposeArgs, LinearBwdArgs, StemBwdArgs, HeadBwdArgs, ColsumFoldArgs]
 
 # every symbol include/anoddpm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -163,6 +211,8 @@ SYMBOLS = [
     "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_conv_head", "anoddpm_nhwc_to_nchw",
     "anoddpm_run_ops", "anoddpm_prof_enable", "anoddpm_prof_active", "anoddpm_prof_collect",
     "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map", "anoddpm_vlb_terms", "anoddpm_conv3x3_wgrad", "anoddpm_gn_silu_backward", "anoddpm_pack_conv3x3",
+    "anoddpm_wgrad_pointwise", "anoddpm_pack_weights", "anoddpm_softmax_rows_backward", "anoddpm_transpose_square",
+    "anoddpm_linear_small_backward", "anoddpm_conv_stem_backward", "anoddpm_conv_head_backward", "anoddpm_colsum_fold",
 ]
 
 _lib = None
@@ -238,6 +288,14 @@ def lib():
     L.anoddpm_conv3x3_wgrad.argtypes = [POINTER(WgradArgs), c_void_p]
     L.anoddpm_gn_silu_backward.argtypes = [POINTER(GnBwdArgs), c_void_p]
     L.anoddpm_pack_conv3x3.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]
+    L.anoddpm_wgrad_pointwise.argtypes = [POINTER(Wgrad1Args), c_void_p]
+    L.anoddpm_pack_weights.argtypes = [POINTER(PackArgs), c_void_p]
+    L.anoddpm_softmax_rows_backward.argtypes = [POINTER(SoftmaxBwdArgs), c_void_p]
+    L.anoddpm_transpose_square.argtypes = [POINTER(TransposeArgs), c_void_p]
+    L.anoddpm_linear_small_backward.argtypes = [POINTER(LinearBwdArgs), c_void_p]
+    L.anoddpm_conv_stem_backward.argtypes = [POINTER(StemBwdArgs), c_void_p]
+    L.anoddpm_conv_head_backward.argtypes = [POINTER(HeadBwdArgs), c_void_p]
+    L.anoddpm_colsum_fold.argtypes = [POINTER(ColsumFoldArgs), c_void_p]
     for i in range(8):
         if os.environ.get(f"ANODDPM_DEBUG{i}"):
             L.anoddpm_debug_set(i, int(os.environ[f"ANODDPM_DEBUG{i}"], 0))

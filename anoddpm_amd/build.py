@@ -26,6 +26,7 @@ SOURCES = {
     "metrics.hip": ["-ffp-contract=off"],
     "wgrad.hip": [],
     "gn_backward.hip": [],
+    "train_kernels.hip": [],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

@@ -24,8 +24,8 @@ struct ProfState {
     std::vector<hipEvent_t> pool;       // pairs: start, stop
     std::vector<int> codes;
     size_t used = 0;
-    double ms[16] = {0};
-    int64_t launches[16] = {0};
+    double ms[ANODDPM_OP_MAX] = {0};
+    int64_t launches[ANODDPM_OP_MAX] = {0};
 };
 static ProfState g_prof;
 
@@ -43,6 +43,16 @@ static int dispatch(const anoddpm_op &op, void *stream)
         case ANODDPM_OP_CHAN_STATS: return anoddpm_chan_stats(static_cast<const anoddpm_chan_stats_args *>(op.args), stream);
         case ANODDPM_OP_HEAD: return anoddpm_conv_head(static_cast<const anoddpm_head_args *>(op.args), stream);
         case ANODDPM_OP_GN_FINALIZE: return anoddpm_gn_finalize(static_cast<const anoddpm_gn_finalize_args *>(op.args), stream);
+        case ANODDPM_OP_WGRAD3: return anoddpm_conv3x3_wgrad(static_cast<const anoddpm_wgrad_args *>(op.args), stream);
+        case ANODDPM_OP_WGRAD1: return anoddpm_wgrad_pointwise(static_cast<const anoddpm_wgrad1_args *>(op.args), stream);
+        case ANODDPM_OP_GN_BWD: return anoddpm_gn_silu_backward(static_cast<const anoddpm_gn_bwd_args *>(op.args), stream);
+        case ANODDPM_OP_PACK: return anoddpm_pack_weights(static_cast<const anoddpm_pack_args *>(op.args), stream);
+        case ANODDPM_OP_SOFTMAX_BWD: return anoddpm_softmax_rows_backward(static_cast<const anoddpm_softmax_bwd_args *>(op.args), stream);
+        case ANODDPM_OP_TRANSPOSE: return anoddpm_transpose_square(static_cast<const anoddpm_transpose_args *>(op.args), stream);
+        case ANODDPM_OP_LINEAR_BWD: return anoddpm_linear_small_backward(static_cast<const anoddpm_linear_bwd_args *>(op.args), stream);
+        case ANODDPM_OP_STEM_BWD: return anoddpm_conv_stem_backward(static_cast<const anoddpm_stem_bwd_args *>(op.args), stream);
+        case ANODDPM_OP_HEAD_BWD: return anoddpm_conv_head_backward(static_cast<const anoddpm_head_bwd_args *>(op.args), stream);
+        case ANODDPM_OP_COLSUM_FOLD: return anoddpm_colsum_fold(static_cast<const anoddpm_colsum_fold_args *>(op.args), stream);
         default: set_error("run_ops: unknown op code %d", op.code); return ANODDPM_EINVAL;
     }
 }
@@ -58,7 +68,7 @@ extern "C" int anoddpm_debug_set(int32_t key, int32_t value)
     return ANODDPM_OK;
 }
 
-extern "C" int anoddpm_abi_version(void) { return 9; }
+extern "C" int anoddpm_abi_version(void) { return 10; }
 
 extern "C" const char *anoddpm_last_error(void) { return g_err; }
 
@@ -75,7 +85,7 @@ extern "C" int anoddpm_run_ops(const anoddpm_op *ops, int32_t n, void *stream)
     for (int i = 0; i < n; ++i) {
         ANODDPM_REQUIRE(ops[i].args, "run_ops: op %d has null args", i);
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool prof = g_prof.on && ops[i].code > 0 && ops[i].code < 16;
+        const bool prof = g_prof.on && ops[i].code > 0 && ops[i].code < ANODDPM_OP_MAX;
         if (prof) {
             if (g_prof.used + 2 > g_prof.pool.size()) {
                 hipEvent_t a, b;
@@ -134,7 +144,7 @@ extern "C" int anoddpm_prof_collect(double *ms_per_code, int64_t *launches_per_c
     }
     g_prof.codes.clear();
     g_prof.used = 0;
-    for (int c = 0; c < 16; ++c) { ms_per_code[c] = g_prof.ms[c]; launches_per_code[c] = g_prof.launches[c]; }
+    for (int c = 0; c < ANODDPM_OP_MAX; ++c) { ms_per_code[c] = g_prof.ms[c]; launches_per_code[c] = g_prof.launches[c]; }
     return ANODDPM_OK;
 }
 
@@ -161,6 +171,14 @@ extern "C" int anoddpm_struct_size(int32_t which)
         case 16: return (int)sizeof(anoddpm_vlb_args);
         case 17: return (int)sizeof(anoddpm_wgrad_args);
         case 18: return (int)sizeof(anoddpm_gn_bwd_args);
+        case 19: return (int)sizeof(anoddpm_wgrad1_args);
+        case 20: return (int)sizeof(anoddpm_pack_args);
+        case 21: return (int)sizeof(anoddpm_softmax_bwd_args);
+        case 22: return (int)sizeof(anoddpm_transpose_args);
+        case 23: return (int)sizeof(anoddpm_linear_bwd_args);
+        case 24: return (int)sizeof(anoddpm_stem_bwd_args);
+        case 25: return (int)sizeof(anoddpm_head_bwd_args);
+        case 26: return (int)sizeof(anoddpm_colsum_fold_args);
         default: return -1;
     }
 }

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(anoddpm_gn_bwd_args a
         for (int e = 0; e < 4; ++e) dx[e] = kc[e * 4 + 0] * dy[e] - kc[e * 4 + 1] - xh[e] * kc[e * 4 + 2];
         float *dst = first ? a.dx0 + (int64_t)b * a.dx0_bs + (int64_t)p * a.dx0_ld + c
                            : a.dx1 + (int64_t)b * a.dx1_bs + (int64_t)p * a.dx1_ld + (c - a.c0);
-        if (a.acc_dx) dx += *reinterpret_cast<const f32x4 *>(dst);
+        if (a.dres) dx += *reinterpret_cast<const f32x4 *>(a.dres + (int64_t)b * a.dres_bs + (int64_t)p * a.dres_ld + c);
+        if (a.acc_dx & (first ? 1 : 2)) dx += *reinterpret_cast<const f32x4 *>(dst);
         *reinterpret_cast<f32x4 *>(dst) = dx;
     }
 }
@@ -211,6 +212,7 @@ extern "C" int anoddpm_gn_silu_backward(const anoddpm_gn_bwd_args *a, void *stre
     ANODDPM_REQUIRE(a->groups > 0 && C % a->groups == 0 && C / a->groups <= 64, "gn_silu_backward: bad group size");
     ANODDPM_REQUIRE(a->B > 0 && a->B <= 65535 && a->Hs > 0 && a->Ws > 0 && a->nslab > 0 && a->nslab <= 65535, "gn_silu_backward: bad sizes");
     ANODDPM_REQUIRE(a->a_mode >= 0 && a->a_mode <= 2 && (a->a_mode != 2 || (a->Hs % 2 == 0 && a->Ws % 2 == 0)), "gn_silu_backward: bad a_mode");
+    ANODDPM_REQUIRE(!a->dres || (a->dres_ld % 4 == 0 && a->dres_bs % 4 == 0), "gn_silu_backward: dres strides must be multiples of 4 floats");
     ANODDPM_REQUIRE(a->x0_ld % 4 == 0 && a->da_ld % 4 == 0 && a->dx0_ld % 4 == 0 && (a->c1 == 0 || (a->x1_ld % 4 == 0 && a->dx1_ld % 4 == 0)),
                     "gn_silu_backward: pixel strides must be multiples of 4 floats");
     hipStream_t s = as_stream(stream);

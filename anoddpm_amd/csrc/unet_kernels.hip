@@ -285,6 +285,11 @@ __global__ __launch_bounds__(256) void resample2x_kernel(anoddpm_resample_args a
             o.z = (((v00.z + v01.z) + v10.z) + v11.z) * 0.25f;
             o.w = (((v00.w + v01.w) + v10.w) + v11.w) * 0.25f;
         }
+        if (a.scale != 0.0f && a.scale != 1.0f) { o.x *= a.scale; o.y *= a.scale; o.z *= a.scale; o.w *= a.scale; }
+        if (a.accumulate) {                                    // gradient fan-in (training backward)
+            const float4 c = reinterpret_cast<const float4 *>(a.out)[i];
+            o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
+        }
         reinterpret_cast<float4 *>(a.out)[i] = o;
     }
 }

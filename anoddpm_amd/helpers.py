@@ -3,6 +3,10 @@
 `from helpers import *` in the reference also leaks `torch, os, json, defaultdict` into its
 importers (GaussianDiffusion.py:8 relies on that); the same names are exported here.
 `gridify_output` is implemented without torchvision (not installed in this image).
+
+Not here on purpose: `load_checkpoint` / `load_parameters` (helpers.py:26-93).  They resolve argv and the ./model
+checkpoint directory for the CLI drivers -- control plane, outside the hot path; a caller
+that wants them keeps the reference's own helpers.py, which needs nothing from this package.
 """
 import json
 import os
@@ -10,8 +14,7 @@ from collections import defaultdict
 
 import torch
 
-__all__ = ["json", "os", "defaultdict", "torch", "gridify_output", "defaultdict_from_json",
-           "load_checkpoint", "load_parameters"]
+__all__ = ["json", "os", "defaultdict", "torch", "gridify_output", "defaultdict_from_json"]
 
 
 def _make_grid(img, nrow, padding=2, pad_value=0):
@@ -45,53 +48,3 @@ def defaultdict_from_json(jsonDict):
     dd = defaultdict(str)
     dd.update(jsonDict)
     return dd
-
-
-def load_checkpoint(param, use_checkpoint, device):
-    """helpers.py:26-45: final params, or the newest checkpoint that un-pickles."""
-    if not use_checkpoint:
-        return torch.load(f'./model/diff-params-ARGS={param}/params-final.pt', map_location=device)
-    checkpoints = sorted(os.listdir(f'./model/diff-params-ARGS={param}/checkpoint'), reverse=True)
-    loaded_model = None
-    for name in checkpoints:
-        try:
-            loaded_model = torch.load(f"./model/diff-params-ARGS={param}/checkpoint/{name}", map_location=device)
-            break
-        except RuntimeError:
-            continue
-    return loaded_model
-
-
-def load_parameters(device):
-    """helpers.py:48-93: resolve argv / ./model into (args, checkpoint dict)."""
-    import sys
-
-    params = sys.argv[1:] if len(sys.argv[1:]) > 0 else os.listdir("./model")
-    if ".DS_Store" in params:
-        params.remove(".DS_Store")
-    use_checkpoint = params[0] == "CHECKPOINT"
-    if use_checkpoint:
-        params = params[1:]
-    print(params)
-    for param in params:
-        if param.isnumeric():
-            output = load_checkpoint(param, use_checkpoint, device)
-        elif param[:4] == "args" and param[-5:] == ".json":
-            output = load_checkpoint(param[4:-5], use_checkpoint, device)
-        elif param[:4] == "args":
-            output = load_checkpoint(param[4:], use_checkpoint, device)
-        else:
-            raise ValueError(f"Unsupported input {param}")
-        if "args" in output:
-            args = output["args"]
-        else:
-            try:
-                with open(f'./test_args/args{param[17:]}.json', 'r') as f:
-                    args = json.load(f)
-                args['arg_num'] = param[17:]
-                args = defaultdict_from_json(args)
-            except FileNotFoundError:
-                raise ValueError(f"args{param[17:]} doesn't exist for {param}")
-        if "noise_fn" not in args:
-            args["noise_fn"] = "gauss"
-        return args, output

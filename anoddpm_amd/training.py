@@ -102,7 +102,10 @@ class GradAllReducer:
         self.pending = [0] * len(self.buckets)
         self.works = []
         self.hooks = []
-        if self.world > 1:
+        self.launched = 0            # buckets reduced by the last finish() (tests)
+        # hooks whenever a process group exists (also at world size 1: the same RCCL path runs, each all-reduce is then
+        # a device-side no-op) -- without torch.distributed the reducer is inert
+        if dist.is_initialized():
             for i, p in enumerate(flat.params):
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.reset()
@@ -126,7 +129,7 @@ class GradAllReducer:
 
     def finish(self):
         """Wait for every bucket (launching any the hooks did not see) and turn sums into means."""
-        if self.world == 1:
+        if not self.hooks:
             return
         for b, left in enumerate(self.pending):
             if left > 0:                       # parameter unused this step: its grad is zero, still reduce
@@ -134,7 +137,9 @@ class GradAllReducer:
                 self._launch(b)
         for work, view in self.works:
             work.wait()
-        self.flat.flat_grad.mul_(1.0 / self.world)
+        self.launched = len(self.works)
+        if self.world > 1:
+            self.flat.flat_grad.mul_(1.0 / self.world)
         self.reset()
 
 

@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- reverse-diffusion throughput of the AnoDDPM hot path on MI355X.
+"""bench.py -- throughput of the AnoDDPM hot path on MI355X, one JSON line per run.
 
-Metric (BASELINE.json): reverse-diffusion images/sec @256x256, T=1000, simplex noise.
-Workload at N=1 (BASELINE config 2): 256x256 MRI-shaped synthetic batch of 4, UNet base 128,
-channel mults (1,1,2,2,4,4), heads 2, attention at 16/8, simplex denoise noise with 8 octaves.
+Default (`--config c2`, BASELINE.json's metric): reverse-diffusion images/sec @256x256, T=1000, simplex noise.
+Workload at N=1 (BASELINE config 2): 256x256 MRI-shaped synthetic batch of 4, UNet base 128, channel mults
+(1,1,2,2,4,4), heads 2, attention at 16/8, simplex denoise noise with 8 octaves.  A "step" is one reverse-diffusion
+step (sample_p) over the per-GPU batch: UNet forward + on-device simplex field + fused update.  Every step of the
+T=1000 chain costs the same, so K steps are timed and images/s = global_batch / (T * seconds_per_step)
+(SURVEY.md 8d allows N << T with N stated).
 
-A "step" is one reverse-diffusion step (sample_p) over the per-GPU batch: UNet forward + on-device
-simplex field + fused update.  Every step of the T=1000 chain costs the same, so K steps are timed and
-images/s = global_batch / (T * seconds_per_step)  (SURVEY.md 8d allows N << T with N stated).
+Other BASELINE configurations, same JSON contract (`--config`):
+  c5  512x512, mults (1,1,2,2,4,4), attention 32/16/8, batch 1 per GPU -- reverse step (as c2)
+  c3  the training step of diffusion_training.py:99-107 at 256x256, batch 4 per GPU: p_loss (q_sample + UNet forward)
+      -> backward -> [RCCL bucketed all-reduce when N > 1] -> clip + AdamW + EMA; value = trained images/s
+  c4  simplex microbench: rand_3d_octaves((1000,256,256), 8 octaves) volumes on the device; value = noise voxels/s
+  c1  config 1's 64x64 model on the GPU (used by the contract test; runs in seconds)
 
-Multi-GPU: one process per GPU (torchrun), each rank denoises its own shard of the batch; inference has
-no data-path collective, scaling is weak (per-GPU batch fixed).  RCCL is used only for the
-timing barrier and the max-over-ranks reduction.
+Multi-GPU: one process per GPU (torchrun), each rank works on its own shard; inference and the simplex microbench
+have no data-path collective -- RCCL is used only for the timing barrier and the max-over-ranks
+reduction; the training step all-reduces the gradient.  Scaling is weak (per-GPU batch fixed).
 
-Extra objects on the JSON line: `roofline` for the dominant kernel (the MFMA implicit-GEMM conv,
-bound = fp32 matrix peak) measured with HIP events on the launch stream, and `cpu_baseline` = the
-stock-PyTorch CPU restatement (oracle/, "port") timed on the host cores (rank 0, N=1 only).
+Extra objects on the JSON line: `roofline` for the dominant kernel, measured with HIP events on the launch stream in an
+instrumented repeat of the same K steps right after the timed region; and `cpu_baseline` = the CPU restatement under
+oracle/ ("port") timed on the host cores on a bounded sample (rank 0, N=1 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -31,16 +38,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    "c2": dict(img=256, base=128, mults="", attn="16,8", heads=2, batch=4, octaves=8,
+    "c2": dict(kind="reverse", img=256, base=128, mults="", attn="16,8", heads=2, batch=4, octaves=8,
                name="256x256 simplex(8 oct) T=1000 base128 attn16,8 batch4/GPU (BASELINE config 2)"),
-    "c5": dict(img=512, base=128, mults=(1, 1, 2, 2, 4, 4), attn="32,16,8", heads=2, batch=1, octaves=8,
-               name="512x512 simplex(8 oct) T=1000 base128 attn32,16,8 batch1/GPU (BASELINE config 5)"),
-    "c1": dict(img=64, base=64, mults="", attn="32,16,8", heads=1, batch=1, octaves=6,
+    "c5": dict(kind="reverse", img=512, base=128, mults=(1, 1, 2, 2, 4, 4), attn="32,16,8", heads=2, batch=1, octaves=8,
+               name="512x512 simplex(8 oct) T=1000 base128 mults 1,1,2,2,4,4 attn32,16,8 batch1/GPU (BASELINE config 5)"),
+    "c1": dict(kind="reverse", img=64, base=64, mults="", attn="32,16,8", heads=1, batch=1, octaves=6,
                name="64x64 base64 batch1 (BASELINE config 1 shape, on GPU)"),
+    "c3": dict(kind="train", img=256, base=128, mults="", attn="16,8", heads=2, batch=4, octaves=6,
+               name="training step @256x256 simplex base128 attn16,8 batch4/GPU: q_sample + UNet fwd/bwd + clip + AdamW + EMA "
+                    "(BASELINE config 3)"),
+    "c4": dict(kind="simplex", img=256, slices=1000, octaves=8, batch=1,
+               name="simplex rand_3d_octaves volume 1000x256x256, 8 octaves, persistence 0.8, frequency 64, fp64 "
+                    "(BASELINE config 4)"),
 }
 T_STEPS = 1000
-MEASURED_TRAFFIC_BYTES_PER_LAUNCH = 1.674e8      # wino_kernel, profiles/r1f_pmc_hbm_by_kernel.csv, config c2 batch 4
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_FP64_VECTOR_TFLOPS = 78.6        # MI355X_MICROARCH.md: fp64 vector (FMA = 2 flop)
+SIMPLEX_FP64_FLOP_PER_EVAL = 200.0    # fp64 operations of one 3-D OpenSimplex evaluation
 
 
 def mri_like(batch, size, device, seed=1234):
@@ -70,18 +84,23 @@ def fill_weights(model, seed=1234):
                 p.copy_(torch.randn(p.shape, generator=g) * max(0.02, 1.0 / np.sqrt(fan_in)))
 
 
-def cpu_baseline(cfg, steps=2):
-    """The reference's CPU path restated (oracle/unet_oracle.py + simplex oracle + diffusion oracle), one
-    image, timed on the host cores: warm-up 1, then `steps` full reverse steps."""
-    from oracle import unet_oracle as uo, diffusion_oracle as do
-    from oracle.simplex_oracle import OracleSimplex
-    # host threads actually used: all cores the process may run on, capped at 64 (the stock ATen CPU
-    # kernels stop scaling -- and with SMT siblings regress badly -- beyond that on the 256-thread hosts)
+def host_threads():
+    """Host threads the CPU baselines use: every core the process may run on, capped at 64 (the stock ATen CPU kernels
+    stop scaling -- and with SMT siblings regress -- beyond that on the 256-thread hosts)."""
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 64))
+    return max(1, min(avail, 64))
+
+
+# ------------------------------------------------------------------------------------------ CPU baselines (oracle/)
+def cpu_baseline_reverse(cfg, steps=5):
+    """The reference's CPU path restated (oracle/unet_oracle.py + simplex oracle + diffusion oracle), one image:
+    warm-up 1, then `steps` full reverse steps."""
+    from oracle import unet_oracle as uo, diffusion_oracle as do
+    from oracle.simplex_oracle import OracleSimplex
+    cores = host_threads()
     torch.set_num_threads(cores)
     kw = dict(img_size=cfg["img"], base_channels=cfg["base"], channel_mults=cfg["mults"],
               attention_resolutions=cfg["attn"], n_heads=cfg["heads"])
@@ -105,8 +124,318 @@ def cpu_baseline(cfg, steps=2):
     dt = (time.perf_counter() - t0) / steps
     return {"value": 1.0 / (T_STEPS * dt), "unit": "images/s", "cores": cores, "kind": "port",
             "sec_per_step": dt,
-            "sample": f"{steps} reverse steps (UNet fwd + simplex + update) of 1 image at {cfg['img']}x{cfg['img']}, "
+            "sample": f"{steps} reverse steps (UNet fwd + simplex + update) of 1 image at {cfg['img']}x{cfg['img']} after 1 warm-up, "
                       f"stock PyTorch CPU fp32 + C/OpenMP simplex, scaled to T={T_STEPS}"}
+
+
+def cpu_baseline_train(cfg, steps=3):
+    """diffusion_training.py:99-107 restated on CPU (oracle/train_oracle.py), one image per step."""
+    from oracle import unet_oracle as uo
+    from oracle.train_oracle import TrainState
+    cores = host_threads()
+    torch.set_num_threads(cores)
+    kw = dict(img_size=cfg["img"], base_channels=cfg["base"], channel_mults=cfg["mults"],
+              attention_resolutions=cfg["attn"], n_heads=cfg["heads"])
+    sd = uo.fill_deterministic(uo.param_shapes(cfg["img"], cfg["base"], cfg["mults"], 2, cfg["attn"], 1))
+    st = TrainState(sd, kw)
+    x = mri_like(1, cfg["img"], "cpu")
+    g = torch.Generator().manual_seed(3)
+    noise = torch.randn(x.shape, generator=g)
+    st.step(x, torch.tensor([500]), noise)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        st.step(x, torch.tensor([100 + i]), noise)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": "port", "sec_per_step": dt,
+            "sample": f"{steps} optimiser steps (q_sample + UNet fwd/bwd + clip + AdamW + EMA) on 1 image at "
+                      f"{cfg['img']}x{cfg['img']} after 1 warm-up, stock PyTorch CPU fp32 autograd"}
+
+
+def cpu_baseline_simplex(cfg, nslices=40):
+    """rand_3d_octaves restated in C/OpenMP (oracle/simplex_oracle.c) on every 25th slice of the volume."""
+    from oracle.simplex_oracle import OracleSimplex
+    o = OracleSimplex(12345)
+    S, Z = cfg["img"], cfg["slices"]
+    zs = np.arange(0, Z, max(1, Z // nslices))[:nslices]
+    o._octaves(zs[:2], S, S, cfg["octaves"], 0.8, 64)
+    t0 = time.perf_counter()
+    o._octaves(zs, S, S, cfg["octaves"], 0.8, 64)
+    dt = time.perf_counter() - t0
+    return {"value": len(zs) * S * S / dt, "unit": "voxels/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sec_per_volume_scaled": dt * Z / len(zs),
+            "sample": f"{len(zs)} of the {Z} z-slices ({S}x{S}, {cfg['octaves']} octaves), C + OpenMP restatement of simplex.py"}
+
+
+# ------------------------------------------------------------------------------------------ workloads
+class Ctx:
+    pass
+
+
+def setup_dist(args):
+    c = Ctx()
+    c.world = int(os.environ.get("WORLD_SIZE", "1"))
+    c.rank = int(os.environ.get("RANK", "0"))
+    c.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    c.dist = None
+    if c.world > 1 or os.environ.get("ANODDPM_BENCH_FORCE_DIST") == "1":
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", c.local_rank), rank=c.rank, world_size=c.world)
+        c.dist = dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (HIP) device; there is no CPU fallback for the product path")
+    torch.cuda.set_device(c.local_rank)
+    c.dev = torch.device("cuda", c.local_rank)
+    return c
+
+
+def timed(c, args, step_fn):
+    """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
+    def barrier():
+        torch.cuda.synchronize()
+        if c.dist is not None:
+            c.dist.barrier()
+    for _ in range(args.warmup):
+        step_fn()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_fn()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if c.dist is not None:
+        c.dist.barrier()
+        el = torch.tensor([elapsed], device=c.dev, dtype=torch.float64)
+        c.dist.all_reduce(el, op=c.dist.ReduceOp.MAX)
+        elapsed = el.item()
+    return elapsed
+
+
+def run_reverse(c, args, cfg):
+    import GaussianDiffusion as GD
+    from UNet import UNetModel
+    from anoddpm_amd import _lib
+    B = args.batch or cfg["batch"]
+    torch.manual_seed(1234)
+    np.random.seed(1234 + c.rank)
+    model = UNetModel(cfg["img"], cfg["base"], channel_mults=cfg["mults"], n_heads=cfg["heads"],
+                      attention_resolutions=cfg["attn"])
+    fill_weights(model)
+    model.to(c.dev).eval()
+    diff = GD.GaussianDiffusionModel([cfg["img"]] * 2, GD.get_beta_schedule(T_STEPS, "linear"), noise="simplex")
+    noise_fn = GD.SimplexNoiseFn(diff.simplex, octave=cfg["octaves"], persistence=0.8, frequency=64)
+    diff.noise_fn = noise_fn
+    x0 = mri_like(B, cfg["img"], c.dev, seed=1234 + c.rank)           # each rank owns a different shard
+    t_T = torch.full((B,), T_STEPS - 1, device=c.dev, dtype=torch.int64)
+    x_T = diff.sample_q(x0, t_T, diff.noise_fn(x0, t_T).float())
+    chain = diff.reverse_chain(model, x_T, T_STEPS, noise_fn)
+    assert (args.warmup + args.steps) * 2 + 2 <= T_STEPS
+    elapsed = timed(c, args, chain.step)
+    if args.dump_plan and c.rank == 0:
+        with open(args.dump_plan, "w") as f:
+            json.dump(next(iter(model._plans.values())).igemm_log, f)
+    ms_per_step = 1000.0 * elapsed / args.steps
+    value = (B * c.world) / (T_STEPS * ms_per_step / 1000.0)
+    finite = bool(torch.isfinite(chain.x).all().item())
+
+    # ---- roofline leg: the same steps again with one HIP-event pair per op on the launch stream
+    roofline = None
+    if not args.no_prof:
+        L = _lib.lib()
+        plan = next(iter(model._plans.values()))
+        L.anoddpm_prof_enable(1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            chain.step()
+        torch.cuda.synchronize()
+        prof_ms_per_step = 1000.0 * (time.perf_counter() - t1) / args.steps
+        ms = (ctypes.c_double * _lib.OP_MAX)()
+        cnt = (ctypes.c_int64 * _lib.OP_MAX)()
+        _lib.check(L.anoddpm_prof_collect(ms, cnt), "prof_collect")
+        L.anoddpm_prof_enable(0)
+        WINO = 12                                              # profiler slot of the Winograd launches
+        w_ms, w_n = ms[WINO], cnt[WINO]
+        d_ms, d_n = ms[_lib.OP_IGEMM], cnt[_lib.OP_IGEMM]      # direct implicit-GEMM launches (1x1, small maps, attention)
+        ig_ms = w_ms + d_ms
+        w_flops = sum(e["gflop"] for e in plan.igemm_log if e["wino"]) * 1e9      # algorithmic (direct-convolution) FLOPs
+        d_flops = sum(e["gflop"] for e in plan.igemm_log if not e["wino"]) * 1e9
+        flops_per_step = plan.igemm_flops
+
+        def tf(flops, msec):
+            return flops * args.steps / (msec / 1000.0) / 1e12 if msec > 0 else 0.0
+        # dominant kernel = wino_kernel when the plan uses it, else the direct kernel.  `achieved` / `frac` price the
+        # FLOPs the matrix pipe EXECUTES (Winograd F(2x2,3x3) issues 4/9 of the direct-convolution count), so frac <= 1
+        # is a pipe utilisation; the algorithmic (direct-convolution) rate of the same launches is a side field.
+        dom_wino = w_ms >= d_ms
+        algorithmic = tf(w_flops, w_ms) if dom_wino else tf(d_flops, d_ms)
+        executed = tf(w_flops * 4.0 / 9.0, w_ms) if dom_wino else algorithmic
+        nl = (w_n if dom_wino else d_n) / args.steps
+        roofline = {"bound": "mfma",
+                    "kernel": ("wino_kernel (Winograd F(2x2,3x3) 3x3 convolutions, v_mfma_f32_32x32x2_f32)" if dom_wino else
+                               "igemm_kernel (direct implicit-GEMM convolution, v_mfma_f32_32x32x2_f32)"),
+                    "achieved": executed, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                    "frac": executed / PEAK_FP32_MATRIX_TFLOPS,
+                    "achieved_is": "FLOPs the matrix pipe executes for the kernel's launches (Winograd layers: 4/9 of the "
+                                   "direct-convolution count) / their HIP-event time",
+                    "algorithmic_tflops": algorithmic,
+                    # HBM bytes come from PMC counters, which cannot be read from inside this process: not reported here;
+                    # the per-kernel counter passes of the same command are committed under profiles/ (README there)
+                    "traffic": None,
+                    "launches_per_step": nl,
+                    "avg_launch_ms": (w_ms / max(w_n, 1)) if dom_wino else (d_ms / max(d_n, 1)),
+                    "algorithmic_gflop_per_launch": ((w_flops if dom_wino else d_flops) / 1e9) / max(nl, 1),
+                    "executed_gflop_per_launch": ((w_flops * 4.0 / 9.0 if dom_wino else d_flops) / 1e9) / max(nl, 1),
+                    "share_of_model_flops": (w_flops if dom_wino else d_flops) / max(flops_per_step, 1.0),
+                    "other_contraction_kernel": {"kernel": "igemm_kernel / gemm1x1 / attention (direct: 1x1, pool-fused and 8x8 3x3, qkv/proj, attention)" if dom_wino else "wino_kernel",
+                                                 "achieved": tf(d_flops, d_ms) if dom_wino else tf(w_flops * 4.0 / 9.0, w_ms),
+                                                 "launches_per_step": (d_n if dom_wino else w_n) / args.steps,
+                                                 "ms_per_step": (d_ms if dom_wino else w_ms) / args.steps},
+                    "all_contractions": {"executed_tflops": tf(w_flops * 4.0 / 9.0 + d_flops, ig_ms),
+                                         "algorithmic_tflops": tf(flops_per_step, ig_ms),
+                                         "ms_per_step": ig_ms / args.steps, "algorithmic_gflop_per_step": flops_per_step / 1e9},
+                    "class_ms_per_step": {name: ms[code] / args.steps for name, code in
+                                          (("winograd", 12), ("igemm_direct", 1), ("gn_stats", 2), ("softmax", 3), ("resample", 4), ("linear", 5),
+                                           ("posemb", 6), ("stem", 7), ("layout", 8), ("chan_stats", 9),
+                                           ("gn_finalize", 10), ("head", 11), ("attention", 13))},
+                    "instrumented_ms_per_step": prof_ms_per_step}
+    metric = ("reverse-diffusion images/sec @256x256 T=1000 simplex" if cfg["img"] == 256 else
+              f"reverse-diffusion images/sec @{cfg['img']}x{cfg['img']} T=1000 simplex")
+    out = {"metric": metric, "value": value, "unit": "images/s", "ms_per_step": ms_per_step, "scaling": "weak", "dtype": "f32",
+           "config": {"workload": cfg["name"], "per_gpu_batch": B, "global_batch": B * c.world, "T": T_STEPS,
+                      "timed_steps_scaled_to_T": True, "parallelism": f"batch-sharded x{c.world} (no data-path collective)",
+                      "output_finite": finite}}
+    return out, roofline, (lambda: cpu_baseline_reverse(cfg))
+
+
+class _TimedEntry:
+    """Bench-only: wraps one C-ABI entry point of the loaded library with a HIP-event pair on torch's current stream (the
+    stream the training operators launch on) and books the FLOPs of each call."""
+
+    def __init__(self, L, name, flops_of):
+        self.L, self.name, self.fn, self.flops_of = L, name, getattr(L, name), flops_of
+        self.events = []
+        setattr(L, name, self)
+
+    def __call__(self, *a):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = self.fn(*a)
+        e1.record()
+        self.events.append((e0, e1, self.flops_of(a[0]._obj)))
+        return rc
+
+    def finish(self):
+        setattr(self.L, self.name, self.fn)
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.events)
+        return ms, len(self.events), sum(f for _, _, f in self.events)
+
+
+def run_train(c, args, cfg):
+    import copy
+    import GaussianDiffusion as GD
+    from UNet import UNetModel
+    from anoddpm_amd import _lib
+    from anoddpm_amd.training import FlatBuffers, FusedAdamWEMA, GradAllReducer, train_step
+    B = args.batch or cfg["batch"]
+    torch.manual_seed(1234)
+    np.random.seed(1234 + c.rank)
+    model = UNetModel(cfg["img"], cfg["base"], channel_mults=cfg["mults"], n_heads=cfg["heads"],
+                      attention_resolutions=cfg["attn"])
+    fill_weights(model)
+    model.to(c.dev).train()
+    ema = copy.deepcopy(model)
+    flat, flat_ema = FlatBuffers(model), FlatBuffers(ema)
+    reducer = GradAllReducer(flat) if c.dist is not None else None
+    opt = FusedAdamWEMA(flat, flat_ema, lr=1e-4, weight_decay=0.0)
+    diff = GD.GaussianDiffusionModel([cfg["img"]] * 2, GD.get_beta_schedule(T_STEPS, "linear"), noise="simplex")
+    targs = {"train_start": True, "sample_distance": 800, "Batch_Size": B}
+    x = mri_like(B, cfg["img"], c.dev, seed=1234 + c.rank)
+    last = {}
+
+    def step():
+        last["loss"], _ = train_step(model, diff, x, targs, flat, reducer, opt)
+    elapsed = timed(c, args, step)
+    ms_per_step = 1000.0 * elapsed / args.steps
+    value = B * c.world / (ms_per_step / 1000.0)
+    finite = bool(torch.isfinite(last["loss"]).item())
+    roofline = None
+    if not args.no_prof:
+        L = _lib.lib()
+        wg = _TimedEntry(L, "anoddpm_conv3x3_wgrad", lambda a: 2.0 * (a.c0 + a.c1) * a.N * 9 * a.H * a.W * a.B)
+        ig = _TimedEntry(L, "anoddpm_igemm", lambda a: 2.0 * (a.c0 + a.c1) * a.N * a.ks * a.ks * a.H * a.W * a.B * a.heads)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        prof_ms = 1000.0 * (time.perf_counter() - t1) / args.steps
+        w_ms, w_n, w_fl = wg.finish()
+        i_ms, i_n, i_fl = ig.finish()
+        ach = w_fl / (w_ms / 1000.0) / 1e12 if w_ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "wgrad_kernel (3x3 weight gradient, nine-tap MFMA tiles, v_mfma_f32_32x32x2_f32)",
+                    "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MATRIX_TFLOPS,
+                    "traffic": None, "launches_per_step": w_n / args.steps, "avg_launch_ms": w_ms / max(w_n, 1),
+                    "gflop_per_launch": w_fl / max(w_n, 1) / 1e9, "ms_per_step": w_ms / args.steps,
+                    "other_contraction_kernel": {"kernel": "anoddpm_igemm launches (forward convs + data gradients; Winograd where eligible)",
+                                                 "algorithmic_tflops": i_fl / (i_ms / 1000.0) / 1e12 if i_ms > 0 else 0.0,
+                                                 "launches_per_step": i_n / args.steps, "ms_per_step": i_ms / args.steps},
+                    "instrumented_ms_per_step": prof_ms}
+    out = {"metric": f"training images/sec @{cfg['img']}x{cfg['img']} (q_sample + UNet fwd/bwd + AdamW + EMA)", "value": value,
+           "unit": "images/s", "ms_per_step": ms_per_step, "scaling": "weak", "dtype": "f32",
+           "config": {"workload": cfg["name"], "per_gpu_batch": B, "global_batch": B * c.world,
+                      "parallelism": (f"data-parallel x{c.world}, bucketed RCCL all-reduce of the flat gradient" if c.dist is not None
+                                      else "single GPU (no collective)"),
+                      "loss_finite": finite, "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}}
+    return out, roofline, (lambda: cpu_baseline_train(cfg))
+
+
+def run_simplex(c, args, cfg):
+    from anoddpm_amd._lib import SimplexArgs, check, current_stream, lib
+    from simplex import Simplex_CLASS
+    s = Simplex_CLASS()
+    s.newSeed(12345 + c.rank)
+    S, Z = cfg["img"], cfg["slices"]
+    out_t = torch.empty((Z, S, S), dtype=torch.float64, device=c.dev)
+    a = SimplexArgs()
+    a.out, a.zvals, a.tables, a.table_sel = out_t.data_ptr(), None, s.device_tables(c.dev).data_ptr(), None
+    a.z0, a.out_slice_stride, a.nslices, a.H, a.W = 0, S * S, Z, S, S
+    a.table_slice_stride, a.table_sel_scale, a.octaves, a.persistence, a.frequency = 0, 1, cfg["octaves"], 0.8, 64.0
+
+    def step():
+        check(lib().anoddpm_simplex3_octaves_f64(ctypes.byref(a), current_stream()), "simplex3_octaves_f64")
+    elapsed = timed(c, args, step)
+    ms_per_step = 1000.0 * elapsed / args.steps
+    voxels = Z * S * S
+    value = voxels * c.world / (ms_per_step / 1000.0)
+    roofline = None
+    if not args.no_prof:
+        evs = []
+        for _ in range(args.steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            step()
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        k_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+        evals = voxels * cfg["octaves"]
+        ach = evals * SIMPLEX_FP64_FLOP_PER_EVAL / (k_ms / 1000.0) / 1e12
+        roofline = {"bound": "fp64-alu", "kernel": "simplex3_octaves_kernel<double> (lattice hash in LDS, octaves accumulated in registers)",
+                    "achieved": ach, "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_VECTOR_TFLOPS,
+                    "traffic": None, "avg_launch_ms": k_ms, "launches_per_step": 1,
+                    "evaluations_per_launch": evals, "fp64_flop_per_evaluation": SIMPLEX_FP64_FLOP_PER_EVAL,
+                    "Gevals_per_s": evals / k_ms / 1e6,
+                    "hbm_write_GBps": voxels * 8 / (k_ms / 1000.0) / 1e9,
+                    "note": "HBM floor (8 B written per voxel at 8 TB/s) is 66 us per volume: the kernel is fp64-ALU bound"}
+    out = {"metric": "simplex rand_3d_octaves noise voxels/sec (256x256xT=1000 volume, 8 octaves)", "value": value, "unit": "voxels/s",
+           "ms_per_step": ms_per_step, "scaling": "weak", "dtype": "f64",
+           "config": {"workload": cfg["name"], "volumes_per_step_per_gpu": 1,
+                      "parallelism": f"replicas x{c.world} (z-slabs / volumes are independent; no collective)",
+                      "output_finite": bool(torch.isfinite(out_t[::97]).all().item())}}
+    return out, roofline, (lambda: cpu_baseline_simplex(cfg))
 
 
 def main():
@@ -120,151 +449,25 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--dump-plan", default="", help="write the igemm launch list of the compiled plan (JSON) here")
     args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (HIP) device; there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    import GaussianDiffusion as GD
-    from UNet import UNetModel
-    from anoddpm_amd import _lib
-
+    c = setup_dist(args)
     cfg = dict(CONFIGS[args.config])
-    B = args.batch or cfg["batch"]
-    torch.manual_seed(1234)
-    np.random.seed(1234 + rank)
-    model = UNetModel(cfg["img"], cfg["base"], channel_mults=cfg["mults"], n_heads=cfg["heads"],
-                      attention_resolutions=cfg["attn"])
-    fill_weights(model)
-    model.to(dev).eval()
-    diff = GD.GaussianDiffusionModel([cfg["img"]] * 2, GD.get_beta_schedule(T_STEPS, "linear"), noise="simplex")
-    noise_fn = GD.SimplexNoiseFn(diff.simplex, octave=cfg["octaves"], persistence=0.8, frequency=64)
-    diff.noise_fn = noise_fn
-    x0 = mri_like(B, cfg["img"], dev, seed=1234 + rank)           # each rank owns a different shard
-    t_T = torch.full((B,), T_STEPS - 1, device=dev, dtype=torch.int64)
-    x_T = diff.sample_q(x0, t_T, diff.noise_fn(x0, t_T).float())
-
-    total = args.warmup + args.steps
-    chain = diff.reverse_chain(model, x_T, T_STEPS, noise_fn)
-    assert total * 2 + 2 <= T_STEPS
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        chain.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        chain.step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-        el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = el.item()
-    if args.dump_plan and rank == 0:
-        with open(args.dump_plan, "w") as f:
-            json.dump(next(iter(model._plans.values())).igemm_log, f)
-    ms_per_step = 1000.0 * elapsed / args.steps
-    value = (B * world) / (T_STEPS * ms_per_step / 1000.0)
-    finite = bool(torch.isfinite(chain.x).all().item())
-
-    # ---- roofline leg: the same steps again with one HIP-event pair per op on the launch stream
-    roofline = None
-    prof_ms_per_step = None
-    if not args.no_prof:
-        import ctypes
-        L = _lib.lib()
-        plan = next(iter(model._plans.values()))
-        L.anoddpm_prof_enable(1)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            chain.step()
-        torch.cuda.synchronize()
-        prof_ms_per_step = 1000.0 * (time.perf_counter() - t1) / args.steps
-        ms = (ctypes.c_double * 16)()
-        cnt = (ctypes.c_int64 * 16)()
-        _lib.check(L.anoddpm_prof_collect(ms, cnt), "prof_collect")
-        L.anoddpm_prof_enable(0)
-        WINO = 12                                              # profiler slot of the Winograd launches
-        w_ms, w_n = ms[WINO], cnt[WINO]
-        d_ms, d_n = ms[_lib.OP_IGEMM], cnt[_lib.OP_IGEMM]      # direct implicit-GEMM launches (1x1, small maps, attention)
-        ig_ms, ig_n = w_ms + d_ms, w_n + d_n
-        w_flops = sum(e["gflop"] for e in plan.igemm_log if e["wino"]) * 1e9      # algorithmic (direct-convolution) FLOPs
-        d_flops = sum(e["gflop"] for e in plan.igemm_log if not e["wino"]) * 1e9
-        flops_per_step = plan.igemm_flops
-
-        def tf(flops, msec):
-            return flops * args.steps / (msec / 1000.0) / 1e12 if msec > 0 else 0.0
-        # dominant kernel = wino_kernel when the plan uses it, else the direct kernel
-        dom_wino = w_ms >= d_ms
-        achieved = tf(w_flops, w_ms) if dom_wino else tf(d_flops, d_ms)
-        # FLOPs the matrix pipe actually executes: Winograd F(2x2,3x3) issues 4/9 of the direct count
-        executed = tf(w_flops * 4.0 / 9.0, w_ms) if dom_wino else achieved
-        roofline = {"bound": "mfma",
-                    "kernel": ("wino_kernel (Winograd F(2x2,3x3) 3x3 convolutions, v_mfma_f32_32x32x2_f32)" if dom_wino else
-                               "igemm_kernel (direct implicit-GEMM convolution, v_mfma_f32_32x32x2_f32)"),
-                    "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
-                    # HBM-side bytes per launch from the committed PMC passes (not collectable from inside this
-                    # process): (2*FETCH_SIZE + WRITE_SIZE) KB averaged over the kernel's 63 launches per step, with the
-                    # guide's gfx950 FETCH_SIZE x2 correction.  Only quoted for the workload it was measured on.
-                    "traffic": MEASURED_TRAFFIC_BYTES_PER_LAUNCH if (args.config == "c2" and B == 4 and dom_wino) else None,
-                    "traffic_source": "profiles/r1f_pmc_hbm_by_kernel.csv",
-                    "achieved_is": "ALGORITHMIC direct-convolution FLOPs of the kernel's launches / their HIP-event time (exceeds the executed rate: Winograd does 2.25x fewer multiplies)",
-                    "executed_tflops": executed, "executed_frac": executed / PEAK_FP32_MATRIX_TFLOPS,
-                    "launches_per_step": (w_n if dom_wino else d_n) / args.steps,
-                    "avg_launch_ms": (w_ms / max(w_n, 1)) if dom_wino else (d_ms / max(d_n, 1)),
-                    "algorithmic_gflop_per_launch": ((w_flops / 1e9) / max(w_n / args.steps, 1)) if dom_wino else ((d_flops / 1e9) / max(d_n / args.steps, 1)),
-                    "share_of_model_flops": (w_flops if dom_wino else d_flops) / max(flops_per_step, 1.0),
-                    "other_contraction_kernel": {"kernel": "igemm_kernel (direct: 1x1, pool-fused and 8x8 3x3, qkv/proj, attention)" if dom_wino else "wino_kernel",
-                                                 "achieved": tf(d_flops, d_ms) if dom_wino else tf(w_flops, w_ms),
-                                                 "launches_per_step": (d_n if dom_wino else w_n) / args.steps,
-                                                 "ms_per_step": (d_ms if dom_wino else w_ms) / args.steps},
-                    "all_contractions": {"achieved": tf(flops_per_step, ig_ms), "executed_tflops": tf(w_flops * 4.0 / 9.0 + d_flops, ig_ms),
-                                         "ms_per_step": ig_ms / args.steps, "algorithmic_gflop_per_step": flops_per_step / 1e9},
-                    "class_ms_per_step": {name: ms[code] / args.steps for name, code in
-                                          (("winograd", 12), ("igemm_direct", 1), ("gn_stats", 2), ("softmax", 3), ("resample", 4), ("linear", 5),
-                                           ("posemb", 6), ("stem", 7), ("layout", 8), ("chan_stats", 9),
-                                           ("gn_finalize", 10), ("head", 11))},
-                    "instrumented_ms_per_step": prof_ms_per_step}
-
-    out = {
-        "metric": "reverse-diffusion images/sec @256x256 T=1000 simplex" if cfg["img"] == 256 else
-                  f"reverse-diffusion images/sec @{cfg['img']}x{cfg['img']} T=1000 simplex",
-        "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": cfg["name"], "per_gpu_batch": B, "global_batch": B * world, "T": T_STEPS,
-                   "timed_steps_scaled_to_T": True, "parallelism": f"batch-sharded x{world} (no data-path collective)",
-                   "output_finite": finite},
-    }
+    run = {"reverse": run_reverse, "train": run_train, "simplex": run_simplex}[cfg["kind"]]
+    out, roofline, cpu_fn = run(c, args, cfg)
+    line = {"metric": out.pop("metric"), "value": out.pop("value"), "unit": out.pop("unit"), "n_gpus": c.world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": out.pop("ms_per_step"), "higher_is_better": True,
+            "scaling": out.pop("scaling"), "vs_baseline": None, "dtype": out.pop("dtype"), "data": "synthetic",
+            "config": out.pop("config")}
     if roofline:
-        out["roofline"] = roofline
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["roofline"] = roofline
+    if c.rank == 0 and c.world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            line["cpu_baseline"] = cpu_fn()
         except Exception as e:                                   # the baseline must never sink the GPU number
-            out["cpu_baseline"] = {"value": None, "error": repr(e)}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+            line["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if c.rank == 0:
+        print(json.dumps(line), flush=True)
+    if c.dist is not None:
+        c.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

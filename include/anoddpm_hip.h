@@ -141,7 +141,20 @@ enum {
     ANODDPM_OP_LAYOUT = 8,       /* anoddpm_layout_args      */
     ANODDPM_OP_CHAN_STATS = 9,   /* anoddpm_chan_stats_args  */
     ANODDPM_OP_GN_FINALIZE = 10, /* anoddpm_gn_finalize_args */
-    ANODDPM_OP_HEAD = 11         /* anoddpm_head_args        */
+    ANODDPM_OP_HEAD = 11,        /* anoddpm_head_args        */
+    /* 12 is the profiler's slot for Winograd launches of ANODDPM_OP_IGEMM */
+    /* training step (backward twins and per-step weight packing) */
+    ANODDPM_OP_WGRAD3 = 16,      /* anoddpm_wgrad_args        */
+    ANODDPM_OP_WGRAD1 = 17,      /* anoddpm_wgrad1_args       */
+    ANODDPM_OP_GN_BWD = 18,      /* anoddpm_gn_bwd_args       */
+    ANODDPM_OP_PACK = 19,        /* anoddpm_pack_args         */
+    ANODDPM_OP_SOFTMAX_BWD = 20, /* anoddpm_softmax_bwd_args  */
+    ANODDPM_OP_TRANSPOSE = 21,   /* anoddpm_transpose_args    */
+    ANODDPM_OP_LINEAR_BWD = 22,  /* anoddpm_linear_bwd_args   */
+    ANODDPM_OP_STEM_BWD = 23,    /* anoddpm_stem_bwd_args     */
+    ANODDPM_OP_HEAD_BWD = 24,    /* anoddpm_head_bwd_args     */
+    ANODDPM_OP_COLSUM_FOLD = 25, /* anoddpm_colsum_fold_args  */
+    ANODDPM_OP_MAX = 32
 };
 
 /* Implicit-GEMM convolution / GEMM on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32: exact fp32).
@@ -247,12 +260,16 @@ typedef struct {
 int anoddpm_softmax_rows(const anoddpm_softmax_args *a, void *stream);
 
 /* 2x resampling of an NHWC tensor (the x_upd path of ResBlock, UNet.py:177-181,207):
- * mode 1: nearest x2 up (in H x W -> out 2H x 2W); mode 2: 2x2 average pool (in -> H/2 x W/2). */
+ * mode 1: nearest x2 up (in H x W -> out 2H x 2W); mode 2: 2x2 average pool (in -> H/2 x W/2).
+ * scale (0 is read as 1) multiplies the result and accumulate != 0 adds it to `out`: the backward of one mode is the
+ * other one scaled -- d(avg pool) = nearest-up * 0.25, d(nearest-up) = avg pool * 4 (the sum of the four children). */
 typedef struct {
     const float *in;
     float *out;
     int32_t B, H, W, C;             /* INPUT dims */
     int32_t mode;
+    float scale;
+    int32_t accumulate;
 } anoddpm_resample_args;
 
 int anoddpm_resample2x(const anoddpm_resample_args *a, void *stream);
@@ -330,8 +347,8 @@ int anoddpm_run_ops(const anoddpm_op *ops, int32_t n, void *stream);
 
 /* Per-class kernel timing with HIP events on the launch stream (bench.py roofline leg).
  * enable=1 starts recording one event pair per launched op; collect() synchronises the events
- * and returns accumulated milliseconds and launch counts per op code (arrays of 16); ANODDPM_OP_IGEMM launches that
- * run the Winograd kernel (cfg == 2) are booked under index 12 instead of 1. */
+ * and returns accumulated milliseconds and launch counts per op code (arrays of ANODDPM_OP_MAX = 32); ANODDPM_OP_IGEMM
+ * launches that run the Winograd kernel (cfg == 2) are booked under index 12 instead of 1. */
 int anoddpm_prof_enable(int32_t enable);
 int anoddpm_prof_active(void);             /* 1 while event recording is on (graph capture must be avoided) */
 int anoddpm_prof_collect(double *ms_per_code, int64_t *launches_per_code);
@@ -469,10 +486,134 @@ typedef struct anoddpm_gn_bwd_args {
     int32_t c0, c1, x0_ld, x1_ld, da_ld, dx0_ld, dx1_ld;
     int32_t Hs, Ws;                 /* SOURCE image dims (P = Hs*Ws) */
     int32_t B, groups, nslab;
-    int32_t act, a_mode, acc_dx;
+    int32_t act, a_mode;
+    int32_t acc_dx;                 /* bit 0: add into dx0, bit 1: add into dx1 (else overwrite) */
+    const float *dres;              /* optional [B][P][C] (row length dres_ld, batch stride dres_bs): added to the source
+                                       gradient -- the identity residual of a block (UNet.py:216 / :125) */
+    int64_t dres_bs;
+    int32_t dres_ld;
 } anoddpm_gn_bwd_args;
 
 int anoddpm_gn_silu_backward(const anoddpm_gn_bwd_args *a, void *stream);
+
+/* Weight gradient of a pointwise (1x1 / Conv1d k=1) convolution (UNet.py:115,117,200) whose input was consumed through
+ * the fused operand load (optional GroupNorm-apply, optional SiLU, two-source concat):
+ *   dw[n][k] (+)= sum_{b,p} dy[b][p][n] * A[b][p][k]            dbias[n] += sum_{b,p} dy[b][p][n]
+ * Contraction over pixels on the fp32 matrix pipe: a workgroup owns a 128 x 128 (k, n) tile of one work item
+ * (image, `span` consecutive pixels); partial tiles go to ws[item][K][N] and are folded in a fixed order.
+ * ws: >= (B * ceil(P/span)) * (K*N + N) floats. */
+typedef struct anoddpm_wgrad1_args {
+    const float *a0, *a1;
+    const float *gn_scale, *gn_shift; /* [B][gn_ld] or NULL */
+    const float *dy;                /* [B][P][dy_ld] */
+    float *dw;                      /* [N][K] */
+    float *dbias;                   /* [N], accumulated into; or NULL */
+    float *ws;
+    int64_t ws_floats;
+    int64_t a0_bs, a1_bs, dy_bs;
+    int32_t c0, c1, a0_ld, a1_ld, dy_ld;
+    int32_t P, N, B;
+    int32_t act, gn_ld;
+    int32_t span;                   /* pixels per work item, multiple of 32 */
+    int32_t accumulate;             /* != 0: add into dw */
+} anoddpm_wgrad1_args;
+
+int anoddpm_wgrad_pointwise(const anoddpm_wgrad1_args *a, void *stream);
+
+/* Device-side weight packing (training re-packs after every optimizer step).
+ *   kind 0: 3x3 direct   (anoddpm_pack_conv3x3 mode 0)       w OIHW [N][K][3][3]
+ *   kind 1: 3x3 Winograd (anoddpm_pack_conv3x3 mode 1)
+ *   kind 2: pointwise    w [N][K] -> [K/4][N][4]; bwd != 0: the data-gradient matrix W'[i=n][o] = w[n][k0 + o],
+ *           o < kc, packed [N/4][kc][4] (a column range: the two sources of a concatenated input get separate matrices)
+ *   kind 3: small conv   w OIHW [N][K][3][3] -> [9][K][N] (stem / head kernels)
+ *   kind 4: plain copy of N*K floats */
+typedef struct anoddpm_pack_args {
+    const float *w;
+    float *out;
+    int32_t N, K, kind, bwd, k0, kc;
+} anoddpm_pack_args;
+
+int anoddpm_pack_weights(const anoddpm_pack_args *a, void *stream);
+
+/* Backward of the row softmax (UNet.py:151), in place on the incoming gradient:
+ *   ds[r][j] = p[r][j] * (dp[r][j] - sum_j dp[r][j] p[r][j]) */
+typedef struct anoddpm_softmax_bwd_args {
+    const float *p;                 /* softmax output [rows][L] */
+    float *dp;                      /* in: dL/dp, out: dL/ds */
+    int64_t rows;
+    int32_t L;
+} anoddpm_softmax_bwd_args;
+
+int anoddpm_softmax_rows_backward(const anoddpm_softmax_bwd_args *a, void *stream);
+
+/* out[z][j][i] = in[z][i][j] for Z square L x L matrices (attention weights / their gradients, so that every
+ * backward contraction of QKVAttention reads its A operand row-major). */
+typedef struct anoddpm_transpose_args {
+    const float *in;
+    float *out;
+    int32_t Z, L;
+} anoddpm_transpose_args;
+
+int anoddpm_transpose_square(const anoddpm_transpose_args *a, void *stream);
+
+/* Backward of anoddpm_linear_small with act_out == 0: y = act_in(x) W^T + b.
+ *   dw[n][k] (+)= sum_b dy[b][n] * act_in(x[b][k]);  db[n] (+)= sum_b dy[b][n];
+ *   dx[b][k] (+)= act_in'(x[b][k]) * sum_n dy[b][n] * w[n][k]            (dx may be NULL) */
+typedef struct anoddpm_linear_bwd_args {
+    const float *x;                 /* [B][K] the forward INPUT (before act_in) */
+    const float *w;                 /* [N][K] */
+    const float *dy;                /* [B][N] */
+    float *dw, *db, *dx;
+    int32_t B, K, N, act_in;
+    int32_t acc_w, acc_x;           /* != 0: add into dw+db / dx */
+} anoddpm_linear_bwd_args;
+
+int anoddpm_linear_small_backward(const anoddpm_linear_bwd_args *a, void *stream);
+
+/* Backward of anoddpm_conv_stem (UNet.py:280): dw (OIHW [Cout][Cin][3][3]) += x (*) dy, db[co] += sum dy, and optionally
+ * dx (NCHW) = dy (*) flipped w.  ws: >= nblk * (Cin * 9 + 1) * Cout floats with nblk = B * ceil(H*W / 1024). */
+typedef struct anoddpm_stem_bwd_args {
+    const float *x;                 /* [B][Cin][H][W] */
+    const float *w;                 /* OIHW (the parameter itself) */
+    const float *dy;                /* [B][H*W][Cout] */
+    float *dw, *db;                 /* accumulated into */
+    float *dx;                      /* [B][Cin][H][W] or NULL (overwritten) */
+    float *ws;
+    int64_t ws_floats;
+    int32_t B, H, W, Cin, Cout;
+} anoddpm_stem_bwd_args;
+
+int anoddpm_conv_stem_backward(const anoddpm_stem_bwd_args *a, void *stream);
+
+/* Backward of anoddpm_conv_head (UNet.py:384-388) up to the activated tensor a = silu(scale*x + shift):
+ *   da[b][p][c] = sum_{o,tap} w[o][c][tap] * dy[b][o][p - off(tap)]           (NHWC, overwritten)
+ *   dw[o][c][tap] += sum_{b,p} a[b][p + off(tap)][c] * dy[b][o][p];  db[o] += sum dy
+ * ws: >= nblk * (9 * C + 1) * Cout floats with nblk = B * ceil(H*W / 512). */
+typedef struct anoddpm_head_bwd_args {
+    const float *x;                 /* [B][H*W][C] */
+    const float *gn_scale, *gn_shift; /* [B][C] */
+    const float *w;                 /* OIHW [Cout][C][3][3] (the parameter itself) */
+    const float *dy;                /* [B][Cout][H][W] */
+    float *da;                      /* [B][H*W][C] */
+    float *dw, *db;                 /* accumulated into */
+    float *ws;
+    int64_t ws_floats;
+    int32_t B, H, W, C, Cout;
+} anoddpm_head_bwd_args;
+
+int anoddpm_conv_head_backward(const anoddpm_head_bwd_args *a, void *stream);
+
+/* Fold of the per-work-item column sums anoddpm_conv3x3_wgrad publishes ([B][ipb][N]: items of an image are
+ * consecutive): dimg[b][n] = sum_items (written, optional: the embedding-projection gradient, UNet.py:213) and
+ * dbias[n] += sum_b dimg[b][n] (optional). */
+typedef struct anoddpm_colsum_fold_args {
+    const float *colsum;
+    float *dimg;                    /* [B][N] or NULL */
+    float *dbias;                   /* [N] or NULL, accumulated into */
+    int32_t B, ipb, N;
+} anoddpm_colsum_fold_args;
+
+int anoddpm_colsum_fold(const anoddpm_colsum_fold_args *a, void *stream);
 
 #ifdef __cplusplus
 }

@@ -265,7 +265,7 @@ def gn_silu_backward(srcs, da, gamma, beta, mean, rstd, *, act=1, a_mode=0, acc_
     st.x0_bs, st.x1_bs, st.da_bs, st.dx0_bs, st.dx1_bs = P * c0, P * c1, Pa * C, P * c0, P * c1
     st.c0, st.c1, st.x0_ld, st.x1_ld, st.da_ld, st.dx0_ld, st.dx1_ld = c0, c1, c0, max(c1, 4), C, c0, max(c1, 4)
     st.Hs, st.Ws, st.B, st.groups, st.nslab = Hs, Ws, B, 32, nslab
-    st.act, st.a_mode, st.acc_dx = act, a_mode, 1 if acc_into is not None else 0
+    st.act, st.a_mode, st.acc_dx = act, a_mode, 3 if acc_into is not None else 0
     check(lib().anoddpm_gn_silu_backward(ctypes.byref(st), current_stream()), "gn_silu_backward")
     torch.cuda.synchronize()
     return dx, dgamma, dbeta

@@ -32,8 +32,8 @@ def test_bench_line_small_config():
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] in ("mfma", "hbm") and r["unit"] == "TFLOP/s" and r["peak"] > 0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["executed_tflops"] <= r["achieved"] + 1e-9
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1.0
+    assert r["algorithmic_tflops"] >= r["achieved"] - 1e-9 and r["traffic"] is None
 
 
 def test_bench_cpu_baseline_object():
@@ -41,6 +41,32 @@ def test_bench_cpu_baseline_object():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "images/s" and c["value"] > 0 and "sample" in c
     assert d["value"] > c["value"]
+
+
+def test_bench_line_simplex_and_training_configs():
+    d = run_bench("--config", "c4", "--no-cpu-baseline")
+    assert d["unit"] == "voxels/s" and d["dtype"] == "f64" and d["value"] > 1e9
+    r = d["roofline"]
+    assert r["bound"] == "fp64-alu" and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    d = run_bench("--config", "c3", "--batch", "1", "--no-cpu-baseline")
+    assert d["unit"] == "images/s" and d["config"]["loss_finite"] is True and d["value"] > 0
+    r = d["roofline"]
+    assert "wgrad" in r["kernel"] and 0 < r["frac"] <= 1.0 and r["launches_per_step"] > 50
+
+
+def test_bench_under_torchrun_one_rank_uses_rccl():
+    """The driver launches N > 1 as `python -m torch.distributed.run ... bench.py --gpus N`; with one GPU here the same
+    launcher at --nproc-per-node 1 plus ANODDPM_BENCH_FORCE_DIST=1 executes the process-group / barrier / all-reduce path."""
+    env = dict(os.environ, ANODDPM_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29544", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "3", "--warmup", "1", "--config", "c1", "--no-prof"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "cpu_baseline" in d
 
 
 def test_smoke_entry():

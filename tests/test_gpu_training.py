@@ -225,3 +225,42 @@ def test_native_backward_matches_torch_autograd(kw, B, monkeypatch):
     relg = lambda a, b: ((a - b).abs().max() / max(b.abs().max().item(), 1e-4 * gmax)).item()
     worst = max((relg(g_nat[k], g_ref[k]), k) for k in g_ref)
     assert worst[0] < 1e-3, worst
+
+
+def test_rccl_world_size_1_reducer_with_native_backward():
+    """The data-parallel machinery on the real backend: `nccl` (= RCCL) process group of one rank, GradAllReducer on a
+    UNetModel whose backward runs the hand-written kernels (custom autograd Functions + post-accumulate hooks + flat
+    gradient views).  Every bucket must be launched from a hook and the step must equal the reducer-free step."""
+    import os
+    import torch.distributed as dist
+    import GaussianDiffusion as GD
+    from UNet import UNetModel
+    from anoddpm_amd.training import FlatBuffers, FusedAdamWEMA, GradAllReducer, train_step
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        torch.manual_seed(5)
+        base = UNetModel(32, 32, n_heads=2, attention_resolutions="16,8").to(DEV)
+        diff = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(1000, "linear"), noise="gauss")
+        x = torch.rand(2, 1, 32, 32, device=DEV) * 2 - 1
+        noise = torch.randn(2, 1, 32, 32, device=DEV)
+        diff.noise_fn = lambda a, b: noise
+        results = []
+        for use_reducer in (False, True):
+            model = copy.deepcopy(base)
+            flat = FlatBuffers(model)
+            opt = FusedAdamWEMA(flat, None, lr=1e-3)
+            red = GradAllReducer(flat, bucket_bytes=1 << 20) if use_reducer else None
+            if red is not None:
+                assert len(red.buckets) > 3 and len(red.hooks) == len(flat.params)
+            torch.manual_seed(77)                                  # same t draw inside p_loss
+            loss, _ = train_step(model, diff, x, {"train_start": False}, flat, red, opt)
+            if red is not None:
+                assert red.launched == len(red.buckets) and all(p == len(m) for p, (_, _, m) in zip(red.pending, red.buckets))
+            results.append((loss.item(), flat.flat_param.clone(), flat.flat_grad.clone()))
+        assert results[0][0] == results[1][0]
+        assert torch.equal(results[0][2], results[1][2]) and torch.equal(results[0][1], results[1][1])
+    finally:
+        dist.destroy_process_group()

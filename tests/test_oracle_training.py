@@ -50,7 +50,7 @@ def check_against_fixture(g, step, keys, loss, grads, norm, params, ema, lr, tol
         bad += int((d > 0.02 * lr).sum())
         tot += d.size
         de = np.abs(probe(ema[k]) - g[p + "eprobe"][i])
-        assert de.max() <= 2.2 * lr * nstep * 1e-4 + 1e-7, (k, de.max())
+        assert de.max() <= 2.2 * lr * nstep * 1e-4 + 5e-7, (k, de.max())          # + a few fp32 ulps of O(1) values
     assert bad <= 0.002 * tot, (bad, tot)
 
 
