@@ -247,31 +247,64 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const anoddpm_linear_
     if (k4 == 0 && a.db) a.db[n] = a.acc_w ? a.db[n] + sb : sb;
 }
 
-__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const anoddpm_linear_bwd_args a)
+// dx: grid (K/64) blocks of 1024 threads: lane = k inside a 64-wide chunk, wave w takes n = w, w + 16, ... for ALL batch rows
+// (W is read once, coalesced); the 16 partial sums per (b, k) are folded through LDS in a fixed order.
+template <int NB>
+__global__ __launch_bounds__(1024) void linear_bwd_x_kernel(const anoddpm_linear_bwd_args a)
 {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)a.B * a.K) return;
-    const int k = (int)(idx % a.K), b = (int)(idx / a.K);
-    float s = 0.f;
-    for (int n = 0; n < a.N; ++n) s += a.dy[(int64_t)b * a.N + n] * a.w[(int64_t)n * a.K + k];
-    if (a.act_in) s *= silu_grad(a.x[idx]);
-    a.dx[idx] = a.acc_x ? a.dx[idx] + s : s;
+    __shared__ float red[16][NB][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane;
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    if (k < a.K)
+        for (int n = wave; n < a.N; n += 16) {
+            const float w = a.w[(int64_t)n * a.K + k];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                if (b < a.B) acc[b] += a.dy[(int64_t)b * a.N + n] * w;
+        }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) red[wave][b][lane] = acc[b];
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.B * 64; i += 1024) {
+        const int b = i >> 6, l = i & 63;
+        const int kk = blockIdx.x * 64 + l;
+        if (kk >= a.K) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += red[w][b][l];
+        const int64_t idx = (int64_t)b * a.K + kk;
+        if (a.act_in) s *= silu_grad(a.x[idx]);
+        a.dx[idx] = a.acc_x ? a.dx[idx] + s : s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ column-sum fold
+// grid (ceil(N/64), B): 64 channels x 4 item lanes; then a second launch folds the batch into the bias gradient.
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const anoddpm_colsum_fold_args a)
+{
+    __shared__ float red[4][64];
+    const int l = threadIdx.x & 63, il = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + l, b = blockIdx.y;
+    float s = 0.f;
+    if (n < a.N) {
+        const float *p = a.colsum + ((int64_t)b * a.ipb) * a.N + n;
+        for (int i = il; i < a.ipb; i += 4) s += p[(int64_t)i * a.N];
+    }
+    red[il][l] = s;
+    __syncthreads();
+    if (il == 0 && n < a.N) a.dimg[(int64_t)b * a.N + n] = ((red[0][l] + red[1][l]) + red[2][l]) + red[3][l];
+}
+
+__global__ __launch_bounds__(256) void colsum_bias_kernel(const anoddpm_colsum_fold_args a)
 {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= a.N) return;
     float tot = 0.f;
-    for (int b = 0; b < a.B; ++b) {
-        float s = 0.f;
-        const float *p = a.colsum + ((int64_t)b * a.ipb) * a.N + n;
-        for (int i = 0; i < a.ipb; ++i) s += p[(int64_t)i * a.N];
-        if (a.dimg) a.dimg[(int64_t)b * a.N + n] = s;
-        tot += s;
-    }
-    if (a.dbias) a.dbias[n] += tot;
+    for (int b = 0; b < a.B; ++b) tot += a.dimg[(int64_t)b * a.N + n];
+    a.dbias[n] += tot;
 }
 
 // ------------------------------------------------------------------------------------------------ stem backward
@@ -530,16 +563,19 @@ extern "C" int anoddpm_linear_small_backward(const anoddpm_linear_bwd_args *a, v
     const int64_t tw = (int64_t)a->N * (a->K / 4);
     hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)((tw + 255) / 256)), dim3(256), 0, s, *a);
     if (a->dx) {
-        const int64_t tx = (int64_t)a->B * a->K;
-        hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((unsigned)((tx + 255) / 256)), dim3(256), 0, s, *a);
+        const dim3 g((unsigned)((a->K + 63) / 64));
+        if (a->B <= 4) hipLaunchKernelGGL(linear_bwd_x_kernel<4>, g, dim3(1024), 0, s, *a);
+        else if (a->B <= 8) hipLaunchKernelGGL(linear_bwd_x_kernel<8>, g, dim3(1024), 0, s, *a);
+        else hipLaunchKernelGGL(linear_bwd_x_kernel<16>, g, dim3(1024), 0, s, *a);
     }
     return check_launch("linear_small_backward");
 }
 
 extern "C" int anoddpm_colsum_fold(const anoddpm_colsum_fold_args *a, void *stream)
 {
-    ANODDPM_REQUIRE(a && a->colsum && a->B >= 1 && a->ipb >= 1 && a->N >= 1, "colsum_fold: bad arguments");
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((a->N + 255) / 256)), dim3(256), 0, as_stream(stream), *a);
+    ANODDPM_REQUIRE(a && a->colsum && a->dimg && a->B >= 1 && a->B <= 65535 && a->ipb >= 1 && a->N >= 1, "colsum_fold: bad arguments");
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((a->N + 63) / 64), (unsigned)a->B), dim3(256), 0, as_stream(stream), *a);
+    if (a->dbias) hipLaunchKernelGGL(colsum_bias_kernel, dim3((unsigned)((a->N + 255) / 256)), dim3(256), 0, as_stream(stream), *a);
     return check_launch("colsum_fold");
 }
 

@@ -209,6 +209,7 @@ class UNetModel(nn.Module):
         self.up = nn.ModuleList([seq(b) for b in up])
         self.out = _indexed(_0=_Affine(out_ch), _2=_Weights((in_channels, self._final_cin, 3, 3), zero=True))
         self._plans = {}
+        self._tplans = {}
         self._weights_epoch = 0
 
     # ------------------------------------------------------------------ helpers
@@ -226,7 +227,7 @@ class UNetModel(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k == "_plans":
+            if k in ("_plans", "_tplans"):
                 new.__dict__[k] = {}
             else:
                 new.__dict__[k] = copy.deepcopy(v, memo)
@@ -235,6 +236,7 @@ class UNetModel(nn.Module):
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_plans"] = {}
+        d["_tplans"] = {}
         return d
 
     # ------------------------------------------------------------------ forward
@@ -273,8 +275,28 @@ class UNetModel(nn.Module):
         return plan
 
     # ------------------------------------------------------------------ differentiable forward (training)
+    def _train_plan_for(self, B, S, device, want_dx):
+        from .train_plan import TrainPlan
+        key = (B, S, device, bool(want_dx))
+        plan = self._tplans.get(key)
+        if plan is None or not plan.params_match():
+            plan = self._tplans[key] = TrainPlan(self, B, S, device, want_dx=want_dx)
+        return plan
+
     def _forward_autograd(self, x, time):
+        """Forward with autograd recording (training, diffusion_training.py:99-102).  Default: the native training plan
+        (train_plan.py: forward + backward as flat C-ABI op lists, no ATen / MIOpen compute).  ANODDPM_TRAIN_PLAN=0 selects the
+        per-operator autograd expression below (fused 3x3 blocks native, the rest PyTorch-ROCm); ANODDPM_TORCH_BACKWARD=1
+        the all-torch expression (also what runs with dropout > 0 or frozen parameters)."""
         _lib.require_cuda(x, "UNetModel.forward (training)")
+        if (x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[1] == self.in_channels
+                and not (self.dropout > 0 and self.training)
+                and os.environ.get("ANODDPM_TORCH_BACKWARD", "0") != "1" and os.environ.get("ANODDPM_TRAIN_PLAN", "1") != "0"):
+            from . import train_plan
+            params = list(self.parameters())
+            if train_plan.eligible(self, x.shape[0], x.shape[2]) and all(p.requires_grad for p in params):
+                plan = self._train_plan_for(x.shape[0], x.shape[2], x.device, x.requires_grad)
+                return train_plan.TrainPlanFunction.apply(x, time, params[0], plan)
         sd = dict(self.named_parameters())
 
         def P(k):
@@ -575,7 +597,7 @@ class _Plan:
         st.gn_ld = K
         self._pending_bmat = (st, bmat, wino)
         st.b_bs, st.b_hs = b_strides
-        st.bias = bias.data_ptr() if bias is not None else None
+        st.bias = (bias if isinstance(bias, int) else bias.data_ptr()) if bias is not None else None
         st.temb = temb if temb else None
         st.temb_ld = temb_ld
         st.res = (res if isinstance(res, int) else res.data_ptr()) if res is not None else None
@@ -602,6 +624,8 @@ class _Plan:
         _st, _bmat, _wino = self._pending_bmat
         if cfg == 2:
             _bmat = _wino()                                    # Winograd-domain weights for this layer
+        elif callable(_bmat):
+            _bmat = _bmat()                                    # packed lazily: only the layout this launch uses
         st.bmat = _bmat if isinstance(_bmat, int) else _bmat.data_ptr()
         st.ws = None                      # patched after the build (one shared workspace)
         if ksplit > 1:

@@ -364,25 +364,61 @@ def run_train(c, args, cfg):
     roofline = None
     if not args.no_prof:
         L = _lib.lib()
-        wg = _TimedEntry(L, "anoddpm_conv3x3_wgrad", lambda a: 2.0 * (a.c0 + a.c1) * a.N * 9 * a.H * a.W * a.B)
-        ig = _TimedEntry(L, "anoddpm_igemm", lambda a: 2.0 * (a.c0 + a.c1) * a.N * a.ks * a.ks * a.H * a.W * a.B * a.heads)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        prof_ms = 1000.0 * (time.perf_counter() - t1) / args.steps
-        w_ms, w_n, w_fl = wg.finish()
-        i_ms, i_n, i_fl = ig.finish()
-        ach = w_fl / (w_ms / 1000.0) / 1e12 if w_ms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "wgrad_kernel (3x3 weight gradient, nine-tap MFMA tiles, v_mfma_f32_32x32x2_f32)",
-                    "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MATRIX_TFLOPS,
-                    "traffic": None, "launches_per_step": w_n / args.steps, "avg_launch_ms": w_ms / max(w_n, 1),
-                    "gflop_per_launch": w_fl / max(w_n, 1) / 1e9, "ms_per_step": w_ms / args.steps,
-                    "other_contraction_kernel": {"kernel": "anoddpm_igemm launches (forward convs + data gradients; Winograd where eligible)",
-                                                 "algorithmic_tflops": i_fl / (i_ms / 1000.0) / 1e12 if i_ms > 0 else 0.0,
-                                                 "launches_per_step": i_n / args.steps, "ms_per_step": i_ms / args.steps},
-                    "instrumented_ms_per_step": prof_ms}
+        plan = next(iter(model._tplans.values()), None)
+        if plan is not None:
+            # native training plan: the C++ executor books every op class with HIP events on the launch stream
+            L.anoddpm_prof_enable(1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            prof_ms = 1000.0 * (time.perf_counter() - t1) / args.steps
+            ms = (ctypes.c_double * _lib.OP_MAX)()
+            cnt = (ctypes.c_int64 * _lib.OP_MAX)()
+            _lib.check(L.anoddpm_prof_collect(ms, cnt), "prof_collect")
+            L.anoddpm_prof_enable(0)
+            w_fl = sum(2.0 * (st.c0 + st.c1) * st.N * 9 * st.H * st.W * st.B for code, st in plan.bops if code == _lib.OP_WGRAD3)
+            w_ms, w_n = ms[_lib.OP_WGRAD3] / args.steps, cnt[_lib.OP_WGRAD3] / args.steps
+            i_fl = sum(2.0 * (st.c0 + st.c1) * st.N * st.ks * st.ks * st.H * st.W * st.B * st.heads
+                       for code, st in plan.ops + plan.bops if code == _lib.OP_IGEMM)
+            i_ms = (ms[_lib.OP_IGEMM] + ms[12]) / args.steps
+            names = {1: "igemm_direct", 12: "winograd", 3: "softmax", 4: "resample", 5: "linear", 6: "posemb", 7: "stem", 9: "chan_stats",
+                     10: "gn_finalize", 11: "head", 16: "wgrad3x3", 17: "wgrad_pointwise", 18: "gn_silu_backward", 19: "pack_weights",
+                     20: "softmax_backward", 21: "transpose", 22: "linear_backward", 23: "stem_backward", 24: "head_backward",
+                     25: "colsum_fold"}
+            ach = w_fl / (w_ms / 1000.0) / 1e12 if w_ms > 0 else 0.0
+            roofline = {"bound": "mfma", "kernel": "wgrad_kernel (3x3 weight gradient, nine-tap MFMA tiles, v_mfma_f32_32x32x2_f32)",
+                        "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MATRIX_TFLOPS,
+                        "traffic": None, "launches_per_step": w_n, "avg_launch_ms": w_ms / max(w_n, 1),
+                        "gflop_per_launch": w_fl / max(w_n, 1) / 1e9, "ms_per_step": w_ms,
+                        "other_contraction_kernel": {"kernel": "anoddpm_igemm launches (forward convs, data gradients, attention GEMMs; Winograd where eligible)",
+                                                     "algorithmic_tflops": i_fl / (i_ms / 1000.0) / 1e12 if i_ms > 0 else 0.0,
+                                                     "launches_per_step": (cnt[_lib.OP_IGEMM] + cnt[12]) / args.steps, "ms_per_step": i_ms},
+                        "class_ms_per_step": {names[c]: ms[c] / args.steps for c in names},
+                        "class_launches_per_step": {names[c]: cnt[c] / args.steps for c in names},
+                        "unet_ms_per_step": sum(ms[c] for c in names) / args.steps,
+                        "instrumented_ms_per_step": prof_ms}
+        else:
+            wg = _TimedEntry(L, "anoddpm_conv3x3_wgrad", lambda a: 2.0 * (a.c0 + a.c1) * a.N * 9 * a.H * a.W * a.B)
+            ig = _TimedEntry(L, "anoddpm_igemm", lambda a: 2.0 * (a.c0 + a.c1) * a.N * a.ks * a.ks * a.H * a.W * a.B * a.heads)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            prof_ms = 1000.0 * (time.perf_counter() - t1) / args.steps
+            w_ms, w_n, w_fl = wg.finish()
+            i_ms, i_n, i_fl = ig.finish()
+            ach = w_fl / (w_ms / 1000.0) / 1e12 if w_ms > 0 else 0.0
+            roofline = {"bound": "mfma", "kernel": "wgrad_kernel (3x3 weight gradient, nine-tap MFMA tiles, v_mfma_f32_32x32x2_f32)",
+                        "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MATRIX_TFLOPS,
+                        "traffic": None, "launches_per_step": w_n / args.steps, "avg_launch_ms": w_ms / max(w_n, 1),
+                        "gflop_per_launch": w_fl / max(w_n, 1) / 1e9, "ms_per_step": w_ms / args.steps,
+                        "other_contraction_kernel": {"kernel": "anoddpm_igemm launches (forward convs + data gradients; Winograd where eligible)",
+                                                     "algorithmic_tflops": i_fl / (i_ms / 1000.0) / 1e12 if i_ms > 0 else 0.0,
+                                                     "launches_per_step": i_n / args.steps, "ms_per_step": i_ms / args.steps},
+                        "instrumented_ms_per_step": prof_ms}
     out = {"metric": f"training images/sec @{cfg['img']}x{cfg['img']} (q_sample + UNet fwd/bwd + AdamW + EMA)", "value": value,
            "unit": "images/s", "ms_per_step": ms_per_step, "scaling": "weak", "dtype": "f32",
            "config": {"workload": cfg["name"], "per_gpu_batch": B, "global_batch": B * c.world,

@@ -604,11 +604,11 @@ typedef struct anoddpm_head_bwd_args {
 int anoddpm_conv_head_backward(const anoddpm_head_bwd_args *a, void *stream);
 
 /* Fold of the per-work-item column sums anoddpm_conv3x3_wgrad publishes ([B][ipb][N]: items of an image are
- * consecutive): dimg[b][n] = sum_items (written, optional: the embedding-projection gradient, UNet.py:213) and
+ * consecutive): dimg[b][n] = sum_items (written: the embedding-projection gradient, UNet.py:213) and
  * dbias[n] += sum_b dimg[b][n] (optional). */
 typedef struct anoddpm_colsum_fold_args {
     const float *colsum;
-    float *dimg;                    /* [B][N] or NULL */
+    float *dimg;                    /* [B][N], written (scratch when only the bias gradient is wanted) */
     float *dbias;                   /* [N] or NULL, accumulated into */
     int32_t B, ipb, N;
 } anoddpm_colsum_fold_args;

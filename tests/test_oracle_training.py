@@ -37,7 +37,7 @@ def check_against_fixture(g, step, keys, loss, grads, norm, params, ema, lr, tol
         # are rounding noise in every implementation: errors are measured against max(|ref|, 1e-4 of the largest gradient element)
         den = max(np.abs(ref).max(), 1e-4 * gabs)
         e = np.abs(got - ref).max() / den
-        en = abs(n - gn_ref[i]) / max(gn_ref[i], 1e-5 * gmax)
+        en = abs(n - gn_ref[i]) / max(gn_ref[i], 1e-4 * gmax)    # noise-level tensors (norm ~1e-8 of the largest): absolute
         worst = max(worst, (e, k), (en, k + " (norm)"))
     assert worst[0] < tol, worst
     # parameters / EMA after the step: Adam normalises the update to O(lr) per element, so errors are measured
@@ -47,6 +47,8 @@ def check_against_fixture(g, step, keys, loss, grads, norm, params, ema, lr, tol
     for i, k in enumerate(keys):
         d = np.abs(probe(params[k]) - g[p + "pprobe"][i])
         assert d.max() <= 2.2 * lr * nstep, (k, d.max())
+        if gn_ref[i] < 1e-4 * gmax:
+            continue          # noise-level gradient: Adam turns rounding noise into +-lr steps, only the bound above applies
         bad += int((d > 0.02 * lr).sum())
         tot += d.size
         de = np.abs(probe(ema[k]) - g[p + "eprobe"][i])
