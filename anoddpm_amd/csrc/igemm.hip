@@ -426,6 +426,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const anoddpm_igemm_
         const int z = (int)(zp / P);
         const int b = z / a.heads, hd = z % a.heads;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
         for (int ks = 0; ks < a.ksplit; ++ks)
             s += ld4(a.ws + ((((int64_t)ks * Z + z) * P + pix) * a.N) + n4 * 4);
         s *= a.alpha;

@@ -29,11 +29,39 @@ __constant__ signed char kGrad3[72] = {
     -11,-4,-4,  -4,-11,-4,  -4,-4,-11,   11,-4,-4,   4,-11,-4,   4,-4,-11,
 };
 
+// LDS tables.  The 24 gradient vectors have components +-4 / +-11: exact in the high dword of a double (low dword 0), so a
+// vertex fetches its whole gradient with ONE 16-byte LDS read instead of three 8-byte ones.
 struct Tables {
     unsigned char perm[256];
-    unsigned char pgi3[256];
-    double grad[72];
+    unsigned char g24[256];          // gradient index perm % 24 (the reference's pgi3 / 3)
+    int4 gradhi[24];                 // {hi(gx), hi(gy), hi(gz), 0}
 };
+
+__device__ __forceinline__ void load_tables(Tables &T, const int16_t *src)
+{
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        T.perm[i] = (unsigned char)src[i];
+        T.g24[i] = (unsigned char)(src[256 + i] / 3);
+    }
+    if (threadIdx.x < 24) {
+        const int g = threadIdx.x;
+        T.gradhi[g] = make_int4(__double2hiint((double)kGrad3[3 * g]), __double2hiint((double)kGrad3[3 * g + 1]),
+                                __double2hiint((double)kGrad3[3 * g + 2]), 0);
+    }
+    __syncthreads();
+}
+
+// x / 103 with IEEE rounding from the correctly rounded reciprocal and two FMAs (Markstein): q = x*r, q' = q + (x - 103 q) r.
+// Exact for every normal-range quotient (checked against hardware division on 4e8 samples, incl. random bit patterns); values
+// near the under / overflow thresholds take the plain division.
+__device__ __forceinline__ double div_norm3(double v)
+{
+    const double av = fabs(v);
+    if (!(av > 1e-280 && av < 1e280)) return v / NORM3;
+    const double r = 1.0 / NORM3;
+    const double q = v * r;
+    return fma(fma(-NORM3, q, v), r, q);
+}
 
 struct Vtx {
     int i, j, k;        // lattice offset
@@ -49,7 +77,7 @@ __device__ __forceinline__ double component(double d0, int off, double sq, int l
     return ((d0 - A) - sq) - C;
 }
 
-__device__ __forceinline__ double vertex_term(const Tables &T, long long xsb, long long ysb, long long zsb,
+__device__ __forceinline__ double vertex_term(const Tables &T, int xsb, int ysb, int zsb,
                                               double dx0, double dy0, double dz0, Vtx v, bool on)
 {
     const int n = v.i + v.j + v.k;
@@ -58,32 +86,39 @@ __device__ __forceinline__ double vertex_term(const Tables &T, long long xsb, lo
     const double dy = component(dy0, v.j, sq, v.ly);
     const double dz = component(dz0, v.k, sq, v.lz);
     double attn = 2 - dx * dx - dy * dy - dz * dz;
-    double r = 0.0;
-    if (on && attn > 0) {
-        const int h0 = T.perm[(int)((xsb + v.i) & 0xFF)];
-        const int h1 = T.perm[(int)((h0 + ysb + v.j) & 0xFF)];
-        const int gi = T.pgi3[(int)((h1 + zsb + v.k) & 0xFF)];
-        attn *= attn;
-        r = attn * attn * (T.grad[gi] * dx + T.grad[gi + 1] * dy + T.grad[gi + 2] * dz);
-    }
-    return r;
+    // branch-free: the hash chain and the gradient read always run (indices are masked, so always valid); a vertex outside
+    // the kernel radius or an unused slot contributes +0.0 exactly as the reference's skipped term does
+    const int h0 = T.perm[(xsb + v.i) & 0xFF];
+    const int h1 = T.perm[(h0 + ysb + v.j) & 0xFF];
+    const int g = T.g24[(h1 + zsb + v.k) & 0xFF];
+    const int4 gh = T.gradhi[g];
+    const double gx = __hiloint2double(gh.x, 0), gy = __hiloint2double(gh.y, 0), gz = __hiloint2double(gh.z, 0);
+    attn = on ? fmax(attn, 0.0) : 0.0;              // out of radius / unused: +0.0, a signed-zero term leaves the sum unchanged
+    attn *= attn;
+    return attn * attn * (gx * dx + gy * dy + gz * dz);
 }
 
-__device__ double noise3(const Tables &T, double x, double y, double z)
+__device__ __forceinline__ double noise3(const Tables &T, double x, double y, double z)
 {
     const double stretch = (x + y + z) * STRETCH3;
     const double xs = x + stretch, ys = y + stretch, zs = z + stretch;
     const double fx = floor(xs), fy = floor(ys), fz = floor(zs);
-    const long long xsb = (long long)fx, ysb = (long long)fy, zsb = (long long)fz;
-    const double squish = (double)(xsb + ysb + zsb) * SQUISH3;
-    const double xb = (double)xsb + squish, yb = (double)ysb + squish, zb = (double)zsb + squish;
-    const double xins = xs - (double)xsb, yins = ys - (double)ysb, zins = zs - (double)zsb;
+    // lattice base: only (xsb + i) & 0xFF reaches the hash, and (double)(xsb + ysb + zsb) == fx + fy + fz exactly while the
+    // floors stay below 2^50; beyond 2^31 (never in practice) the low bits come from the 64-bit conversion
+    int xsb, ysb, zsb;
+    if (fabs(fx) < 2147483000.0 && fabs(fy) < 2147483000.0 && fabs(fz) < 2147483000.0) {
+        xsb = (int)fx; ysb = (int)fy; zsb = (int)fz;
+    } else {
+        xsb = (int)((long long)fx & 0xFF); ysb = (int)((long long)fy & 0xFF); zsb = (int)((long long)fz & 0xFF);
+    }
+    const double squish = ((fx + fy) + fz) * SQUISH3;
+    const double xb = fx + squish, yb = fy + squish, zb = fz + squish;
+    const double xins = xs - fx, yins = ys - fy, zins = zs - fz;
     const double in_sum = xins + yins + zins;
     const double dx0 = x - xb, dy0 = y - yb, dz0 = z - zb;
 
     Vtx e0 = mk(0, 0, 0), e1 = mk(0, 0, 0);
-    int body;       // six 3-bit vertex codes (bit0 = +x, bit1 = +y, bit2 = +z), slot s at bits [3s,3s+3)
-    int nbody;
+    int body;       // bit c set: cube corner c (bit0 = +x, bit1 = +y, bit2 = +z) is on this region's vertex list
 
     if (in_sum <= 1) {                       // tetrahedron at (0,0,0): simplex.py:354-468
         int ap = 1, bp = 2;
@@ -101,8 +136,7 @@ __device__ double noise3(const Tables &T, double x, double y, double z)
             e0 = mk(c & 1, (c >> 1) & 1, (c >> 2) & 1);
             e1 = mk((c & 1) ? 1 : -1, (c & 2) ? 1 : -1, (c & 4) ? 1 : -1);
         }
-        body = 0 | (1 << 3) | (2 << 6) | (4 << 9);
-        nbody = 4;
+        body = 0x17;                         // corners 0, 1, 2, 4
     } else if (in_sum >= 2) {                // tetrahedron at (1,1,1): simplex.py:469-586
         int ap = 6, bp = 5;
         double as = xins, bs = yins;
@@ -122,8 +156,7 @@ __device__ double noise3(const Tables &T, double x, double y, double z)
             e0 = mk(c & 1, (c >> 1) & 1, (c >> 2) & 1);
             e1 = mk(2 * (c & 1), 2 * ((c >> 1) & 1), 2 * ((c >> 2) & 1));
         }
-        body = 3 | (5 << 3) | (6 << 6) | (7 << 9);
-        nbody = 4;
+        body = 0xE8;                         // corners 3, 5, 6, 7
     } else {                                 // octahedron: simplex.py:587-798
         double as, bs;
         int ap, bp;
@@ -157,20 +190,44 @@ __device__ double noise3(const Tables &T, double x, double y, double z)
             else if (c2 & 2) { e1 = mk(0, 2, 0); e1.ly = 2; }
             else             { e1 = mk(0, 0, 2); e1.lz = 2; }
         }
-        body = 1 | (2 << 3) | (4 << 6) | (3 << 9) | (5 << 12) | (6 << 15);
-        nbody = 6;
+        body = 0x7E;                         // corners 1, 2, 4, 3, 5, 6
     }
 
-    double value = 0.0;
+    // ---- the unit cube's corners.  Every region's vertex list is a subset of the eight corners taken in the order
+    // 0,1,2,4,3,5,6,7 (tetra0: 0 1 2 4; octahedron: 1 2 4 3 5 6; tetra1: 3 5 6 7), so all eight are evaluated with COMPILE-TIME
+    // offsets -- displacement (d0 - i) - n*SQUISH, hash chain shared per (i) and (i,j) -- and a corner outside the region's
+    // list contributes +0.0, exactly like an out-of-radius vertex.  This replaces per-slot decoding of runtime vertex codes.
+    const double X[2] = {dx0, dx0 - 1.0}, Y[2] = {dy0, dy0 - 1.0}, Z[2] = {dz0, dz0 - 1.0};
+    const double SQ[4] = {0.0, 1.0 * SQUISH3, 2.0 * SQUISH3, 3.0 * SQUISH3};
+    int h0[2], h1[2][2];
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const int code = (body >> (3 * s)) & 7;
-        value += vertex_term(T, xsb, ysb, zsb, dx0, dy0, dz0,
-                             mk(code & 1, (code >> 1) & 1, (code >> 2) & 1), s < nbody);
+    for (int i = 0; i < 2; ++i) h0[i] = T.perm[(xsb + i) & 0xFF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) h1[i][j] = T.perm[(h0[i] + ysb + j) & 0xFF];
+    double value = 0.0;
+    constexpr int ORDER[8] = {0, 1, 2, 4, 3, 5, 6, 7};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int code = ORDER[s];
+        const bool listed = (body >> code) & 1;
+        const int i = code & 1, j = (code >> 1) & 1, k = (code >> 2) & 1, n = i + j + k;
+        const double dx = n ? X[i] - SQ[n] : X[i];
+        const double dy = n ? Y[j] - SQ[n] : Y[j];
+        const double dz = n ? Z[k] - SQ[n] : Z[k];
+        double attn = 2 - dx * dx - dy * dy - dz * dz;
+        const int g = T.g24[(h1[i][j] + zsb + k) & 0xFF];
+        const int4 gh = T.gradhi[g];
+        const double gx = __hiloint2double(gh.x, 0), gy = __hiloint2double(gh.y, 0), gz = __hiloint2double(gh.z, 0);
+        // attn <= 0 or an unlisted corner -> attn := +0.0, and 0^4 * (g . d) is a signed zero that leaves the sum unchanged
+        attn = listed ? fmax(attn, 0.0) : 0.0;
+        attn *= attn;
+        value += attn * attn * (gx * dx + gy * dy + gz * dz);
     }
     value += vertex_term(T, xsb, ysb, zsb, dx0, dy0, dz0, e0, true);
     value += vertex_term(T, xsb, ysb, zsb, dx0, dy0, dz0, e1, true);
-    return value / NORM3;
+    return div_norm3(value);
 }
 
 template <typename OutT>
@@ -180,13 +237,7 @@ __global__ __launch_bounds__(256) void simplex3_octaves_kernel(anoddpm_simplex_a
     const int s = blockIdx.z;
     long long tab = (a.table_sel ? (long long)(*a.table_sel) * a.table_sel_scale : 0) +
                     (long long)s * a.table_slice_stride;
-    const int16_t *src = a.tables + tab * 512;
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-        T.perm[i] = (unsigned char)src[i];
-        T.pgi3[i] = (unsigned char)src[256 + i];
-    }
-    if (threadIdx.x < 72) T.grad[threadIdx.x] = (double)kGrad3[threadIdx.x];
-    __syncthreads();
+    load_tables(T, a.tables + tab * 512);
 
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -194,8 +245,15 @@ __global__ __launch_bounds__(256) void simplex3_octaves_kernel(anoddpm_simplex_a
     const long long zi = a.zvals ? a.zvals[s] : a.z0 + s;
 
     double acc = 0.0, amp = 1.0, f = a.frequency;
+    // x / f: when f is a power of two (every frequency the reference uses: 64, 2^i, and their halvings) the quotient is an
+    // exact scaling and equals x * (1/f) bit for bit; any other f takes the IEEE division
+    int fe;
+    const bool pow2 = (frexp(f, &fe) == 0.5) && fe > -900 && fe - a.octaves > -900 && fe < 900;
     for (int o = 0; o < a.octaves; ++o) {
-        const double n = noise3(T, (double)x / f, (double)y / f, (double)zi / f);
+        double cx, cy, cz;
+        if (pow2) { const double rf = 1.0 / f; cx = (double)x * rf; cy = (double)y * rf; cz = (double)zi * rf; }
+        else      { cx = (double)x / f; cy = (double)y / f; cz = (double)zi / f; }
+        const double n = noise3(T, cx, cy, cz);
         acc = acc + amp * n;            // noise += amplitude * field, octave 0 first (simplex.py:90)
         f = f / 2;
         amp = amp * a.persistence;
@@ -209,12 +267,7 @@ __global__ __launch_bounds__(256) void simplex3_grid_kernel(double *out, const d
                                                             const double *Z, int nz, const int16_t *tables)
 {
     __shared__ Tables T;
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-        T.perm[i] = (unsigned char)tables[i];
-        T.pgi3[i] = (unsigned char)tables[256 + i];
-    }
-    if (threadIdx.x < 72) T.grad[threadIdx.x] = (double)kGrad3[threadIdx.x];
-    __syncthreads();
+    load_tables(T, tables);
     const long long total = (long long)nx * ny * nz;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int ix = (int)(i % nx);

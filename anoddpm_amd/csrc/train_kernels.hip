@@ -259,7 +259,8 @@ __global__ __launch_bounds__(1024) void linear_bwd_x_kernel(const anoddpm_linear
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = 0.f;
     if (k < a.K)
-        for (int n = wave; n < a.N; n += 16) {
+#pragma unroll 8
+        for (int n = wave; n < a.N; n += 16) {                         // 8 independent weight loads in flight
             const float w = a.w[(int64_t)n * a.K + k];
 #pragma unroll
             for (int b = 0; b < NB; ++b)

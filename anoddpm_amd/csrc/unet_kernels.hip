@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void gn_finalize2_kernel(anoddpm_gn_finalize_a
         else             { st = a.stats1; rows = a.rows1; cl = cbeg - a.c0; cw = a.c1; }
         st += (int64_t)b * rows * cw * 2 + (int64_t)cl * 2;
         const int nq = cpg >> 1;
-        for (int r = tid; r < rows; r += 256) {
+#pragma unroll 4
+        for (int r = tid; r < rows; r += 256) {                        // independent row loads: keep four in flight
             const float4 *p = reinterpret_cast<const float4 *>(st + (int64_t)r * cw * 2);
             for (int k = 0; k < nq; ++k) {
                 const float4 v = p[k];
