@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 (OP_WGRAD3, OP_WGRAD1, OP_GN_BWD, OP_PACK, OP_SOFTMAX_BWD, OP_TRANSPOSE, OP_LINEAR_BWD, OP_STEM_BWD, OP_HEAD_BWD,
@@ -194,12 +194,25 @@ class ColsumFoldArgs(Structure):
     _fields_ = [("colsum", c_void_p), ("dimg", c_void_p), ("dbias", c_void_p), ("B", c_int32), ("ipb", c_int32), ("N", c_int32)]
 
 
+class MriSliceArgs(Structure):
+    _fields_ = [("vols", c_void_p), ("ydim", c_void_p), ("slice_idx", c_void_p), ("affine", c_void_p), ("out", c_void_p),
+                ("B", c_int32), ("X", c_int32), ("Z", c_int32), ("crop", c_int32), ("pad_left", c_int32), ("crop_top", c_int32)]
+
+
+class ResizeArgs(Structure):
+    _fields_ = [("inp", c_void_p), ("tmp", c_void_p), ("out", c_void_p), ("kx", c_void_p), ("kx_min", c_void_p), ("kx_n", c_void_p),
+                ("ky", c_void_p), ("ky_min", c_void_p), ("ky_n", c_void_p),
+                ("B", c_int32), ("in_h", c_int32), ("in_w", c_int32), ("out_h", c_int32), ("out_w", c_int32),
+                ("kmax_x", c_int32), ("kmax_y", c_int32), ("mean", c_float), ("std", c_float), ("normalize", c_int32)]
+
+
 ANOMALY_NCOUNTS = 12
 ANOMALY_BLOCKS = 64
 
 _STRUCTS = [SimplexArgs, PUpdateArgs, IgemmArgs, GnArgs, SoftmaxArgs, ResampleArgs, LinearArgs,
             PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, AnomalyArgs, VlbArgs, WgradArgs, GnBwdArgs,
-            Wgrad1Args, PackArgs, SoftmaxBwdArgs, TransposeArgs, LinearBwdArgs, StemBwdArgs, HeadBwdArgs, ColsumFoldArgs]
+            Wgrad1Args, PackArgs, SoftmaxBwdArgs, TransposeArgs, LinearBwdArgs, StemBwdArgs, HeadBwdArgs, ColsumFoldArgs,
+            MriSliceArgs, ResizeArgs]
 
 # every symbol include/anoddpm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -213,6 +226,7 @@ SYMBOLS = [
     "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map", "anoddpm_vlb_terms", "anoddpm_conv3x3_wgrad", "anoddpm_gn_silu_backward", "anoddpm_pack_conv3x3",
     "anoddpm_wgrad_pointwise", "anoddpm_pack_weights", "anoddpm_softmax_rows_backward", "anoddpm_transpose_square",
     "anoddpm_linear_small_backward", "anoddpm_conv_stem_backward", "anoddpm_conv_head_backward", "anoddpm_colsum_fold",
+    "anoddpm_volume_normalise", "anoddpm_mri_slice_prepare", "anoddpm_resize_bilinear_pil",
 ]
 
 _lib = None
@@ -296,6 +310,9 @@ def lib():
     L.anoddpm_conv_stem_backward.argtypes = [POINTER(StemBwdArgs), c_void_p]
     L.anoddpm_conv_head_backward.argtypes = [POINTER(HeadBwdArgs), c_void_p]
     L.anoddpm_colsum_fold.argtypes = [POINTER(ColsumFoldArgs), c_void_p]
+    L.anoddpm_volume_normalise.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
+    L.anoddpm_mri_slice_prepare.argtypes = [POINTER(MriSliceArgs), c_void_p]
+    L.anoddpm_resize_bilinear_pil.argtypes = [POINTER(ResizeArgs), c_void_p]
     for i in range(8):
         if os.environ.get(f"ANODDPM_DEBUG{i}"):
             L.anoddpm_debug_set(i, int(os.environ[f"ANODDPM_DEBUG{i}"], 0))

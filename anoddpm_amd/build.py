@@ -27,6 +27,7 @@ SOURCES = {
     "wgrad.hip": [],
     "gn_backward.hip": [],
     "train_kernels.hip": [],
+    "loader.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

@@ -68,7 +68,7 @@ extern "C" int anoddpm_debug_set(int32_t key, int32_t value)
     return ANODDPM_OK;
 }
 
-extern "C" int anoddpm_abi_version(void) { return 10; }
+extern "C" int anoddpm_abi_version(void) { return 11; }
 
 extern "C" const char *anoddpm_last_error(void) { return g_err; }
 
@@ -179,6 +179,8 @@ extern "C" int anoddpm_struct_size(int32_t which)
         case 24: return (int)sizeof(anoddpm_stem_bwd_args);
         case 25: return (int)sizeof(anoddpm_head_bwd_args);
         case 26: return (int)sizeof(anoddpm_colsum_fold_args);
+        case 27: return (int)sizeof(anoddpm_mri_slice_args);
+        case 28: return (int)sizeof(anoddpm_resize_args);
         default: return -1;
     }
 }

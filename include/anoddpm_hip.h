@@ -615,6 +615,42 @@ typedef struct anoddpm_colsum_fold_args {
 
 int anoddpm_colsum_fold(const anoddpm_colsum_fold_args *a, void *stream);
 
+/* ------------------------------------------------------------------ MRI slice loader (dataset.py:575-643) ----------
+ * Volume normalisation of MRIDataset.__getitem__ (dataset.py:585-592): clip to [mean - std, mean + 2 std] (population
+ * std, fp64 two-pass), divide by the range, store fp32.  workspace: >= 2*256 + 4 doubles [dev]. */
+int anoddpm_volume_normalise(const double *vol, int64_t n, float *out, double *workspace, void *stream);
+
+/* Slice cut (dataset.py:621: image[:, s:s+1, :].reshape(X, Z)), optional RandomAffine resampling (PIL AFFINE / NEAREST:
+ * affine = six 16.16 fixed-point coefficients per item, source = (a2 + a0 x + a1 y) >> 16, (a5 + a3 x + a4 y) >> 16, fill 0)
+ * and torchvision CenterCrop(crop) with its zero padding: out[b][oy][ox] = img[oy + crop_top][ox - pad_left]. */
+typedef struct anoddpm_mri_slice_args {
+    const float *const *vols;       /* [dev] B pointers to resident fp32 volumes [X][Y_b][Z] */
+    const int32_t *ydim;            /* [dev] Y_b */
+    const int32_t *slice_idx;       /* [dev] */
+    const long long *affine;        /* [dev] [B][6] or NULL (no augmentation) */
+    float *out;                     /* [B][crop][crop] */
+    int32_t B, X, Z, crop, pad_left, crop_top;
+} anoddpm_mri_slice_args;
+
+int anoddpm_mri_slice_prepare(const anoddpm_mri_slice_args *a, void *stream);
+
+/* PIL Image.resize(BILINEAR) on fp32 images (what torchvision Resize does to a mode-"F" image), then optionally
+ * Normalize: out = (v - mean) / std.  Coefficient tables are PIL's precompute_coeffs (host, fp64): for output index o the
+ * taps in[kmin[o] .. kmin[o] + kn[o]) with weights k[o][0 .. kn[o]), row length kmax.  tmp: [B][in_h][out_w] floats. */
+typedef struct anoddpm_resize_args {
+    const float *in;                /* [B][in_h][in_w] */
+    float *tmp, *out;               /* out: [B][out_h][out_w] */
+    const double *kx;               /* [out_w][kmax_x] */
+    const int32_t *kx_min, *kx_n;
+    const double *ky;               /* [out_h][kmax_y] */
+    const int32_t *ky_min, *ky_n;
+    int32_t B, in_h, in_w, out_h, out_w, kmax_x, kmax_y;
+    float mean, std;
+    int32_t normalize;
+} anoddpm_resize_args;
+
+int anoddpm_resize_bilinear_pil(const anoddpm_resize_args *a, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

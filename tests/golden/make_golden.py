@@ -349,6 +349,80 @@ def gen_detection():
     print("detection_fixedT.npz", out.shape, float(out.abs().mean()))
 
 
+def gen_loader():
+    """MRIDataset (dataset.py:575-643) run by the reference on a synthetic NIfTI-shaped volume (nibabel stubbed: `nib.load`
+    returns an object whose get_fdata() is the array): the normalised .npy cache it writes and the slices it cuts.  The
+    default transform needs torchvision, which is not installed; its deterministic stages are Pillow calls, so the fixture
+    holds Pillow's own outputs for centre-crop-235 + BILINEAR resize (+ Normalize) and for AFFINE / NEAREST with matrices
+    built by oracle/loader_oracle.py's restatement of torchvision's parameter glue."""
+    import importlib
+    import tempfile
+    import types
+    from PIL import Image
+    from oracle import loader_oracle as lo
+    vol = lo.synthetic_volume()
+    saved = {k: sys.modules.get(k) for k in ("cv2", "nibabel", "torchvision", "dataset")}
+    nib = types.ModuleType("nibabel")
+    nib.load = lambda path: types.SimpleNamespace(get_fdata=lambda: vol)
+    sys.modules["nibabel"] = nib
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    tv = types.ModuleType("torchvision")
+    tv.datasets, tv.transforms = types.ModuleType("torchvision.datasets"), types.ModuleType("torchvision.transforms")
+    sys.modules["torchvision"] = tv
+    sys.path.insert(0, _refimport.REF)
+    try:
+        sys.modules.pop("dataset", None)
+        ref_ds = importlib.import_module("dataset")
+    finally:
+        sys.path.remove(_refimport.REF)
+    out = {"volume_probe": vol.flatten()[::9973].copy()}     # the volume itself is regenerated by loader_oracle.synthetic_volume()
+    with tempfile.TemporaryDirectory() as root:
+        os.makedirs(os.path.join(root, "vol0"))
+        ds = ref_ds.MRIDataset(root, transform=lambda a: a, img_size=(64, 64), random_slice=False)
+        s80 = ds[0]["image"]                                 # writes vol0/vol0.npy, returns the slice at 80
+        npy = np.load(os.path.join(root, "vol0", "vol0.npy"))
+        out["npy_shape"] = np.array(npy.shape, dtype=np.int64)
+        out["npy_probe"] = npy.flatten()[::97].copy()
+        out["npy_stats"] = np.array([npy.astype(np.float64).mean(), npy.astype(np.float64).std(), npy.min(), npy.max()])
+        out["slice80"] = s80
+        import random
+        random.seed(5)
+        ds2 = ref_ds.MRIDataset(root, transform=lambda a: a, img_size=(64, 64), random_slice=True)
+        sl = [ds2[0]["image"] for _ in range(3)]
+        random.seed(5)
+        out["random_slices_idx"] = np.array([random.randint(40, 100) for _ in range(3)], dtype=np.int64)
+        out["random_slices"] = np.stack(sl)
+    for k, v in saved.items():
+        if v is not None:
+            sys.modules[k] = v
+        else:
+            sys.modules.pop(k, None)
+    # deterministic transform stages through Pillow itself
+    img = Image.fromarray(s80, mode="F")                     # torchvision ToPILImage of a float32 2-D array
+    w, h = img.size
+    pl, pt, ct, cl = lo.center_crop_geometry(h, w, 235)
+    padded = Image.new("F", (w + pl + (235 - w + 1) // 2 if 235 > w else w, h), 0.0)
+    padded.paste(img, (pl, pt))
+    cropped = padded.crop((cl, ct, cl + 235, ct + 235))
+    out["crop235"] = np.array(cropped)
+    for (oh, ow) in ((64, 64), (256, 256), (32, 48)):
+        r = np.array(cropped.resize((ow, oh), Image.BILINEAR))
+        out[f"resized_{oh}x{ow}"] = r
+        out[f"final_{oh}x{ow}"] = ((torch.from_numpy(r) - 0.5) / 0.5).numpy()[None]           # ToTensor + Normalize(0.5, 0.5)
+    params = [(2.3, (3, -17)), (-2.9, (-2, 20)), (0.7, (0, 5))]
+    out["affine_angle"] = np.array([p[0] for p in params])
+    out["affine_translate"] = np.array([p[1] for p in params], dtype=np.int64)
+    for i, (ang, tr) in enumerate(params):
+        m = lo.inverse_affine_matrix((w * 0.5, h * 0.5), ang, tr)
+        a = img.transform((w, h), Image.AFFINE, m, Image.NEAREST, fillcolor=0)
+        out[f"affine{i}"] = np.array(a)
+        pa = Image.new("F", padded.size, 0.0)
+        pa.paste(a, (pl, pt))
+        out[f"affine{i}_final_64x64"] = ((torch.from_numpy(np.array(pa.crop((cl, ct, cl + 235, ct + 235)).resize((64, 64), Image.BILINEAR))) - 0.5) / 0.5).numpy()[None]
+    np.savez_compressed(os.path.join(HERE, "mri_loader.npz"), **out)
+    print("mri_loader.npz", {k: getattr(v, "shape", ()) for k, v in out.items()})
+
+
 def gen_metrics():
     """Anomaly-map arithmetic and segmentation metrics: the reference's evaluation.py functions (called) and the
     inline tensor expressions of GaussianDiffusion.py:572, 581-583 / detection.py:229-232 (evaluated with torch CPU)."""
