@@ -21,6 +21,7 @@ SOURCES = {
     "unet_kernels.hip": [],
     "igemm.hip": [],
     "winograd.hip": [],
+    "winograd43.hip": [],
     "executor.hip": [],
     "optim.hip": [],
     "metrics.hip": ["-ffp-contract=off"],

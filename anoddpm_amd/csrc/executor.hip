@@ -99,9 +99,9 @@ extern "C" int anoddpm_run_ops(const anoddpm_op *ops, int32_t n, void *stream)
             e0 = g_prof.pool[g_prof.used];
             e1 = g_prof.pool[g_prof.used + 1];
             g_prof.used += 2;
-            // Winograd launches of anoddpm_igemm are booked under code 12 so the dominant kernel can be priced alone
-            const bool wino = ops[i].code == ANODDPM_OP_IGEMM && static_cast<const anoddpm_igemm_args *>(ops[i].args)->cfg == 2;
-            g_prof.codes.push_back(wino ? 12 : ops[i].code);
+            // Winograd launches of anoddpm_igemm are booked under code 12 (F(2x2,3x3)) / 14 (F(4x4,3x3)) so the dominant kernels can be priced alone
+            const int icfg = ops[i].code == ANODDPM_OP_IGEMM ? static_cast<const anoddpm_igemm_args *>(ops[i].args)->cfg : 0;
+            g_prof.codes.push_back(icfg == 2 ? 12 : (icfg == 3 ? 14 : ops[i].code));
             (void)hipEventRecord(e0, as_stream(stream));
         }
         const int rc = dispatch(ops[i], stream);

@@ -1,0 +1,344 @@
+// Winograd F(4x4,3x3) convolution on the fp32 matrix pipe (cfg = 3 of anoddpm_igemm) -- the large-map twin of winograd.hip.
+//
+// Same contract as cfg 2 (nn.Conv2d 3x3 / stride 1 / pad 1, UNet.py:172,193, with GroupNorm-apply + SiLU, nearest-x2, two-source
+// concat fused into the operand load and bias / time-embedding / residual / GroupNorm statistics in the epilogue), but a
+// 4x4 output tile costs 36 multiplies instead of 144: 4x fewer MFMAs than the direct form, 1.78x fewer than F(2x2,3x3).
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A,   B^T 6x6, G 6x3, A^T 4x6  (Lavin & Gray, interpolation points 0, +-1, +-2, inf)
+// fp32 throughout; the wider transforms cost accuracy -- measured ~8e-6 of the output's magnitude per layer against 4e-7 for
+// F(2x2,3x3) -- so the launcher (unet.choose_conv_cfg) uses this kernel only on the large maps where it pays (>= 128x128),
+// inside the 1e-3 activation budget of the north star.
+//
+// Mapping to gfx950.  36 transform positions x (16 tiles x 128 channels) of accumulators is 288 KB: the whole register file of
+// a CU minus operands, so ONE 768-thread workgroup (12 waves, 3 per SIMD, <= 168 VGPRs) owns a 16x16 output patch x 128 output
+// channels; wave w accumulates positions 3w .. 3w+2 with v_mfma_f32_16x16x4_f32 (16 tiles x 16 channels x 4 k, same rate as the
+// 32x32x2 form).  K advances 16 channels per iteration:
+//   * the activated 18x18 halo patch is double-buffered in LDS (fetched two iterations ahead, scalar in-loop addressing);
+//   * all twelve waves compute B^T d B for the NEXT chunk (768 items = 16 tiles x 8 channel pairs x 6 transform rows) into a
+//     double-buffered V[pos][tile][quad] array, so the MFMA A operands are one ds_read_b128 per position;
+//   * the B operands U[pos][k][n] stream from L2 as 16-byte loads (layout [36][K/4][N][4]: one load = one lane's four k);
+//   * 96 MFMAs per wave per iteration, one barrier per iteration.
+// Epilogue: the 36 x 16 x 128 products go through LDS in two rounds of 64 channels (157 KB, aliasing the loop buffers); one
+// thread per (tile, channel) forms A^T M A, adds bias / temb / residual, stores 16 pixels and folds the GroupNorm sums.
+#include "common.h"
+
+using anoddpm::silu_f;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int F4_NT = 768;                 // threads
+constexpr int F4_KC = 16;                  // channels per K iteration
+constexpr int F4_PW = 18;                  // patch width / height (16 + 2)
+constexpr int F4_PPIX = F4_PW * F4_PW;     // 324 patch pixels
+constexpr int F4_PITCH = 5;                // float4 per patch pixel (4 quads + 1 pad)
+constexpr int F4_PJ = 2;                   // staging slots per thread (2 * 768 = 1536 >= 324 * 4)
+constexpr int F4_SLOTPX = F4_PJ * F4_NT / 4;          // 384 pixel slots per buffer
+constexpr int F4_DT = F4_SLOTPX * F4_PITCH;           // float4 per patch buffer
+constexpr int F4_V = 36 * 16 * 4;                     // float4 per V buffer: [pos][tile][quad]
+constexpr int F4_MS = 68;                             // floats per (pos, tile) row of the exchange buffer (64 channels + pad)
+constexpr int F4_LOOP_FLOATS = (2 * F4_DT + 2 * F4_V) * 4;
+constexpr int F4_EX_FLOATS = 36 * 16 * F4_MS;
+constexpr int F4_LDS_FLOATS = F4_EX_FLOATS > F4_LOOP_FLOATS ? F4_EX_FLOATS : F4_LOOP_FLOATS;
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc43(const float *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7ffffffe, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned wave_bytes)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)wave_bytes, 0));
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_args a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[F4_LDS_FLOATS];
+    f32x4 *ldsD = reinterpret_cast<f32x4 *>(lds);
+    f32x4 *ldsV = ldsD + 2 * F4_DT;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W;
+    const int K = a.c0 + a.c1, N = a.N, K4 = K >> 2;
+    const int tiles_x = W >> 4;
+    const int y0 = (blockIdx.x / tiles_x) * 16, x0 = (blockIdx.x % tiles_x) * 16;
+    const int n0 = blockIdx.y * 128;
+    const int b = blockIdx.z;
+    const int a_mode = a.a_mode;
+
+    const float *A0 = a.a0 + (int64_t)b * a.a0_bs;
+    const float *A1 = a.a1 ? a.a1 + (int64_t)b * a.a1_bs : nullptr;
+    const float *gsc = a.gn_scale ? a.gn_scale + (int64_t)b * a.gn_ld : nullptr;
+    const float *gsh = a.gn_shift ? a.gn_shift + (int64_t)b * a.gn_ld : nullptr;
+    const bool affine = gsc != nullptr, act = a.act != 0;
+    const int nchunks = K / F4_KC;
+
+    // ---- patch staging (pixel = idx >> 2, quad = idx & 3): geometry fixed for the workgroup
+    int spix[F4_PJ];
+    const int pq = tid & 3;
+#pragma unroll
+    for (int j = 0; j < F4_PJ; ++j) {
+        const int p = (tid + j * F4_NT) >> 2;
+        const int py = p / F4_PW, px = p - py * F4_PW;
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        int sp = -1;
+        if (p < F4_PPIX && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            sp = (a_mode == 0) ? gy * W + gx : (gy >> 1) * (W >> 1) + (gx >> 1);
+        spix[j] = sp;
+    }
+    f32x4 praw[F4_PJ];
+    f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rA0 = rsrc43(A0), rA1 = rsrc43(A1 ? A1 : A0);
+    const __amdgpu_buffer_rsrc_t rSc = rsrc43(gsc ? gsc : A0), rSh = rsrc43(gsh ? gsh : A0);
+    auto load_patch = [&](int chunk) {                              // unconditional loads, clamped addresses
+        const int kbase = chunk * F4_KC;
+        const bool first = kbase < a.c0;
+        const __amdgpu_buffer_rsrc_t r = first ? rA0 : rA1;
+        const unsigned ld = (unsigned)(first ? a.a0_ld : a.a1_ld);
+        const unsigned koff = (unsigned)(first ? kbase : kbase - a.c0) * 4u;
+#pragma unroll
+        for (int j = 0; j < F4_PJ; ++j) {
+            const unsigned sp = spix[j] >= 0 ? (unsigned)spix[j] : 0u;
+            praw[j] = bld4(r, (sp * ld + (unsigned)(pq * 4)) * 4u, koff);
+        }
+    };
+    auto store_patch = [&](int buf, int chunk) {                    // transform, zero padding AFTER it
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        // the GroupNorm affine of this chunk's channels is fetched here (L2-hot, 32 bytes per lane) instead of riding in eight
+        // registers from the patch request to its use: the register file belongs to the accumulators
+        if (FAST || affine) {
+            asc = bld4(rSc, (unsigned)(pq * 16), (unsigned)(chunk * F4_KC) * 4u);
+            ash = bld4(rSh, (unsigned)(pq * 16), (unsigned)(chunk * F4_KC) * 4u);
+        }
+#pragma unroll
+        for (int j = 0; j < F4_PJ; ++j) {
+            const int idx = tid + j * F4_NT;
+            f32x4 v = praw[j];
+            if (FAST) {
+                v = v * asc + ash;
+                v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
+            } else {
+                if (affine) v = v * asc + ash;
+                if (act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+            }
+            ldsD[buf * F4_DT + (idx >> 2) * F4_PITCH + (idx & 3)] = spix[j] >= 0 ? v : zero;
+        }
+    };
+
+    // ---- input transform role: ALL twelve waves, 768 items = 16 tiles x 8 channel pairs x 6 transform rows.
+    // wave -> (row u = wave % 6, tile-row pair = wave / 6); lane -> (channel pair = lane & 7, tile slot = lane >> 3): the 32 lanes
+    // of a ds_read_b64 group then cover one tile row x 8 pairs = 32 distinct 8-byte bank slots, and the 16 lanes of a ds_write_b64
+    // group two neighbouring tiles x 8 pairs.  float2 items keep the transform at ~30 live registers.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int tu = wave % 6;
+    const int tpair = lane & 7;
+    const int ttile = ((wave / 6) * 2 + (lane >> 5)) * 4 + ((lane >> 3) & 3);
+    const int tbase2 = (((4 * (ttile >> 2)) * F4_PW + 4 * (ttile & 3)) * F4_PITCH) * 2 + tpair;      // float2 index of the tile's patch corner
+    // B^T row u as (patch row, coefficient) pairs -- every row of B^T touches at most four patch rows:
+    //   u0: 4 d0 - 5 d2 + d4        u1: -4 d1 - 4 d2 + d3 + d4     u2: 4 d1 - 4 d2 - d3 + d4
+    //   u3: -2 d1 - d2 + 2 d3 + d4  u4: 2 d1 - d2 - 2 d3 + d4      u5: 4 d1 - 5 d3 + d5
+    const int tr0 = (tu == 0) ? 0 : 1, tr1 = (tu == 5) ? 3 : 2, tr2 = (tu == 0) ? 4 : ((tu == 5) ? 5 : 3), tr3 = 4;
+    const float tc0 = (tu == 0) ? 4.f : (tu == 1 ? -4.f : (tu == 2 ? 4.f : (tu == 3 ? -2.f : (tu == 4 ? 2.f : 4.f))));
+    const float tc1 = (tu == 0 || tu == 5) ? -5.f : ((tu == 1 || tu == 2) ? -4.f : -1.f);
+    const float tc2 = (tu == 0 || tu == 5) ? 1.f : (tu == 1 ? 1.f : (tu == 2 ? -1.f : (tu == 3 ? 2.f : -2.f)));
+    const float tc3 = (tu == 0 || tu == 5) ? 0.f : 1.f;
+    const int to0 = tr0 * F4_PW * F4_PITCH * 2, to1 = tr1 * F4_PW * F4_PITCH * 2, to2 = tr2 * F4_PW * F4_PITCH * 2, to3 = tr3 * F4_PW * F4_PITCH * 2;
+    auto transform = [&](int pbuf, int vbuf) {
+        const f32x2 *D = reinterpret_cast<const f32x2 *>(ldsD + pbuf * F4_DT) + tbase2;
+        f32x2 t[6];
+        // stage 1: t[j] = sum_i B^T[u][i] d[i][j]
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            t[j] = tc0 * D[to0 + j * F4_PITCH * 2] + tc1 * D[to1 + j * F4_PITCH * 2] + tc2 * D[to2 + j * F4_PITCH * 2] + tc3 * D[to3 + j * F4_PITCH * 2];
+            // one column of reads in flight: the register file is full of accumulators (3 waves per SIMD), the LDS latency
+            // this exposes is covered by the other waves' MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // stage 2: V[u][v] = sum_j t[j] B^T[v][j];  V layout [pos][tile][quad] float4 = [pos][tile][pair] float2
+        const f32x2 p = t[4] - 4.f * t[2], q = t[3] - 4.f * t[1], r = t[4] - t[2], s = t[3] - t[1];
+        f32x2 *V = reinterpret_cast<f32x2 *>(ldsV + vbuf * F4_V) + ((tu * 6) * 16 + ttile) * 8 + tpair;
+        V[0 * 128] = 4.f * t[0] - 5.f * t[2] + t[4];
+        V[1 * 128] = p + q;
+        V[2 * 128] = p - q;
+        V[3 * 128] = r + 2.f * s;
+        V[4 * 128] = r - 2.f * s;
+        V[5 * 128] = 4.f * t[1] - 5.f * t[3] + t[5];
+    };
+
+    // ---- accumulators: positions 3*wave + {0,1,2} x 8 channel tiles of 16
+    f32x4 acc[3][8];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) acc[p][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int l15 = lane & 15, kq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rU = rsrc43(a.bmat);
+    const unsigned xi_bytes = (unsigned)K4 * (unsigned)N * 16u;                       // bytes per position of U
+    const unsigned ulane = ((unsigned)kq * (unsigned)N + (unsigned)(n0 + l15)) * 16u;  // + nt*256 + chunk*4*N*16 + pos*xi_bytes
+    const int vread = (wave * 3) * 64 + l15 * 4 + kq;                                 // + p*64 float4
+
+    // B operands: 24 (position, channel tile) groups of four MFMAs per iteration, streamed through a four-deep register ring
+    // (group g + 4 is requested when group g is consumed; the last four requests belong to the next iteration)
+    f32x4 ring[4];
+    auto load_group = [&](int chunk, int g, int slot) {             // g = p * 8 + nt (compile-time), slot = g % 4
+        const unsigned w = (unsigned)(wave * 3 + (g >> 3)) * xi_bytes + (unsigned)(chunk * 4) * (unsigned)N * 16u;
+        ring[slot] = bld4(rU, ulane + (unsigned)(g & 7) * 256u, w);
+    };
+
+    // prologue: patch(0) -> LDS -> V(0); patch(1) -> LDS; patch(2) requested
+    const int last = nchunks - 1;
+    const int c1 = last >= 1 ? 1 : 0, c2 = last >= 2 ? 2 : last;
+    load_patch(0);
+    store_patch(0, 0);
+    load_patch(c1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) load_group(0, g, g);
+    __syncthreads();
+    transform(0, 0);
+    store_patch(1, c1);
+    load_patch(c2);
+    __syncthreads();
+
+    // ONE basic block per iteration: no `if (more)` -- the tail iterations transform / re-stage already consumed buffers with
+    // clamped chunk indices (valid memory, results unused); branches here would turn the register-carried ring and the 96
+    // accumulators into phi copies.  Schedule of iteration c (vmcnt retires in order, so a B request issued after a patch
+    // request inherits its HBM latency: patch requests go out late, their stores early in the NEXT iteration):
+    //   T  V(c+1) <- patch(c+1)      groups 0..5      S  patch(c+2) -> LDS (requested in iteration c-1)
+    //   groups 6..17                 L  request patch(c+3)                groups 18..23      barrier
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        transform((chunk + 1) & 1, (chunk + 1) & 1);
+        const f32x4 *V = ldsV + (chunk & 1) * F4_V + vread;
+        const int nxt = chunk < last ? chunk + 1 : last;            // clamped: the tail re-loads valid memory, unused
+        const int s2 = chunk + 2 <= last ? chunk + 2 : last, l3 = chunk + 3 <= last ? chunk + 3 : last;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const f32x4 av = V[p * 64];
+            __builtin_amdgcn_sched_barrier(0);                      // one position's A fragment live at a time
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const int g = p * 8 + nt;
+                if (g == 6) store_patch(chunk & 1, s2);             // patch(chunk+2) replaces patch(chunk): its readers passed the last barrier
+                if (g == 18) load_patch(l3);
+                const f32x4 bv = ring[g % 4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[kk], acc[p][nt], 0, 0, 0);
+                if (g + 4 < 24) load_group(chunk, g + 4, g % 4);
+                else            load_group(nxt, g + 4 - 24, g % 4);
+                __builtin_amdgcn_sched_barrier(0);                  // keep the ring at four requests: no hoisting of later loads
+            }
+        }
+        __syncthreads();                                            // publishes V(chunk+1) and patch(chunk+2); retires V(chunk)
+    }
+
+    // ---- epilogue: two rounds of 64 output channels through LDS
+    float *M = lds;
+    const float *TE = a.temb ? a.temb + (int64_t)b * a.temb_ld : nullptr;
+    float *__restrict__ O = a.out + (int64_t)b * a.o_bs;
+    const float *__restrict__ R = a.res ? a.res + (int64_t)b * a.r_bs : nullptr;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    M[((wave * 3 + p) * 16 + kq * 4 + r) * F4_MS + nt * 16 + l15] = acc[p][round * 4 + nt][r];
+        __syncthreads();
+        float *red = M + 36 * 16 * F4_MS - 2 * 16 * 64;             // statistics scratch aliases the tail rows AFTER they are consumed
+        float cs = 0.f, cq = 0.f;
+        int my_tile = -1, my_ch = 0;
+        for (int it = tid; it < 16 * 64; it += F4_NT) {
+            const int tile = it >> 6, ch = it & 63;
+            const float *m = M + (size_t)tile * F4_MS + ch;
+            // columns first: y[i][v] = sum_u A^T[i][u] m[u][v]
+            float y[4][6];
+#pragma unroll
+            for (int v = 0; v < 6; ++v) {
+                float mu[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) mu[u] = m[(size_t)((u * 6 + v) * 16) * F4_MS];
+                const float s12 = mu[1] + mu[2], d12 = mu[1] - mu[2], s34 = mu[3] + mu[4], d34 = mu[3] - mu[4];
+                y[0][v] = mu[0] + s12 + s34;
+                y[1][v] = d12 + 2.f * d34;
+                y[2][v] = s12 + 4.f * s34;
+                y[3][v] = d12 + 8.f * d34 + mu[5];
+            }
+            const int n = n0 + round * 64 + ch;
+            float add = 0.f;
+            if (a.bias) add += a.bias[n];
+            if (TE) add += TE[n];
+            const int ty = tile >> 2, tx = tile & 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float s12 = y[i][1] + y[i][2], d12 = y[i][1] - y[i][2], s34 = y[i][3] + y[i][4], d34 = y[i][3] - y[i][4];
+                float o4[4];
+                o4[0] = y[i][0] + s12 + s34;
+                o4[1] = d12 + 2.f * d34;
+                o4[2] = s12 + 4.f * s34;
+                o4[3] = d12 + 8.f * d34 + y[i][5];
+                const int64_t prow = (int64_t)(y0 + ty * 4 + i) * W + x0 + tx * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = a.alpha * o4[j] + add;
+                    if (R) v += R[(prow + j) * a.res_ld + n];
+                    O[(prow + j) * a.out_ld + n] = v;
+                    cs += v;
+                    cq += v * v;
+                }
+            }
+            my_tile = tile;
+            my_ch = ch;
+        }
+        if (a.stats) {
+            // per-channel sums over the workgroup's 256 pixels: one statistics row per workgroup.  Threads own (tile, ch) items
+            // (tid < 768: tiles 0..11; the second pass of threads 0..255: tiles 12..15 -- their sums are already merged in cs/cq)
+            __syncthreads();                                        // all reads of M done
+            float *rs = red, *rq = red + 16 * 64;
+            if (my_tile >= 0) {
+                // threads with two items (tid < 256) hold tiles t and t+12 of the same channel: one slot each in rows t (< 12)
+                rs[(tid >> 6) * 64 + my_ch] = cs;
+                rq[(tid >> 6) * 64 + my_ch] = cq;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int t = 0; t < 12; ++t) { s += rs[t * 64 + tid]; q += rq[t * 64 + tid]; }
+                float *st = a.stats + (((int64_t)b * gridDim.x + blockIdx.x) * N + n0 + round * 64 + tid) * 2;
+                st[0] = s;
+                st[1] = q;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+namespace anoddpm {
+
+// Called by anoddpm_igemm for cfg == 3 (common arguments already validated there).
+int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
+{
+    ANODDPM_REQUIRE(a->ks == 3 && a->b_mode == 0 && a->heads == 1 && a->ksplit == 1, "winograd43: needs an unsplit 3x3 conv with packed weights");
+    ANODDPM_REQUIRE(a->a_mode == 0 || a->a_mode == 1, "winograd43: pooled operand loads use the direct kernel");
+    ANODDPM_REQUIRE(a->H % 16 == 0 && a->W % 16 == 0 && a->N % 128 == 0, "winograd43: H, W must be multiples of 16 and N of 128");
+    const int K = a->c0 + a->c1;
+    ANODDPM_REQUIRE(K % F4_KC == 0 && (a->c1 == 0 || a->c0 % F4_KC == 0), "winograd43: channel counts must be multiples of 16");
+    ANODDPM_REQUIRE((int64_t)36 * K * a->N * 4 < ((int64_t)1 << 31), "winograd43: transformed weights exceed 32-bit buffer offsets");
+    ANODDPM_REQUIRE((int64_t)a->H * a->W * (a->a0_ld > a->a1_ld ? a->a0_ld : a->a1_ld) * 4 < ((int64_t)1 << 31),
+                    "winograd43: operand slice exceeds 32-bit buffer offsets");
+    dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / 128), (unsigned)a->B);
+    ANODDPM_REQUIRE(a->B <= 65535, "winograd43: batch too large");
+    const bool fast = a->gn_scale && a->act;
+    if (fast) hipLaunchKernelGGL((wino43_kernel<true>), grid, dim3(F4_NT), 0, s, *a);
+    else      hipLaunchKernelGGL((wino43_kernel<false>), grid, dim3(F4_NT), 0, s, *a);
+    return check_launch("winograd43");
+}
+
+}  // namespace anoddpm

@@ -419,13 +419,28 @@ def _pack_wino(w):
     return U.reshape(16, i // 4, 4, o).permute(0, 1, 3, 2).contiguous()
 
 
+_WINO43_G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                          [0, 0, 1]], dtype=torch.float64)
+
+
+def _pack_wino43(w):
+    """OIHW 3x3 -> Winograd F(4x4,3x3) weights U = G g G^T (G 6x3, fp64, rounded once), laid out [36][I/4][O][4] (xi = 6*u + v)."""
+    o, i, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    G = _WINO43_G.to(device=w.device)
+    U = torch.einsum("ua,oiab,vb->uvio", G, w.detach().double(), G).float()          # [6][6][I][O]
+    return U.reshape(36, i // 4, 4, o).permute(0, 1, 3, 2).contiguous()
+
+
 def _use_winograd():
     import os
     return os.environ.get("ANODDPM_NO_WINOGRAD", "0") != "1"
 
 
-def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None, c1=0, wino=True):
-    """Tile configuration (0: 128x128 direct, 1: 64x64 direct, 2: Winograd F(2x2,3x3)) and split-K of one
+def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None, c1=0, wino=True, f43=False):
+    """Tile configuration (0: 128x128 direct, 1: 64x64 direct, 2: Winograd F(2x2,3x3), 3: Winograd F(4x4,3x3) -- only when the
+    caller can supply its weights, `f43`, and only on large maps, where its 1.78x fewer MFMAs outweigh the looser fp32
+    rounding: ~8e-6 per layer instead of 4e-7) and split-K of one
     anoddpm_igemm launch; shared by the inference plan and the training operators (train_ops).  Policy: fill the 256
     CUs -- >= 512 workgroups for the direct kernels when K allows it, one full round of >= 4-chunk workgroups for
     Winograd on small maps."""
@@ -456,6 +471,9 @@ def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None
         else:
             cps = -(-wch // wino_ksplit)
             wino_ksplit = -(-wch // cps)                   # no empty trailing block
+    if wino_ok and f43 and wino_ksplit == 1 and N % 128 == 0 and H * W >= int(os.environ.get("ANODDPM_F43_MIN_PIXELS", 128 * 128)) \
+            and os.environ.get("ANODDPM_NO_F43", "0") != "1":
+        return 3, 1
     if wino_ok:
         return 2, wino_ksplit
     bm = 128 if cfg == 0 else 64
@@ -574,7 +592,7 @@ class _Plan:
     def igemm(self, *, srcs, H, W, ks, N, bmat, out, out_ld=None, gn=None, act=0, a_mode=0, bias=None,
               temb=None, temb_ld=0, res=None, res_ld=0, b_mode=0, ldb=0, heads=1, alpha=1.0,
               a_strides=None, b_strides=(0, 0), o_strides=None, r_strides=None, kind="conv3", want_stats=False,
-              wino=None):
+              wino=None, wino43=None):
         B = self.B
         P = H * W
         c0 = srcs[0][1]
@@ -618,11 +636,13 @@ class _Plan:
         st.B, st.heads, st.alpha = B, heads, alpha
         Z = B * heads
         cfg, ksplit = choose_conv_cfg(H, W, K, N, Z, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads, c0=c0, c1=c1,
-                                      wino=bool(wino))
+                                      wino=bool(wino), f43=bool(wino43))
         bm = 128 if cfg == 0 else 64
         st.cfg, st.ksplit = cfg, ksplit
         _st, _bmat, _wino = self._pending_bmat
-        if cfg == 2:
+        if cfg == 3:
+            _bmat = wino43()                                   # F(4x4,3x3) weights
+        elif cfg == 2:
             _bmat = _wino()                                    # Winograd-domain weights for this layer
         elif callable(_bmat):
             _bmat = _bmat()                                    # packed lazily: only the layout this launch uses
@@ -633,14 +653,14 @@ class _Plan:
         st.stats = None
         if want_stats and ksplit == 1 and heads == 1:
             # the epilogue emits per-channel {sum, sumsq} per wave-row of every pixel tile
-            if cfg == 2:
+            if cfg in (2, 3):
                 tiles = (H // 16) * (W // 16)
             elif ks == 1:
                 tiles = -(-P // bm)
             else:
                 tw = min(W, 32)
                 tiles = (W // tw) * -(-H // (bm // tw))
-            rows = tiles * (4 if cfg == 2 else 2)              # wave-rows per pixel tile that emit a partial row
+            rows = tiles * {2: 4, 3: 1}.get(cfg, 2)            # partial rows per pixel tile (F(4x4,3x3): one per workgroup)
             stats = self.buf(B, rows, N, 2)
             st.stats = stats.data_ptr()
             self.stats_of[out.data_ptr()] = (stats, rows)
@@ -653,7 +673,7 @@ class _Plan:
             st.stats, st.stats_rows = stats.data_ptr(), nslab
             self.stats_of[out.data_ptr()] = (stats, nslab)
         self.add(_lib.OP_IGEMM, st)
-        self.igemm_log.append(dict(wino=(cfg == 2), kind=kind, H=H, W=W, K=K, N=N, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads,
+        self.igemm_log.append(dict(wino=(cfg in (2, 3)), f43=(cfg == 3), kind=kind, H=H, W=W, K=K, N=N, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads,
                                    cfg=cfg, ksplit=ksplit, dual=bool(c1), gflop=2.0 * K * N * ks * ks * P * Z / 1e9))
         if want_stats and st.stats is None:
             self.chan_stats(out, N, P)
@@ -725,6 +745,7 @@ class _Plan:
                        a_mode={None: 0, "up": 1, "down": 2}[resample],
                        bmat=self.packed(prefix + ".in_layers.2.weight", _pack_conv),
                        wino=lambda p=prefix: self.packed(p + ".in_layers.2.weight", _pack_wino),
+                       wino43=lambda p=prefix: self.packed(p + ".in_layers.2.weight", _pack_wino43),
                        bias=self.packed(prefix + ".in_layers.2.bias", lambda t: t.detach().float()),
                        temb=emb_all.data_ptr() + 4 * offs[prefix], temb_ld=tot, out=h1, want_stats=True)
             g2 = self.gn([(h1, cout)], Pout, prefix + ".out_layers.0.weight", prefix + ".out_layers.0.bias")
@@ -749,6 +770,7 @@ class _Plan:
             self.igemm(srcs=[(h1, cout)], H=Hout, W=Hout, ks=3, N=cout, gn=g2, act=1,
                        bmat=self.packed(prefix + ".out_layers.3.weight", _pack_conv),
                        wino=lambda p=prefix: self.packed(p + ".out_layers.3.weight", _pack_wino),
+                       wino43=lambda p=prefix: self.packed(p + ".out_layers.3.weight", _pack_wino43),
                        bias=self.packed(prefix + ".out_layers.3.bias", lambda t: t.detach().float()),
                        res=sk, out=h2, want_stats=True)
             return h2, Hout

@@ -68,6 +68,10 @@ def gn_finalize(stats, gamma, beta, P, want_mean_rstd=False):
     return (scale, shift, mean, rstd) if want_mean_rstd else (scale, shift)
 
 
+LAST_IGEMM = None
+_LAST_KEEP = None
+
+
 def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=None, res=None, cfg=0, ksplit=1,
                stats_out=None):
     """srcs: NHWC sources; w: OIHW weights.  Returns NHWC [B,Hout,Hout,N]."""
@@ -79,7 +83,8 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
     P = Hout * Hout
     Pin = srcs[0].shape[1] * srcs[0].shape[2]
     st = IgemmArgs()
-    wp = _pack_wino(w) if cfg == 2 else _pack_conv(w)
+    from anoddpm_amd.unet import _pack_wino43
+    wp = _pack_wino43(w) if cfg == 3 else (_pack_wino(w) if cfg == 2 else _pack_conv(w))
     out = torch.full((B, Hout, Hout, N), float("nan"), device=dev)
     st.a0, st.a1 = srcs[0].data_ptr(), srcs[1].data_ptr() if c1 else None
     st.a0_ld, st.a1_ld, st.c0, st.c1 = c0, max(c1, 4), c0, c1
@@ -106,15 +111,17 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
         stats_out.append(stats)
     elif stats_out is not None:
         bm = 128 if cfg == 0 else 64
-        if cfg == 2:
+        if cfg in (2, 3):
             tiles = (Hout // 16) ** 2
         else:
             tiles = -(-P // bm) if ks == 1 else (Hout // min(Hout, 32)) * -(-Hout // (bm // min(Hout, 32)))
-        stats = torch.full((B, tiles * (4 if cfg == 2 else 2), N, 2), float("nan"), device=dev)
+        stats = torch.full((B, tiles * {2: 4, 3: 1}.get(cfg, 2), N, 2), float("nan"), device=dev)
         st.stats = stats.data_ptr()
         stats_out.append(stats)
     check(lib().anoddpm_igemm(ctypes.byref(st), current_stream()), "igemm")
     torch.cuda.synchronize()
+    global LAST_IGEMM, _LAST_KEEP
+    LAST_IGEMM, _LAST_KEEP = st, (srcs, wp, out, gn, bias, temb, res, ws)        # tools/bench_conv.py re-launches the prepared call
     return out
 
 

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Time single 3x3 layers through the C ABI: python tools/bench_conv.py  (cfg 2 = F(2x2,3x3), cfg 3 = F(4x4,3x3), 0 = direct)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import hipops  # noqa: E402
+
+SHAPES = [  # B, (c0, c1), N, H
+    (4, (128, 0), 128, 256), (4, (128, 128), 128, 256), (4, (128, 0), 128, 128), (4, (256, 0), 256, 128),
+    (4, (256, 128), 128, 128), (4, (128, 0), 256, 128), (4, (256, 0), 256, 64), (1, (128, 0), 128, 512),
+]
+dev = torch.device("cuda:0")
+for (B, (c0, c1), N, H) in SHAPES:
+    C = c0 + c1
+    x = torch.randn(B, H, H, C, device=dev)
+    srcs = [x[..., :c0].contiguous()] + ([x[..., c0:].contiguous()] if c1 else [])
+    w = torch.randn(N, C, 3, 3, device=dev) * 0.02
+    b = torch.zeros(N, device=dev)
+    gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    gn = hipops.gn_affine(srcs, gamma, beta)
+    line = f"B{B} {c0}+{c1}->{N} @{H}:"
+    for cfg in (2, 3):
+        for _ in range(2):
+            hipops.conv_igemm(srcs, w, b, Hout=H, ks=3, gn=gn, act=1, cfg=cfg)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        import ctypes
+        # re-launch the prepared struct without the per-call packing of hipops: time 10 launches of the kernel alone
+        from anoddpm_amd._lib import lib, current_stream
+        st = hipops.LAST_IGEMM
+        e0.record()
+        for _ in range(10):
+            lib().anoddpm_igemm(ctypes.byref(st), current_stream())
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 100
+        gf = 2.0 * C * N * 9 * H * H * B / 1e9
+        line += f"  cfg{cfg} {us:7.1f} us ({gf / us * 1e-3 * 1e3:6.1f} alg TFLOP/s)"
+    print(line, flush=True)
