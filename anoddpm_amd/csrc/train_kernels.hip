@@ -520,9 +520,10 @@ extern "C" int anoddpm_wgrad_pointwise(const anoddpm_wgrad1_args *a, void *strea
 extern "C" int anoddpm_pack_weights(const anoddpm_pack_args *a, void *stream)
 {
     ANODDPM_REQUIRE(a && a->w && a->out, "pack_weights: null pointer");
-    ANODDPM_REQUIRE(a->N >= 1 && a->K >= 1 && a->kind >= 0 && a->kind <= 4, "pack_weights: bad arguments");
+    ANODDPM_REQUIRE(a->N >= 1 && a->K >= 1 && a->kind >= 0 && a->kind <= 5, "pack_weights: bad arguments");
     hipStream_t s = as_stream(stream);
     if (a->kind <= 1) return anoddpm_pack_conv3x3(a->w, a->out, a->N, a->K, a->kind, a->bwd, stream);
+    if (a->kind == 5) return anoddpm_pack_conv3x3(a->w, a->out, a->N, a->K, 2, a->bwd, stream);
     if (a->kind == 2) {
         if (a->bwd) ANODDPM_REQUIRE(a->N % 4 == 0 && a->k0 >= 0 && a->kc >= 1 && a->k0 + a->kc <= a->K, "pack_weights: bad column range");
         else ANODDPM_REQUIRE(a->K % 4 == 0, "pack_weights: K must be a multiple of 4");

@@ -249,6 +249,27 @@ __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float *__restri
 #pragma unroll
         for (int t = 0; t < 9; ++t)
             dst[t * plane] = make_float4((float)g[0][t / 3][t % 3], (float)g[1][t / 3][t % 3], (float)g[2][t / 3][t % 3], (float)g[3][t / 3][t % 3]);
+    } else if (mode == 2) {
+        // Winograd F(4x4,3x3): U = G g G^T with the 6x3 G of interpolation points 0, +-1, +-2, inf; [36 xi = 6u+v][I/4][O][4]
+        const double G6[6][3] = {{1.0 / 4, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            double t1[4][3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int b2 = 0; b2 < 3; ++b2) t1[e][b2] = G6[u][0] * g[e][0][b2] + G6[u][1] * g[e][1][b2] + G6[u][2] * g[e][2][b2];
+#pragma unroll
+            for (int v = 0; v < 6; ++v) {
+                float4 o4;
+                o4.x = (float)(t1[0][0] * G6[v][0] + t1[0][1] * G6[v][1] + t1[0][2] * G6[v][2]);
+                o4.y = (float)(t1[1][0] * G6[v][0] + t1[1][1] * G6[v][1] + t1[1][2] * G6[v][2]);
+                o4.z = (float)(t1[2][0] * G6[v][0] + t1[2][1] * G6[v][1] + t1[2][2] * G6[v][2]);
+                o4.w = (float)(t1[3][0] * G6[v][0] + t1[3][1] * G6[v][1] + t1[3][2] * G6[v][2]);
+                dst[(u * 6 + v) * plane] = o4;
+            }
+        }
     } else {
         const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
         float U[4][16];
@@ -304,7 +325,7 @@ extern "C" int anoddpm_pack_conv3x3(const float *w, float *out, int32_t N, int32
 {
     using namespace anoddpm;
     ANODDPM_REQUIRE(w && out, "pack_conv3x3: null pointer");
-    ANODDPM_REQUIRE(N >= 1 && K >= 1 && (mode == 0 || mode == 1), "pack_conv3x3: bad arguments");
+    ANODDPM_REQUIRE(N >= 1 && K >= 1 && mode >= 0 && mode <= 2, "pack_conv3x3: bad arguments");
     ANODDPM_REQUIRE((bwd ? N : K) % 4 == 0, "pack_conv3x3: input channel count must be a multiple of 4");
     const int64_t total = (int64_t)N * K / 4;
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), w, out, N, K, mode, bwd);

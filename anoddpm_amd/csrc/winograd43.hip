@@ -51,7 +51,8 @@ __device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned lane_by
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)wave_bytes, 0));
 }
 
-template <bool FAST>
+// DBG (timing ablations only, wrong results; ANODDPM_DEBUG2): 1 no epilogue, 2 no input transform, 3 no patch staging, 4 no B requests
+template <bool FAST, int DBG = 0>
 __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_args a)
 {
     __shared__ __attribute__((aligned(16))) float lds[F4_LDS_FLOATS];
@@ -192,10 +193,20 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
     const int last = nchunks - 1;
     const int c1 = last >= 1 ? 1 : 0, c2 = last >= 2 ? 2 : last;
     load_patch(0);
-    store_patch(0, 0);
-    load_patch(c1);
+    f32x4 praw0[F4_PJ];
+#pragma unroll
+    for (int j = 0; j < F4_PJ; ++j) praw0[j] = praw[j];
+    load_patch(c1);                                                 // both requests in flight: one HBM latency, not two
 #pragma unroll
     for (int g = 0; g < 4; ++g) load_group(0, g, g);
+    {
+        f32x4 keep[F4_PJ];
+#pragma unroll
+        for (int j = 0; j < F4_PJ; ++j) { keep[j] = praw[j]; praw[j] = praw0[j]; }
+        store_patch(0, 0);
+#pragma unroll
+        for (int j = 0; j < F4_PJ; ++j) praw[j] = keep[j];
+    }
     __syncthreads();
     transform(0, 0);
     store_patch(1, c1);
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
     //   T  V(c+1) <- patch(c+1)      groups 0..5      S  patch(c+2) -> LDS (requested in iteration c-1)
     //   groups 6..17                 L  request patch(c+3)                groups 18..23      barrier
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        transform((chunk + 1) & 1, (chunk + 1) & 1);
+        if (DBG != 2) transform((chunk + 1) & 1, (chunk + 1) & 1);
         const f32x4 *V = ldsV + (chunk & 1) * F4_V + vread;
         const int nxt = chunk < last ? chunk + 1 : last;            // clamped: the tail re-loads valid memory, unused
         const int s2 = chunk + 2 <= last ? chunk + 2 : last, l3 = chunk + 3 <= last ? chunk + 3 : last;
@@ -220,14 +231,16 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
                 const int g = p * 8 + nt;
-                if (g == 6) store_patch(chunk & 1, s2);             // patch(chunk+2) replaces patch(chunk): its readers passed the last barrier
-                if (g == 18) load_patch(l3);
+                if (g == 6 && DBG != 3) store_patch(chunk & 1, s2); // patch(chunk+2) replaces patch(chunk): its readers passed the last barrier
+                if (g == 18 && DBG != 3) load_patch(l3);
                 const f32x4 bv = ring[g % 4];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
                     acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[kk], acc[p][nt], 0, 0, 0);
-                if (g + 4 < 24) load_group(chunk, g + 4, g % 4);
-                else            load_group(nxt, g + 4 - 24, g % 4);
+                if (DBG != 4) {
+                    if (g + 4 < 24) load_group(chunk, g + 4, g % 4);
+                    else            load_group(nxt, g + 4 - 24, g % 4);
+                }
                 __builtin_amdgcn_sched_barrier(0);                  // keep the ring at four requests: no hoisting of later loads
             }
         }
@@ -235,6 +248,15 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
     }
 
     // ---- epilogue: two rounds of 64 output channels through LDS
+    if (DBG == 1) {
+        float sum = 0.f;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) sum += (acc[p][nt][0] + acc[p][nt][1]) + (acc[p][nt][2] + acc[p][nt][3]);
+        if (sum == 12345.678f) a.out[0] = sum;
+        return;
+    }
     float *M = lds;
     const float *TE = a.temb ? a.temb + (int64_t)b * a.temb_ld : nullptr;
     float *__restrict__ O = a.out + (int64_t)b * a.o_bs;
@@ -336,7 +358,12 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
     dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / 128), (unsigned)a->B);
     ANODDPM_REQUIRE(a->B <= 65535, "winograd43: batch too large");
     const bool fast = a->gn_scale && a->act;
-    if (fast) hipLaunchKernelGGL((wino43_kernel<true>), grid, dim3(F4_NT), 0, s, *a);
+    const int dbg = anoddpm::g_debug[2];
+    if (fast && dbg == 1) hipLaunchKernelGGL((wino43_kernel<true, 1>), grid, dim3(F4_NT), 0, s, *a);
+    else if (fast && dbg == 2) hipLaunchKernelGGL((wino43_kernel<true, 2>), grid, dim3(F4_NT), 0, s, *a);
+    else if (fast && dbg == 3) hipLaunchKernelGGL((wino43_kernel<true, 3>), grid, dim3(F4_NT), 0, s, *a);
+    else if (fast && dbg == 4) hipLaunchKernelGGL((wino43_kernel<true, 4>), grid, dim3(F4_NT), 0, s, *a);
+    else if (fast) hipLaunchKernelGGL((wino43_kernel<true>), grid, dim3(F4_NT), 0, s, *a);
     else      hipLaunchKernelGGL((wino43_kernel<false>), grid, dim3(F4_NT), 0, s, *a);
     return check_launch("winograd43");
 }

@@ -117,7 +117,7 @@ class TrainPlan(_Plan):
             return hit
         w = self.named[key]
         N, K = w.shape[0], w.shape[1]
-        n = {0: 9 * N * K, 1: 16 * N * K, 2: (N * kc if bwd else N * K), 3: 9 * N * K, 4: N * K}[kind]
+        n = {0: 9 * N * K, 1: 16 * N * K, 2: (N * kc if bwd else N * K), 3: 9 * N * K, 4: N * K, 5: 36 * N * K}[kind]
         out = self.buf(n)
         st = PackArgs()
         st.w, st.out, st.N, st.K, st.kind, st.bwd, st.k0, st.kc = self.W(key), out.data_ptr(), N, K, kind, bwd, k0, kc
@@ -334,14 +334,15 @@ class TrainPlan(_Plan):
 
         def conv3(srcs, Hout, N, gnp, a_mode, wkey, bkey, out, temb_ptr=None, temb_ld=0, res=None):
             self.igemm(srcs=srcs, H=Hout, W=Hout, ks=3, N=N, gn=(gnp[0], gnp[1]), act=1, a_mode=a_mode,
-                       bmat=lambda: self.pack(wkey, 0), wino=lambda: self.pack(wkey, 1), bias=bias(bkey),
+                       bmat=lambda: self.pack(wkey, 0), wino=lambda: self.pack(wkey, 1), wino43=lambda: self.pack(wkey, 5),
+                       bias=bias(bkey),
                        temb=temb_ptr, temb_ld=temb_ld, res=res, out=out, want_stats=True)
 
         def dgrad3(dy, Hout, Kc, N, wkey):
             """da [B][Hout^2][Kc] = conv3x3(dy, flipped / transposed weights): the forward kernels on the packed twin."""
             da = self.buf(B, Hout * Hout, Kc)
             self.igemm(srcs=[(dy, N)], H=Hout, W=Hout, ks=3, N=Kc, bmat=lambda: self.pack(wkey, 0, bwd=1),
-                       wino=lambda: self.pack(wkey, 1, bwd=1), out=da)
+                       wino=lambda: self.pack(wkey, 1, bwd=1), wino43=lambda: self.pack(wkey, 5, bwd=1), out=da)
             return da
 
         def res_block(prefix, srcs, Hin, cout, resample):

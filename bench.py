@@ -256,50 +256,55 @@ def run_reverse(c, args, cfg):
         cnt = (ctypes.c_int64 * _lib.OP_MAX)()
         _lib.check(L.anoddpm_prof_collect(ms, cnt), "prof_collect")
         L.anoddpm_prof_enable(0)
-        WINO = 12                                              # profiler slot of the Winograd launches
-        w_ms, w_n = ms[WINO], cnt[WINO]
-        d_ms, d_n = ms[_lib.OP_IGEMM], cnt[_lib.OP_IGEMM]      # direct implicit-GEMM launches (1x1, small maps, attention)
-        ig_ms = w_ms + d_ms
-        w_flops = sum(e["gflop"] for e in plan.igemm_log if e["wino"]) * 1e9      # algorithmic (direct-convolution) FLOPs
-        d_flops = sum(e["gflop"] for e in plan.igemm_log if not e["wino"]) * 1e9
+        # contraction classes: profiler slot, launches of the plan, fraction of the direct-convolution FLOPs the matrix pipe executes
+        classes = {
+            "wino43_kernel (Winograd F(4x4,3x3) 3x3 convolutions on maps >= 128x128, v_mfma_f32_16x16x4_f32)":
+                (14, [e for e in plan.igemm_log if e.get("f43")], 36.0 / (16 * 9)),
+            "wino_kernel (Winograd F(2x2,3x3) 3x3 convolutions, v_mfma_f32_32x32x2_f32)":
+                (12, [e for e in plan.igemm_log if e["wino"] and not e.get("f43")], 4.0 / 9.0),
+            "igemm_kernel (direct implicit GEMM: 1x1, pool-fused and 8x8 3x3, qkv/proj, attention; v_mfma_f32_32x32x2_f32)":
+                (_lib.OP_IGEMM, [e for e in plan.igemm_log if not e["wino"]], 1.0),
+        }
         flops_per_step = plan.igemm_flops
 
         def tf(flops, msec):
             return flops * args.steps / (msec / 1000.0) / 1e12 if msec > 0 else 0.0
-        # dominant kernel = wino_kernel when the plan uses it, else the direct kernel.  `achieved` / `frac` price the
-        # FLOPs the matrix pipe EXECUTES (Winograd F(2x2,3x3) issues 4/9 of the direct-convolution count), so frac <= 1
-        # is a pipe utilisation; the algorithmic (direct-convolution) rate of the same launches is a side field.
-        dom_wino = w_ms >= d_ms
-        algorithmic = tf(w_flops, w_ms) if dom_wino else tf(d_flops, d_ms)
-        executed = tf(w_flops * 4.0 / 9.0, w_ms) if dom_wino else algorithmic
-        nl = (w_n if dom_wino else d_n) / args.steps
-        roofline = {"bound": "mfma",
-                    "kernel": ("wino_kernel (Winograd F(2x2,3x3) 3x3 convolutions, v_mfma_f32_32x32x2_f32)" if dom_wino else
-                               "igemm_kernel (direct implicit-GEMM convolution, v_mfma_f32_32x32x2_f32)"),
-                    "achieved": executed, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                    "frac": executed / PEAK_FP32_MATRIX_TFLOPS,
-                    "achieved_is": "FLOPs the matrix pipe executes for the kernel's launches (Winograd layers: 4/9 of the "
+        rows = {}
+        for name, (slot, entries, frac_exec) in classes.items():
+            fl = sum(e["gflop"] for e in entries) * 1e9
+            rows[name] = dict(ms=ms[slot], n=cnt[slot], alg=fl, exe=fl * frac_exec)
+        # dominant kernel = the class with the most time.  `achieved` / `frac` price the FLOPs the matrix pipe EXECUTES
+        # (Winograd issues 4/9 resp. 1/4 of the direct-convolution count), so frac <= 1 is a pipe utilisation; the
+        # algorithmic (direct-convolution) rate of the same launches is a side field.
+        dom = max(rows, key=lambda k: rows[k]["ms"])
+        d = rows[dom]
+        nl = d["n"] / args.steps
+        ig_ms = sum(r["ms"] for r in rows.values())
+        roofline = {"bound": "mfma", "kernel": dom,
+                    "achieved": tf(d["exe"], d["ms"]), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf(d["exe"], d["ms"]) / PEAK_FP32_MATRIX_TFLOPS,
+                    "achieved_is": "FLOPs the matrix pipe executes for the kernel's launches (Winograd F(4x4,3x3): 1/4, F(2x2,3x3): 4/9 of the "
                                    "direct-convolution count) / their HIP-event time",
-                    "algorithmic_tflops": algorithmic,
+                    "algorithmic_tflops": tf(d["alg"], d["ms"]),
                     # HBM bytes come from PMC counters, which cannot be read from inside this process: not reported here;
                     # the per-kernel counter passes of the same command are committed under profiles/ (README there)
                     "traffic": None,
                     "launches_per_step": nl,
-                    "avg_launch_ms": (w_ms / max(w_n, 1)) if dom_wino else (d_ms / max(d_n, 1)),
-                    "algorithmic_gflop_per_launch": ((w_flops if dom_wino else d_flops) / 1e9) / max(nl, 1),
-                    "executed_gflop_per_launch": ((w_flops * 4.0 / 9.0 if dom_wino else d_flops) / 1e9) / max(nl, 1),
-                    "share_of_model_flops": (w_flops if dom_wino else d_flops) / max(flops_per_step, 1.0),
-                    "other_contraction_kernel": {"kernel": "igemm_kernel / gemm1x1 / attention (direct: 1x1, pool-fused and 8x8 3x3, qkv/proj, attention)" if dom_wino else "wino_kernel",
-                                                 "achieved": tf(d_flops, d_ms) if dom_wino else tf(w_flops * 4.0 / 9.0, w_ms),
-                                                 "launches_per_step": (d_n if dom_wino else w_n) / args.steps,
-                                                 "ms_per_step": (d_ms if dom_wino else w_ms) / args.steps},
-                    "all_contractions": {"executed_tflops": tf(w_flops * 4.0 / 9.0 + d_flops, ig_ms),
+                    "avg_launch_ms": d["ms"] / max(d["n"], 1),
+                    "ms_per_step": d["ms"] / args.steps,
+                    "algorithmic_gflop_per_launch": d["alg"] / 1e9 / max(nl, 1),
+                    "executed_gflop_per_launch": d["exe"] / 1e9 / max(nl, 1),
+                    "share_of_model_flops": d["alg"] / max(flops_per_step, 1.0),
+                    "other_contraction_kernels": [{"kernel": k, "achieved": tf(r["exe"], r["ms"]), "algorithmic_tflops": tf(r["alg"], r["ms"]),
+                                                   "launches_per_step": r["n"] / args.steps, "ms_per_step": r["ms"] / args.steps}
+                                                  for k, r in rows.items() if k != dom and r["n"]],
+                    "all_contractions": {"executed_tflops": tf(sum(r["exe"] for r in rows.values()), ig_ms),
                                          "algorithmic_tflops": tf(flops_per_step, ig_ms),
                                          "ms_per_step": ig_ms / args.steps, "algorithmic_gflop_per_step": flops_per_step / 1e9},
                     "class_ms_per_step": {name: ms[code] / args.steps for name, code in
-                                          (("winograd", 12), ("igemm_direct", 1), ("gn_stats", 2), ("softmax", 3), ("resample", 4), ("linear", 5),
-                                           ("posemb", 6), ("stem", 7), ("layout", 8), ("chan_stats", 9),
-                                           ("gn_finalize", 10), ("head", 11), ("attention", 13))},
+                                          (("winograd_f43", 14), ("winograd_f23", 12), ("igemm_direct", 1), ("gn_stats", 2), ("softmax", 3), ("resample", 4),
+                                           ("linear", 5), ("posemb", 6), ("stem", 7), ("layout", 8), ("chan_stats", 9),
+                                           ("gn_finalize", 10), ("head", 11))},
                     "instrumented_ms_per_step": prof_ms_per_step}
     metric = ("reverse-diffusion images/sec @256x256 T=1000 simplex" if cfg["img"] == 256 else
               f"reverse-diffusion images/sec @{cfg['img']}x{cfg['img']} T=1000 simplex")
@@ -382,8 +387,8 @@ def run_train(c, args, cfg):
             w_ms, w_n = ms[_lib.OP_WGRAD3] / args.steps, cnt[_lib.OP_WGRAD3] / args.steps
             i_fl = sum(2.0 * (st.c0 + st.c1) * st.N * st.ks * st.ks * st.H * st.W * st.B * st.heads
                        for code, st in plan.ops + plan.bops if code == _lib.OP_IGEMM)
-            i_ms = (ms[_lib.OP_IGEMM] + ms[12]) / args.steps
-            names = {1: "igemm_direct", 12: "winograd", 3: "softmax", 4: "resample", 5: "linear", 6: "posemb", 7: "stem", 9: "chan_stats",
+            i_ms = (ms[_lib.OP_IGEMM] + ms[12] + ms[14]) / args.steps
+            names = {1: "igemm_direct", 12: "winograd_f23", 14: "winograd_f43", 3: "softmax", 4: "resample", 5: "linear", 6: "posemb", 7: "stem", 9: "chan_stats",
                      10: "gn_finalize", 11: "head", 16: "wgrad3x3", 17: "wgrad_pointwise", 18: "gn_silu_backward", 19: "pack_weights",
                      20: "softmax_backward", 21: "transpose", 22: "linear_backward", 23: "stem_backward", 24: "head_backward",
                      25: "colsum_fold"}
@@ -394,7 +399,7 @@ def run_train(c, args, cfg):
                         "gflop_per_launch": w_fl / max(w_n, 1) / 1e9, "ms_per_step": w_ms,
                         "other_contraction_kernel": {"kernel": "anoddpm_igemm launches (forward convs, data gradients, attention GEMMs; Winograd where eligible)",
                                                      "algorithmic_tflops": i_fl / (i_ms / 1000.0) / 1e12 if i_ms > 0 else 0.0,
-                                                     "launches_per_step": (cnt[_lib.OP_IGEMM] + cnt[12]) / args.steps, "ms_per_step": i_ms},
+                                                     "launches_per_step": (cnt[_lib.OP_IGEMM] + cnt[12] + cnt[14]) / args.steps, "ms_per_step": i_ms},
                         "class_ms_per_step": {names[c]: ms[c] / args.steps for c in names},
                         "class_launches_per_step": {names[c]: cnt[c] / args.steps for c in names},
                         "unet_ms_per_step": sum(ms[c] for c in names) / args.steps,

@@ -194,7 +194,8 @@ typedef struct {
     int32_t B, heads;               /* Z = B*heads */
     int32_t ksplit;                 /* >= 1 */
     int32_t cfg;                    /* 0: 128x128 tile, 1: 64x64 tile, 2: Winograd F(2x2,3x3): ks 3, a_mode 0/1, H,W % 16 == 0,
-                                       ksplit 1, bmat = host-transformed weights [16][K/4][N][4] (G g G^T) */
+                                       bmat = transformed weights [16][K/4][N][4] (G g G^T); 3: Winograd F(4x4,3x3): as 2 with
+                                       N % 128 == 0, ksplit 1, bmat [36][K/4][N][4]; statistics: one row per 16x16 patch */
     float alpha;
     int32_t gn_ld;                  /* row length of gn_scale/gn_shift (= K) */
     float *stats;                   /* or NULL: per-channel partial sums of the OUTPUT, [B][tiles*2][N][2]
@@ -458,7 +459,8 @@ typedef struct anoddpm_wgrad_args {
 int anoddpm_conv3x3_wgrad(const anoddpm_wgrad_args *a, void *stream);
 
 /* Device-side weight packing for the 3x3 kernels (training re-packs after every optimizer step).  w: OIHW [N][K][3][3].
- * mode 0: direct layout [9][I/4][O][4]; mode 1: Winograd U = G g G^T as [16][I/4][O][4].  bwd != 0 packs the
+ * mode 0: direct layout [9][I/4][O][4]; mode 1: Winograd F(2x2,3x3) U = G g G^T as [16][I/4][O][4]; mode 2: Winograd
+ * F(4x4,3x3) as [36][I/4][O][4].  bwd != 0 packs the
  * data-gradient weights W'[o=k][i=n][a][b] = w[n][k][2-a][2-b] (I = N, O = K), else I = K, O = N. */
 int anoddpm_pack_conv3x3(const float *w, float *out, int32_t N, int32_t K, int32_t mode, int32_t bwd, void *stream);
 
@@ -526,7 +528,8 @@ int anoddpm_wgrad_pointwise(const anoddpm_wgrad1_args *a, void *stream);
  *   kind 2: pointwise    w [N][K] -> [K/4][N][4]; bwd != 0: the data-gradient matrix W'[i=n][o] = w[n][k0 + o],
  *           o < kc, packed [N/4][kc][4] (a column range: the two sources of a concatenated input get separate matrices)
  *   kind 3: small conv   w OIHW [N][K][3][3] -> [9][K][N] (stem / head kernels)
- *   kind 4: plain copy of N*K floats */
+ *   kind 4: plain copy of N*K floats
+ *   kind 5: 3x3 Winograd F(4x4,3x3) (anoddpm_pack_conv3x3 mode 2): [36][I/4][O][4] */
 typedef struct anoddpm_pack_args {
     const float *w;
     float *out;
