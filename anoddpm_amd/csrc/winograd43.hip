@@ -17,8 +17,9 @@
 //     double-buffered V[pos][tile][quad] array, so the MFMA A operands are one ds_read_b128 per position;
 //   * the B operands U[pos][k][n] stream from L2 as 16-byte loads (layout [36][K/4][N][4]: one load = one lane's four k);
 //   * 96 MFMAs per wave per iteration, one barrier per iteration.
-// Epilogue: the 36 x 16 x 128 products go through LDS in two rounds of 64 channels (157 KB, aliasing the loop buffers); one
-// thread per (tile, channel) forms A^T M A, adds bias / temb / residual, stores 16 pixels and folds the GroupNorm sums.
+// Epilogue: the 36 x 16 x 128 products go through LDS in three rounds of 48 / 48 / 32 channels (120 KB, aliasing the loop
+// buffers); one thread per (tile, channel) forms A^T M A, adds bias / temb / residual, stores 16 pixels through buffer stores with
+// scalar pixel offsets and folds the GroupNorm sums.
 #include "common.h"
 
 using anoddpm::silu_f;
@@ -36,7 +37,7 @@ constexpr int F4_PJ = 2;                   // staging slots per thread (2 * 768 
 constexpr int F4_SLOTPX = F4_PJ * F4_NT / 4;          // 384 pixel slots per buffer
 constexpr int F4_DT = F4_SLOTPX * F4_PITCH;           // float4 per patch buffer
 constexpr int F4_V = 36 * 16 * 4;                     // float4 per V buffer: [pos][tile][quad]
-constexpr int F4_MS = 68;                             // floats per (pos, tile) row of the exchange buffer (64 channels + pad)
+constexpr int F4_MS = 52;                             // floats per (pos, tile) row of the exchange buffer (48 channels + pad: 4 * 52 = 16 mod 32)
 constexpr int F4_LOOP_FLOATS = (2 * F4_DT + 2 * F4_V) * 4;
 constexpr int F4_EX_FLOATS = 36 * 16 * F4_MS;
 constexpr int F4_LDS_FLOATS = F4_EX_FLOATS > F4_LOOP_FLOATS ? F4_EX_FLOATS : F4_LOOP_FLOATS;
@@ -52,7 +53,9 @@ __device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned lane_by
 }
 
 // DBG (timing ablations only, wrong results; ANODDPM_DEBUG2): 1 no epilogue, 2 no input transform, 3 no patch staging, 4 no B requests
-template <bool FAST, int DBG = 0>
+// NTL = 16-channel tiles per workgroup: 8 (128 output channels) or 4 (64 channels: twice the workgroups when the map is too
+// small to fill the 256 CUs with 128-channel ones, at the price of repeating the staging / input transform per 64 channels)
+template <bool FAST, int DBG = 0, int NTL = 8>
 __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_args a)
 {
     __shared__ __attribute__((aligned(16))) float lds[F4_LDS_FLOATS];
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
     const int K = a.c0 + a.c1, N = a.N, K4 = K >> 2;
     const int tiles_x = W >> 4;
     const int y0 = (blockIdx.x / tiles_x) * 16, x0 = (blockIdx.x % tiles_x) * 16;
-    const int n0 = blockIdx.y * 128;
+    const int n0 = blockIdx.y * (16 * NTL);
     const int b = blockIdx.z;
     const int a_mode = a.a_mode;
 
@@ -169,11 +172,11 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
     };
 
     // ---- accumulators: positions 3*wave + {0,1,2} x 8 channel tiles of 16
-    f32x4 acc[3][8];
+    f32x4 acc[3][NTL];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) acc[p][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NTL; ++nt) acc[p][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int l15 = lane & 15, kq = lane >> 4;
     const __amdgpu_buffer_rsrc_t rU = rsrc43(a.bmat);
@@ -184,9 +187,10 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
     // B operands: 24 (position, channel tile) groups of four MFMAs per iteration, streamed through a four-deep register ring
     // (group g + 4 is requested when group g is consumed; the last four requests belong to the next iteration)
     f32x4 ring[4];
-    auto load_group = [&](int chunk, int g, int slot) {             // g = p * 8 + nt (compile-time), slot = g % 4
-        const unsigned w = (unsigned)(wave * 3 + (g >> 3)) * xi_bytes + (unsigned)(chunk * 4) * (unsigned)N * 16u;
-        ring[slot] = bld4(rU, ulane + (unsigned)(g & 7) * 256u, w);
+    constexpr int NG = 3 * NTL;                                     // (position, channel tile) groups per iteration
+    auto load_group = [&](int chunk, int g, int slot) {             // g = p * NTL + nt (compile-time), slot = g % 4
+        const unsigned w = (unsigned)(wave * 3 + g / NTL) * xi_bytes + (unsigned)(chunk * 4) * (unsigned)N * 16u;
+        ring[slot] = bld4(rU, ulane + (unsigned)(g % NTL) * 256u, w);
     };
 
     // prologue: patch(0) -> LDS -> V(0); patch(1) -> LDS; patch(2) requested
@@ -229,17 +233,17 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
             const f32x4 av = V[p * 64];
             __builtin_amdgcn_sched_barrier(0);                      // one position's A fragment live at a time
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                const int g = p * 8 + nt;
-                if (g == 6 && DBG != 3) store_patch(chunk & 1, s2); // patch(chunk+2) replaces patch(chunk): its readers passed the last barrier
-                if (g == 18 && DBG != 3) load_patch(l3);
+            for (int nt = 0; nt < NTL; ++nt) {
+                const int g = p * NTL + nt;
+                if (g == NG / 4 && DBG != 3) store_patch(chunk & 1, s2); // patch(chunk+2) replaces patch(chunk): its readers passed the last barrier
+                if (g == (3 * NG) / 4 && DBG != 3) load_patch(l3);
                 const f32x4 bv = ring[g % 4];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
                     acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[kk], acc[p][nt], 0, 0, 0);
                 if (DBG != 4) {
-                    if (g + 4 < 24) load_group(chunk, g + 4, g % 4);
-                    else            load_group(nxt, g + 4 - 24, g % 4);
+                    if (g + 4 < NG) load_group(chunk, g + 4, g % 4);
+                    else            load_group(nxt, g + 4 - NG, g % 4);
                 }
                 __builtin_amdgcn_sched_barrier(0);                  // keep the ring at four requests: no hoisting of later loads
             }
@@ -247,35 +251,46 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
         __syncthreads();                                            // publishes V(chunk+1) and patch(chunk+2); retires V(chunk)
     }
 
-    // ---- epilogue: two rounds of 64 output channels through LDS
+    // ---- epilogue: three rounds of <= 48 output channels through LDS
     if (DBG == 1) {
         float sum = 0.f;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) sum += (acc[p][nt][0] + acc[p][nt][1]) + (acc[p][nt][2] + acc[p][nt][3]);
+            for (int nt = 0; nt < NTL; ++nt) sum += (acc[p][nt][0] + acc[p][nt][1]) + (acc[p][nt][2] + acc[p][nt][3]);
         if (sum == 12345.678f) a.out[0] = sum;
         return;
     }
+    // Three rounds over the channel tiles (3 + 3 + 2 of the eight 16-channel tiles): a 48-channel round is 16 tiles x 48 = 768
+    // items, exactly one per thread.  Pixel addresses are one per-lane byte offset (tile origin, channel) plus a wave-uniform
+    // scalar offset per pixel of the 4x4 tile, so the 16 stores / residual loads of an item carry no vector address arithmetic.
     float *M = lds;
     const float *TE = a.temb ? a.temb + (int64_t)b * a.temb_ld : nullptr;
-    float *__restrict__ O = a.out + (int64_t)b * a.o_bs;
-    const float *__restrict__ R = a.res ? a.res + (int64_t)b * a.r_bs : nullptr;
+    const __amdgpu_buffer_rsrc_t rO = rsrc43(a.out + (int64_t)b * a.o_bs);
+    const __amdgpu_buffer_rsrc_t rR = rsrc43(a.res ? a.res + (int64_t)b * a.r_bs : a.out);
+    const bool has_res = a.res != nullptr;
+    const unsigned uW = (unsigned)W, o_ld = (unsigned)a.out_ld, r_ld = (unsigned)a.res_ld;
+    constexpr int ROUNDS = NTL == 8 ? 3 : 2;                        // 8 tiles: 3 + 3 + 2; 4 tiles: 2 + 2
+    constexpr int RT = NTL == 8 ? 3 : 2;
 #pragma unroll
-    for (int round = 0; round < 2; ++round) {
+    for (int round = 0; round < ROUNDS; ++round) {
+        const int nt0 = round * RT;
+        const int ntn = (NTL == 8 && round == 2) ? 2 : RT;
+        const int nch = ntn * 16;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 3; ++nt)
+                if (nt < ntn) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    M[((wave * 3 + p) * 16 + kq * 4 + r) * F4_MS + nt * 16 + l15] = acc[p][round * 4 + nt][r];
+                    for (int r = 0; r < 4; ++r)
+                        M[((wave * 3 + p) * 16 + kq * 4 + r) * F4_MS + nt * 16 + l15] = acc[p][nt0 + nt][r];
+                }
         __syncthreads();
-        float *red = M + 36 * 16 * F4_MS - 2 * 16 * 64;             // statistics scratch aliases the tail rows AFTER they are consumed
+        const int tile = tid / nch, ch = tid - tile * nch;
+        const bool active = tile < 16;                              // third round: 512 items, waves 8..11 idle (wave-uniform)
         float cs = 0.f, cq = 0.f;
-        int my_tile = -1, my_ch = 0;
-        for (int it = tid; it < 16 * 64; it += F4_NT) {
-            const int tile = it >> 6, ch = it & 63;
+        if (active) {
             const float *m = M + (size_t)tile * F4_MS + ch;
             // columns first: y[i][v] = sum_u A^T[i][u] m[u][v]
             float y[4][6];
@@ -290,11 +305,12 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
                 y[2][v] = s12 + 4.f * s34;
                 y[3][v] = d12 + 8.f * d34 + mu[5];
             }
-            const int n = n0 + round * 64 + ch;
+            const int n = n0 + nt0 * 16 + ch;
             float add = 0.f;
             if (a.bias) add += a.bias[n];
             if (TE) add += TE[n];
-            const int ty = tile >> 2, tx = tile & 3;
+            const unsigned pix0 = (unsigned)(y0 + (tile >> 2) * 4) * uW + (unsigned)(x0 + (tile & 3) * 4);
+            const unsigned vo = (pix0 * o_ld + (unsigned)n) * 4u, vr = (pix0 * r_ld + (unsigned)n) * 4u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float s12 = y[i][1] + y[i][2], d12 = y[i][1] - y[i][2], s34 = y[i][3] + y[i][4], d34 = y[i][3] - y[i][4];
@@ -303,35 +319,28 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
                 o4[1] = d12 + 2.f * d34;
                 o4[2] = s12 + 4.f * s34;
                 o4[3] = d12 + 8.f * d34 + y[i][5];
-                const int64_t prow = (int64_t)(y0 + ty * 4 + i) * W + x0 + tx * 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    const unsigned so = ((unsigned)i * uW + (unsigned)j) * 4u;          // wave-uniform pixel offset (x ld below)
                     float v = a.alpha * o4[j] + add;
-                    if (R) v += R[(prow + j) * a.res_ld + n];
-                    O[(prow + j) * a.out_ld + n] = v;
+                    if (has_res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR, (int)vr, (int)(so * r_ld), 0));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, (int)vo, (int)(so * o_ld), 0);
                     cs += v;
                     cq += v * v;
                 }
             }
-            my_tile = tile;
-            my_ch = ch;
         }
         if (a.stats) {
-            // per-channel sums over the workgroup's 256 pixels: one statistics row per workgroup.  Threads own (tile, ch) items
-            // (tid < 768: tiles 0..11; the second pass of threads 0..255: tiles 12..15 -- their sums are already merged in cs/cq)
-            __syncthreads();                                        // all reads of M done
-            float *rs = red, *rq = red + 16 * 64;
-            if (my_tile >= 0) {
-                // threads with two items (tid < 256) hold tiles t and t+12 of the same channel: one slot each in rows t (< 12)
-                rs[(tid >> 6) * 64 + my_ch] = cs;
-                rq[(tid >> 6) * 64 + my_ch] = cq;
-            }
+            // per-channel sums over the workgroup's 256 pixels: ONE statistics row per workgroup
+            __syncthreads();                                        // all reads of M done: its head becomes the scratch
+            float *rs = M, *rq = M + 16 * 48;
+            if (active) { rs[tile * 48 + ch] = cs; rq[tile * 48 + ch] = cq; }
             __syncthreads();
-            if (tid < 64) {
+            if (tid < nch) {
                 float s = 0.f, q = 0.f;
 #pragma unroll
-                for (int t = 0; t < 12; ++t) { s += rs[t * 64 + tid]; q += rq[t * 64 + tid]; }
-                float *st = a.stats + (((int64_t)b * gridDim.x + blockIdx.x) * N + n0 + round * 64 + tid) * 2;
+                for (int t = 0; t < 16; ++t) { s += rs[t * 48 + tid]; q += rq[t * 48 + tid]; }
+                float *st = a.stats + (((int64_t)b * gridDim.x + blockIdx.x) * N + n0 + nt0 * 16 + tid) * 2;
                 st[0] = s;
                 st[1] = q;
             }
@@ -349,13 +358,17 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
 {
     ANODDPM_REQUIRE(a->ks == 3 && a->b_mode == 0 && a->heads == 1 && a->ksplit == 1, "winograd43: needs an unsplit 3x3 conv with packed weights");
     ANODDPM_REQUIRE(a->a_mode == 0 || a->a_mode == 1, "winograd43: pooled operand loads use the direct kernel");
-    ANODDPM_REQUIRE(a->H % 16 == 0 && a->W % 16 == 0 && a->N % 128 == 0, "winograd43: H, W must be multiples of 16 and N of 128");
+    ANODDPM_REQUIRE(a->H % 16 == 0 && a->W % 16 == 0 && a->N % 64 == 0, "winograd43: H, W must be multiples of 16 and N of 64");
     const int K = a->c0 + a->c1;
     ANODDPM_REQUIRE(K % F4_KC == 0 && (a->c1 == 0 || a->c0 % F4_KC == 0), "winograd43: channel counts must be multiples of 16");
     ANODDPM_REQUIRE((int64_t)36 * K * a->N * 4 < ((int64_t)1 << 31), "winograd43: transformed weights exceed 32-bit buffer offsets");
     ANODDPM_REQUIRE((int64_t)a->H * a->W * (a->a0_ld > a->a1_ld ? a->a0_ld : a->a1_ld) * 4 < ((int64_t)1 << 31),
                     "winograd43: operand slice exceeds 32-bit buffer offsets");
-    dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / 128), (unsigned)a->B);
+    // 64-channel workgroups when 128-channel ones would leave CUs idle (or N is not a multiple of 128)
+    const int64_t wg128 = (int64_t)(a->H / 16) * (a->W / 16) * (a->N / 128) * a->B;
+    const bool half = (a->N % 128 != 0) || wg128 < 200;
+    const int nblk = half ? 64 : 128;
+    dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / nblk), (unsigned)a->B);
     ANODDPM_REQUIRE(a->B <= 65535, "winograd43: batch too large");
     const bool fast = a->gn_scale && a->act;
     const int dbg = anoddpm::g_debug[2];
@@ -363,6 +376,8 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
     else if (fast && dbg == 2) hipLaunchKernelGGL((wino43_kernel<true, 2>), grid, dim3(F4_NT), 0, s, *a);
     else if (fast && dbg == 3) hipLaunchKernelGGL((wino43_kernel<true, 3>), grid, dim3(F4_NT), 0, s, *a);
     else if (fast && dbg == 4) hipLaunchKernelGGL((wino43_kernel<true, 4>), grid, dim3(F4_NT), 0, s, *a);
+    else if (fast && half) hipLaunchKernelGGL((wino43_kernel<true, 0, 4>), grid, dim3(F4_NT), 0, s, *a);
+    else if (half) hipLaunchKernelGGL((wino43_kernel<false, 0, 4>), grid, dim3(F4_NT), 0, s, *a);
     else if (fast) hipLaunchKernelGGL((wino43_kernel<true>), grid, dim3(F4_NT), 0, s, *a);
     else      hipLaunchKernelGGL((wino43_kernel<false>), grid, dim3(F4_NT), 0, s, *a);
     return check_launch("winograd43");

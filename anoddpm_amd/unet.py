@@ -99,12 +99,19 @@ class GroupNorm32(nn.GroupNorm):
 
 
 def update_ema_params(target, source, decay_rate=0.9999):
-    """ema = decay*ema + (1-decay)*src per named parameter (UNet.py:423-427)."""
+    """ema = decay*ema + (1-decay)*src per named parameter (UNet.py:423-427).  Two multi-tensor launches instead of two
+    launches per parameter (536 tensors at config 2); training.FusedAdamWEMA folds the same update into the optimizer
+    kernel and is what the training step uses."""
     tp = dict(target.named_parameters())
     sp = dict(source.named_parameters())
+    keys = list(tp)
     with torch.no_grad():
-        for k in tp:
-            tp[k].data.mul_(decay_rate).add_(sp[k].data, alpha=1 - decay_rate)
+        dst = [tp[k].data for k in keys]
+        src = [sp[k].data for k in keys]
+        torch._foreach_mul_(dst, decay_rate)
+        torch._foreach_add_(dst, src, alpha=1 - decay_rate)
+    if hasattr(target, "mark_weights_changed"):
+        target.mark_weights_changed()
 
 
 # ----------------------------------------------------------------------------- topology
@@ -439,8 +446,8 @@ def _use_winograd():
 
 def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None, c1=0, wino=True, f43=False):
     """Tile configuration (0: 128x128 direct, 1: 64x64 direct, 2: Winograd F(2x2,3x3), 3: Winograd F(4x4,3x3) -- only when the
-    caller can supply its weights, `f43`, and only on large maps, where its 1.78x fewer MFMAs outweigh the looser fp32
-    rounding: ~8e-6 per layer instead of 4e-7) and split-K of one
+    caller can supply its weights, `f43`, and only on maps >= 64x64 with enough workgroups, where its 1.78x fewer MFMAs outweigh
+    the looser fp32 rounding: ~8e-6 per layer instead of 4e-7) and split-K of one
     anoddpm_igemm launch; shared by the inference plan and the training operators (train_ops).  Policy: fill the 256
     CUs -- >= 512 workgroups for the direct kernels when K allows it, one full round of >= 4-chunk workgroups for
     Winograd on small maps."""
@@ -471,17 +478,18 @@ def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None
         else:
             cps = -(-wch // wino_ksplit)
             wino_ksplit = -(-wch // cps)                   # no empty trailing block
-    if wino_ok and f43 and wino_ksplit == 1 and N % 128 == 0 and H * W >= int(os.environ.get("ANODDPM_F43_MIN_PIXELS", 128 * 128)) \
-            and os.environ.get("ANODDPM_NO_F43", "0") != "1":
-        return 3, 1
+    if wino_ok and f43 and N % 64 == 0 and H * W >= int(os.environ.get("ANODDPM_F43_MIN_PIXELS", 64 * 64)) \
+            and (H // 16) * (W // 16) * (N // 64) * Z >= 128 and os.environ.get("ANODDPM_NO_F43", "0") != "1":
+        return 3, 1                                            # the kernel picks 64- or 128-channel workgroups itself
     if wino_ok:
         return 2, wino_ksplit
     bm = 128 if cfg == 0 else 64
     blocks = -(-P // bm) * ((N + bm - 1) // bm) * Z
     nchunks = (K + 31) // 32
     ksplit = 1
-    if blocks < 512 and nchunks > 1 and N % 4 == 0:
-        ksplit = int(min(nchunks, 16, max(1, -(-512 // blocks))))
+    target = int(os.environ.get("ANODDPM_SPLITK_TARGET", 512))
+    if blocks < target and nchunks > 1 and N % 4 == 0:
+        ksplit = int(min(nchunks, 16, max(1, -(-target // blocks))))
     return cfg, ksplit
 
 

@@ -152,5 +152,11 @@ def test_conv_launch_policy_on_config2_shapes():
     assert pick(256, 256, 256, 128, Z, ks=1) == (0, 1)              # 1x1 skip convolution
     assert pick(16, 16, 512, 1536, Z, ks=1) == (1, 2)               # qkv projection
     assert pick(256, 256, 128, 128, Z, wino=False)[0] in (0, 1)
+    # Winograd F(4x4,3x3): only when the caller can supply its weights, on maps >= 128^2 with Cout % 128 == 0
+    assert pick(256, 256, 128, 128, Z, f43=True) == (3, 1) and pick(128, 128, 384, 128, Z, c0=256, c1=128, f43=True) == (3, 1)
+    assert pick(128, 128, 256, 256, Z, a_mode=1, f43=True) == (3, 1)                # fused nearest x2
+    assert pick(64, 64, 256, 256, Z, f43=True) == (3, 1) and pick(128, 128, 128, 96, Z, f43=True)[0] == 2
+    assert pick(32, 32, 256, 256, Z, f43=True) == (2, 4) and pick(64, 64, 128, 64, 1, f43=True)[0] != 3      # too few workgroups
+    assert pick(128, 128, 128, 128, Z, a_mode=2, f43=True) == (0, 1)
     cfg, ks = pick(32, 32, 768, 256, Z)
     assert cfg == 2 and (768 // 16) % 1 == 0 and (ks - 1) * -(-(768 // 16) // ks) < 768 // 16      # no empty K slice

@@ -12,7 +12,7 @@ import hipops  # noqa: E402
 
 SHAPES = [  # B, (c0, c1), N, H
     (4, (128, 0), 128, 256), (4, (128, 128), 128, 256), (4, (128, 0), 128, 128), (4, (256, 0), 256, 128),
-    (4, (256, 128), 128, 128), (4, (128, 0), 256, 128), (4, (256, 0), 256, 64), (1, (128, 0), 128, 512),
+    (4, (256, 128), 128, 128), (4, (128, 0), 256, 128), (4, (256, 0), 256, 64), (4, (512, 0), 256, 64), (1, (128, 0), 128, 512),
 ]
 dev = torch.device("cuda:0")
 for (B, (c0, c1), N, H) in SHAPES:
