@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 (OP_WGRAD3, OP_WGRAD1, OP_GN_BWD, OP_PACK, OP_SOFTMAX_BWD, OP_TRANSPOSE, OP_LINEAR_BWD, OP_STEM_BWD, OP_HEAD_BWD,
@@ -79,7 +79,8 @@ class SoftmaxArgs(Structure):
 
 class ResampleArgs(Structure):
     _fields_ = [("inp", c_void_p), ("out", c_void_p), ("B", c_int32), ("H", c_int32), ("W", c_int32),
-                ("C", c_int32), ("mode", c_int32), ("scale", c_float), ("accumulate", c_int32)]
+                ("C", c_int32), ("mode", c_int32), ("scale", c_float), ("accumulate", c_int32),
+                ("gn_scale", c_void_p), ("gn_shift", c_void_p), ("out_act", c_void_p)]
 
 
 class LinearArgs(Structure):

@@ -285,6 +285,22 @@ __global__ __launch_bounds__(256) void resample2x_kernel(anoddpm_resample_args a
             o.y = (((v00.y + v01.y) + v10.y) + v11.y) * 0.25f;
             o.z = (((v00.z + v01.z) + v10.z) + v11.z) * 0.25f;
             o.w = (((v00.w + v01.w) + v10.w) + v11.w) * 0.25f;
+            if (a.out_act) {                                       // the same four pixels, activated first (igemm a_mode 2 order)
+                const float4 sc = reinterpret_cast<const float4 *>(a.gn_scale)[(int64_t)b * C4 + q];
+                const float4 sh = reinterpret_cast<const float4 *>(a.gn_shift)[(int64_t)b * C4 + q];
+                auto act4 = [&](float4 v) {
+                    v.x = silu_f(v.x * sc.x + sh.x); v.y = silu_f(v.y * sc.y + sh.y);
+                    v.z = silu_f(v.z * sc.z + sh.z); v.w = silu_f(v.w * sc.w + sh.w);
+                    return v;
+                };
+                const float4 a00 = act4(v00), a01 = act4(v01), a10 = act4(v10), a11 = act4(v11);
+                float4 oa;
+                oa.x = (((a00.x + a01.x) + a10.x) + a11.x) * 0.25f;
+                oa.y = (((a00.y + a01.y) + a10.y) + a11.y) * 0.25f;
+                oa.z = (((a00.z + a01.z) + a10.z) + a11.z) * 0.25f;
+                oa.w = (((a00.w + a01.w) + a10.w) + a11.w) * 0.25f;
+                reinterpret_cast<float4 *>(a.out_act)[i] = oa;
+            }
         }
         if (a.scale != 0.0f && a.scale != 1.0f) { o.x *= a.scale; o.y *= a.scale; o.z *= a.scale; o.w *= a.scale; }
         if (a.accumulate) {                                    // gradient fan-in (training backward)
@@ -515,6 +531,7 @@ extern "C" int anoddpm_resample2x(const anoddpm_resample_args *a, void *stream)
 {
     ANODDPM_REQUIRE(a && a->in && a->out, "resample2x: null pointer");
     ANODDPM_REQUIRE(a->C % 4 == 0 && (a->mode == 1 || (a->mode == 2 && a->H % 2 == 0 && a->W % 2 == 0)), "resample2x: bad shape/mode");
+    ANODDPM_REQUIRE(!a->out_act || (a->mode == 2 && a->gn_scale && a->gn_shift), "resample2x: the activated output needs mode 2 and a GroupNorm affine");
     const int Ho = a->mode == 1 ? a->H * 2 : a->H / 2, Wo = a->mode == 1 ? a->W * 2 : a->W / 2;
     const int64_t total = (int64_t)a->B * Ho * Wo * (a->C / 4);
     if (total == 0) return ANODDPM_OK;

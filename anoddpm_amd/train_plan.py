@@ -353,8 +353,24 @@ class TrainPlan(_Plan):
             g1 = self.gn_t(srcs, Pin, prefix + ".in_layers.0")
             emb = self.linear_t(temb, prefix + ".embed_layers.1.weight", prefix + ".embed_layers.1.bias", ted, cout, 1)
             h1 = self.buf(B, Pout, cout)
-            conv3(srcs, Hout, cout, g1, am, prefix + ".in_layers.2.weight", prefix + ".in_layers.2.bias", h1,
-                  temb_ptr=emb.data_ptr(), temb_ld=cout)
+            sk_pool = None
+            if resample == "down":
+                # one pass over x: pooled skip input + pooled ACTIVATED conv operand (so the conv runs on the Winograd kernels);
+                # the backward is unchanged -- weight gradient and GroupNorm backward re-apply the pooling on the raw input
+                assert len(srcs) == 1
+                pooled, sk_pool = self.buf(B, Pout, cin), self.buf(B, Pout, cin)
+                st = ResampleArgs()
+                st.inp, st.out = srcs[0][0].data_ptr(), sk_pool.data_ptr()
+                st.B, st.H, st.W, st.C, st.mode, st.scale, st.accumulate = B, Hin, Hin, cin, 2, 1.0, 0
+                st.gn_scale, st.gn_shift, st.out_act = g1[0].data_ptr(), g1[1].data_ptr(), pooled.data_ptr()
+                self.add(_lib.OP_RESAMPLE, st)
+                wk, bk = prefix + ".in_layers.2.weight", prefix + ".in_layers.2.bias"
+                self.igemm(srcs=[(pooled, cin)], H=Hout, W=Hout, ks=3, N=cout, bmat=lambda: self.pack(wk, 0),
+                           wino=lambda: self.pack(wk, 1), wino43=lambda: self.pack(wk, 5), bias=bias(bk),
+                           temb=emb.data_ptr(), temb_ld=cout, out=h1, want_stats=True)
+            else:
+                conv3(srcs, Hout, cout, g1, am, prefix + ".in_layers.2.weight", prefix + ".in_layers.2.bias", h1,
+                      temb_ptr=emb.data_ptr(), temb_ld=cout)
             g2 = self.gn_t([(h1, cout)], Pout, prefix + ".out_layers.0")
             skip_kind = "identity"
             if cin != cout:
@@ -364,6 +380,9 @@ class TrainPlan(_Plan):
                 self.igemm(srcs=srcs, H=Hout, W=Hout, ks=1, N=cout, kind="conv1",
                            bmat=lambda: self.pack(prefix + ".skip_connection.weight", 2),
                            bias=bias(prefix + ".skip_connection.bias"), out=sk)
+            elif resample is not None and sk_pool is not None:
+                skip_kind = "resample"
+                sk = sk_pool
             elif resample is not None:
                 assert len(srcs) == 1
                 skip_kind = "resample"

@@ -749,9 +749,21 @@ class _Plan:
             Pin, Pout = Hin * Hin, Hout * Hout
             g1 = self.gn(srcs, Pin, prefix + ".in_layers.0.weight", prefix + ".in_layers.0.bias")
             h1 = self.buf(B, Pout, cout)
-            self.igemm(srcs=srcs, H=Hout, W=Hout, ks=3, N=cout, gn=g1, act=1,
-                       a_mode={None: 0, "up": 1, "down": 2}[resample],
-                       bmat=self.packed(prefix + ".in_layers.2.weight", _pack_conv),
+            pooled = None
+            if resample == "down" and len(srcs) == 1 and os.environ.get("ANODDPM_NO_POOL_ACT", "0") != "1":
+                # down block: ONE pass over x gives both the pooled skip input and the pooled ACTIVATED operand of the first
+                # convolution, which then runs on the Winograd kernels instead of the pool-fused direct one
+                pooled = self.buf(B, Pout, cin)
+                sk_pool = self.buf(B, Pout, cin)
+                st = ResampleArgs()
+                st.inp, st.out = srcs[0][0].data_ptr(), sk_pool.data_ptr()
+                st.B, st.H, st.W, st.C, st.mode, st.scale, st.accumulate = B, Hin, Hin, cin, 2, 1.0, 0
+                st.gn_scale, st.gn_shift, st.out_act = g1[0].data_ptr(), g1[1].data_ptr(), pooled.data_ptr()
+                self.add(_lib.OP_RESAMPLE, st)
+            self.igemm(srcs=([(pooled, cin)] if pooled is not None else srcs), H=Hout, W=Hout, ks=3, N=cout,
+                       gn=(None if pooled is not None else g1), act=(0 if pooled is not None else 1),
+                       a_mode=(0 if pooled is not None else {None: 0, "up": 1, "down": 2}[resample]),
+                       bmat=lambda p=prefix: self.packed(p + ".in_layers.2.weight", _pack_conv),
                        wino=lambda p=prefix: self.packed(p + ".in_layers.2.weight", _pack_wino),
                        wino43=lambda p=prefix: self.packed(p + ".in_layers.2.weight", _pack_wino43),
                        bias=self.packed(prefix + ".in_layers.2.bias", lambda t: t.detach().float()),
@@ -763,6 +775,8 @@ class _Plan:
                 self.igemm(srcs=srcs, H=Hout, W=Hout, ks=1, N=cout, kind="conv1",
                            bmat=self.packed(prefix + ".skip_connection.weight", _pack_conv),
                            bias=self.packed(prefix + ".skip_connection.bias", lambda t: t.detach().float()), out=sk)
+            elif resample is not None and pooled is not None:
+                sk = sk_pool
             elif resample is not None:
                 assert len(srcs) == 1
                 sk = self.buf(B, Pout, cout)
@@ -776,7 +790,7 @@ class _Plan:
                 sk = srcs[0][0]
             h2 = self.buf(B, Pout, cout)
             self.igemm(srcs=[(h1, cout)], H=Hout, W=Hout, ks=3, N=cout, gn=g2, act=1,
-                       bmat=self.packed(prefix + ".out_layers.3.weight", _pack_conv),
+                       bmat=lambda p=prefix: self.packed(p + ".out_layers.3.weight", _pack_conv),
                        wino=lambda p=prefix: self.packed(p + ".out_layers.3.weight", _pack_wino),
                        wino43=lambda p=prefix: self.packed(p + ".out_layers.3.weight", _pack_wino43),
                        bias=self.packed(prefix + ".out_layers.3.bias", lambda t: t.detach().float()),

@@ -271,6 +271,11 @@ typedef struct {
     int32_t mode;
     float scale;
     int32_t accumulate;
+    /* optional second output of mode 2: out_act = 2x2 average of silu(gn_scale[b][c] * in + gn_shift[b][c]) -- the operand the
+     * first 3x3 convolution of a down block consumes (UNet.py:170-171, 70, 206), produced in the same pass over `in` so that
+     * the convolution itself can run on the Winograd kernels */
+    const float *gn_scale, *gn_shift;   /* [B][C] or NULL */
+    float *out_act;                     /* [B][H/2][W/2][C] or NULL */
 } anoddpm_resample_args;
 
 int anoddpm_resample2x(const anoddpm_resample_args *a, void *stream);
