@@ -366,7 +366,69 @@ __global__ void posemb_kernel(anoddpm_posemb_args a)
 }
 
 // ---------------------------------------------------------------- stem conv -------------------
-// NCHW (Cin <= 4) -> NHWC Cout, 3x3 pad 1.  Thread = (pixel, 4 output channels).  Write-bound.
+// NCHW (Cin <= 4) -> NHWC Cout, 3x3 pad 1.  Write-bound (512 B per pixel at Cout = 128).  Thread = (4 output channels, a strip
+// of STEM_STRIP pixels along x): its 9 * Cin weight float4 are loaded ONCE into registers, the three input rows of the strip
+// slide through registers, and every store is 16 bytes with the Cout/4 lanes of a pixel contiguous (full 128-byte lines).
+// Cin > 2 keeps the generic per-pixel form (the reference's MRI models have Cin = 1).
+constexpr int STEM_STRIP = 8;
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_stem_strip_kernel(anoddpm_stem_args a)
+{
+    const int QP = a.Cout >> 2;
+    const int spb = 256 / QP;                        // strips per block
+    const int q = threadIdx.x % QP;
+    const int sl = threadIdx.x / QP;
+    if (sl >= spb) return;
+    const int strips_x = a.W / STEM_STRIP;
+    const int64_t nstrips = (int64_t)a.B * a.H * strips_x;
+    const int64_t strip = (int64_t)blockIdx.x * spb + sl;
+    if (strip >= nstrips) return;
+    const int sx = (int)(strip % strips_x);
+    const int y = (int)((strip / strips_x) % a.H);
+    const int b = (int)(strip / ((int64_t)strips_x * a.H));
+    const int x0 = sx * STEM_STRIP;
+    const float4 *w = reinterpret_cast<const float4 *>(a.w);
+    float4 wr[9 * CIN];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) wr[t * CIN + ci] = w[(t * CIN + ci) * QP + q];
+    const float4 bias = a.bias ? reinterpret_cast<const float4 *>(a.bias)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float in[CIN][3][STEM_STRIP + 2];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+        const float *plane = a.x + ((int64_t)b * CIN + ci) * a.H * a.W;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+#pragma unroll
+            for (int i = 0; i < STEM_STRIP + 2; ++i) {
+                const int xx = x0 + i - 1;
+                in[ci][dy][i] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? plane[(int64_t)yy * a.W + xx] : 0.f;
+            }
+        }
+    }
+    float4 *out = reinterpret_cast<float4 *>(a.out) + (((int64_t)b * a.H + y) * a.W + x0) * QP + q;
+#pragma unroll
+    for (int i = 0; i < STEM_STRIP; ++i) {
+        float4 acc = bias;
+        // same accumulation order as the per-pixel kernel: ci outermost, then dy, dx
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float v = in[ci][dy][i + dx];
+                    const float4 wv = wr[(dy * 3 + dx) * CIN + ci];
+                    acc.x += v * wv.x; acc.y += v * wv.y; acc.z += v * wv.z; acc.w += v * wv.w;
+                }
+        out[(int64_t)i * QP] = acc;
+    }
+}
+
+// generic form: thread = (pixel, 4 output channels)
 __global__ __launch_bounds__(256) void conv_stem_kernel(anoddpm_stem_args a)
 {
     const int QP = a.Cout >> 2;
@@ -566,6 +628,13 @@ extern "C" int anoddpm_conv_stem(const anoddpm_stem_args *a, void *stream)
     const int ppb = 256 / (a->Cout / 4);
     const int64_t npix = (int64_t)a->B * a->H * a->W;
     if (npix == 0) return ANODDPM_OK;
+    if (a->Cin <= 2 && a->W % STEM_STRIP == 0) {
+        const int64_t nstrips = npix / STEM_STRIP;
+        const dim3 grid((unsigned)((nstrips + ppb - 1) / ppb));
+        if (a->Cin == 1) hipLaunchKernelGGL(conv_stem_strip_kernel<1>, grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
+        else             hipLaunchKernelGGL(conv_stem_strip_kernel<2>, grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
+        return anoddpm::check_launch("conv_stem");
+    }
     hipLaunchKernelGGL(conv_stem_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, anoddpm::as_stream(stream), *a);
     return anoddpm::check_launch("conv_stem");
 }

@@ -247,6 +247,8 @@ F43_CASES = [
     (1, (64, 0), 128, 32, 1, True, 1, False, False),       # fused nearest x2
     (1, (96, 0), 128, 48, 0, True, 1, False, True),        # non power-of-two image, six K iterations
     (1, (128, 0), 128, 32, 0, False, 0, False, False),     # data-gradient form: no GroupNorm / activation
+    (4, (64, 0), 256, 64, 0, True, 1, True, True),         # 64-channel workgroups (128 of the 128-channel ones would not fill the chip)
+    (2, (32, 32), 64, 32, 0, True, 1, False, True),        # N = 64: only the 64-channel variant applies; virtual concat
 ]
 
 
