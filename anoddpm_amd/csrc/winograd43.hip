@@ -272,11 +272,46 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
     const unsigned uW = (unsigned)W, o_ld = (unsigned)a.out_ld, r_ld = (unsigned)a.res_ld;
     constexpr int ROUNDS = NTL == 8 ? 3 : 2;                        // 8 tiles: 3 + 3 + 2; 4 tiles: 2 + 2
     constexpr int RT = NTL == 8 ? 3 : 2;
+    // Item geometry of a round: tile = tid / nch, channel = tid % nch (nch = 48, 48, 32 resp. 32, 32).
+    struct Item { int tile, ch, n; bool active; unsigned vo, vr; };
+    auto item_of = [&](int round) {
+        const int nch = ((NTL == 8 && round == 2) ? 2 : RT) * 16;
+        Item it;
+        it.tile = tid / nch;
+        it.ch = tid - it.tile * nch;
+        it.active = it.tile < 16;                                   // third round: 512 items, waves 8..11 idle (wave-uniform)
+        it.n = n0 + round * RT * 16 + it.ch;
+        const unsigned pix0 = (unsigned)(y0 + (it.tile >> 2) * 4) * uW + (unsigned)(x0 + (it.tile & 3) * 4);
+        it.vo = (pix0 * o_ld + (unsigned)it.n) * 4u;
+        it.vr = (pix0 * r_ld + (unsigned)it.n) * 4u;
+        return it;
+    };
+    // The residual pixels and the per-channel addend of a round are requested one round AHEAD (round 0: before the accumulators
+    // go through LDS): the output stores may alias them as far as the compiler knows, so left next to their use each of the 16
+    // loads would wait out its own HBM latency (measured: 256^2 128->128 with residual 310 -> 270 us).
+    auto prefetch = [&](const Item &it, float (&rv)[16], float &add) {
+        add = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rv[i] = 0.f;
+        if (it.active) {
+            if (has_res) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        rv[i * 4 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rR, (int)it.vr, (int)((((unsigned)i * uW + (unsigned)j) * 4u) * r_ld), 0));
+            }
+            if (a.bias) add += a.bias[it.n];
+            if (TE) add += TE[it.n];
+        }
+    };
+    float rv[ROUNDS][16], add[ROUNDS], cs[ROUNDS], cq[ROUNDS];
+    prefetch(item_of(0), rv[0], add[0]);
 #pragma unroll
     for (int round = 0; round < ROUNDS; ++round) {
         const int nt0 = round * RT;
         const int ntn = (NTL == 8 && round == 2) ? 2 : RT;
-        const int nch = ntn * 16;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -287,11 +322,12 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
                         M[((wave * 3 + p) * 16 + kq * 4 + r) * F4_MS + nt * 16 + l15] = acc[p][nt0 + nt][r];
                 }
         __syncthreads();
-        const int tile = tid / nch, ch = tid - tile * nch;
-        const bool active = tile < 16;                              // third round: 512 items, waves 8..11 idle (wave-uniform)
-        float cs = 0.f, cq = 0.f;
-        if (active) {
-            const float *m = M + (size_t)tile * F4_MS + ch;
+        if (round + 1 < ROUNDS) prefetch(item_of(round + 1), rv[round + 1], add[round + 1]);
+        const Item it = item_of(round);
+        cs[round] = 0.f;
+        cq[round] = 0.f;
+        if (it.active) {
+            const float *m = M + (size_t)it.tile * F4_MS + it.ch;
             // columns first: y[i][v] = sum_u A^T[i][u] m[u][v]
             float y[4][6];
 #pragma unroll
@@ -305,12 +341,6 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
                 y[2][v] = s12 + 4.f * s34;
                 y[3][v] = d12 + 8.f * d34 + mu[5];
             }
-            const int n = n0 + nt0 * 16 + ch;
-            float add = 0.f;
-            if (a.bias) add += a.bias[n];
-            if (TE) add += TE[n];
-            const unsigned pix0 = (unsigned)(y0 + (tile >> 2) * 4) * uW + (unsigned)(x0 + (tile & 3) * 4);
-            const unsigned vo = (pix0 * o_ld + (unsigned)n) * 4u, vr = (pix0 * r_ld + (unsigned)n) * 4u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float s12 = y[i][1] + y[i][2], d12 = y[i][1] - y[i][2], s34 = y[i][3] + y[i][4], d34 = y[i][3] - y[i][4];
@@ -322,30 +352,33 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const unsigned so = ((unsigned)i * uW + (unsigned)j) * 4u;          // wave-uniform pixel offset (x ld below)
-                    float v = a.alpha * o4[j] + add;
-                    if (has_res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR, (int)vr, (int)(so * r_ld), 0));
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, (int)vo, (int)(so * o_ld), 0);
-                    cs += v;
-                    cq += v * v;
+                    const float v = a.alpha * o4[j] + add[round] + rv[round][i * 4 + j];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, (int)it.vo, (int)(so * o_ld), 0);
+                    cs[round] += v;
+                    cq[round] += v * v;
                 }
             }
         }
-        if (a.stats) {
-            // per-channel sums over the workgroup's 256 pixels: ONE statistics row per workgroup
-            __syncthreads();                                        // all reads of M done: its head becomes the scratch
-            float *rs = M, *rq = M + 16 * 48;
-            if (active) { rs[tile * 48 + ch] = cs; rq[tile * 48 + ch] = cq; }
-            __syncthreads();
-            if (tid < nch) {
-                float s = 0.f, q = 0.f;
+        __syncthreads();                                            // all reads of M done
+    }
+    if (a.stats) {
+        // per-channel sums over the workgroup's 256 pixels: ONE statistics row per workgroup, reduced once for all rounds
+        float *rs = M, *rq = M + ROUNDS * 16 * 48;
 #pragma unroll
-                for (int t = 0; t < 16; ++t) { s += rs[t * 48 + tid]; q += rq[t * 48 + tid]; }
-                float *st = a.stats + (((int64_t)b * gridDim.x + blockIdx.x) * N + n0 + nt0 * 16 + tid) * 2;
-                st[0] = s;
-                st[1] = q;
-            }
+        for (int round = 0; round < ROUNDS; ++round) {
+            const Item it = item_of(round);
+            if (it.active) { rs[(round * 16 + it.tile) * 48 + it.ch] = cs[round]; rq[(round * 16 + it.tile) * 48 + it.ch] = cq[round]; }
         }
         __syncthreads();
+        if (tid < NTL * 16) {
+            const int round = tid / (RT * 16), chl = tid - round * (RT * 16);
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { s += rs[(round * 16 + t) * 48 + chl]; q += rq[(round * 16 + t) * 48 + chl]; }
+            float *st = a.stats + (((int64_t)b * gridDim.x + blockIdx.x) * N + n0 + tid) * 2;
+            st[0] = s;
+            st[1] = q;
+        }
     }
 }
 

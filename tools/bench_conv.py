@@ -24,9 +24,11 @@ for (B, (c0, c1), N, H) in SHAPES:
     gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     gn = hipops.gn_affine(srcs, gamma, beta)
     line = f"B{B} {c0}+{c1}->{N} @{H}:"
+    full = bool(os.environ.get("FULL"))             # FULL=1: + residual, time-embedding addend and GroupNorm statistics
+    extra = dict(res=torch.randn(B, H, H, N, device=dev), temb=torch.randn(B, N, device=dev), stats_out=[]) if full else {}
     for cfg in ((3,) if os.environ.get('ONLY3') else (2, 3)):
         for _ in range(2):
-            hipops.conv_igemm(srcs, w, b, Hout=H, ks=3, gn=gn, act=1, cfg=cfg)
+            hipops.conv_igemm(srcs, w, b, Hout=H, ks=3, gn=gn, act=1, cfg=cfg, **extra)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         import ctypes
         # re-launch the prepared struct without the per-call packing of hipops: time 10 launches of the kernel alone
@@ -39,5 +41,5 @@ for (B, (c0, c1), N, H) in SHAPES:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 100
         gf = 2.0 * C * N * 9 * H * H * B / 1e9
-        line += f"  cfg{cfg} {us:7.1f} us ({gf / us * 1e-3 * 1e3:6.1f} alg TFLOP/s)"
+        line += f"  cfg{cfg} {us:7.1f} us ({gf / us * 1e3:6.1f} alg TFLOP/s)"
     print(line, flush=True)

@@ -30,4 +30,4 @@ print("kind,H,K,N,ks,a_mode,cfg,ksplit,launches_per_step,avg_us,algorithmic_TFLO
 for k, (cnt, us, gf) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     avg = us / cnt
     ex = {2: 4.0 / 9.0, 3: 0.25}.get(k[6], 1.0)
-    print(",".join(str(v) for v in k) + f",{cnt // nst},{avg:.1f},{gf / avg * 1e-3:.1f},{gf * ex / avg * 1e-3:.1f},{us / nst:.0f}")
+    print(",".join(str(v) for v in k) + f",{cnt // nst},{avg:.1f},{gf / avg * 1e3:.1f},{gf * ex / avg * 1e3:.1f},{us / nst:.0f}")
