@@ -22,6 +22,7 @@ SOURCES = {
     "igemm.hip": [],
     "winograd.hip": [],
     "winograd43.hip": [],
+    "pointwise.hip": [],
     "executor.hip": [],
     "optim.hip": [],
     "metrics.hip": ["-ffp-contract=off"],

@@ -30,6 +30,7 @@ inline int check_launch(const char *what)
 
 int launch_winograd(const anoddpm_igemm_args *a, hipStream_t s);   // winograd.hip (cfg == 2 of anoddpm_igemm)
 int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s); // winograd43.hip (cfg == 3)
+int launch_pointwise_stream(const anoddpm_igemm_args *a, hipStream_t s); // pointwise.hip (cfg == 4)
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -444,8 +444,9 @@ def _use_winograd():
     return os.environ.get("ANODDPM_NO_WINOGRAD", "0") != "1"
 
 
-def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None, c1=0, wino=True, f43=False):
-    """Tile configuration (0: 128x128 direct, 1: 64x64 direct, 2: Winograd F(2x2,3x3), 3: Winograd F(4x4,3x3) -- only when the
+def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None, c1=0, wino=True, f43=False, plain=False):
+    """Tile configuration (0: 128x128 direct, 1: 64x64 direct, 4: streaming 1x1 for large maps, 2: Winograd F(2x2,3x3),
+    3: Winograd F(4x4,3x3) -- only when the
     caller can supply its weights, `f43`, and only on maps >= 64x64 with enough workgroups, where its 1.78x fewer MFMAs outweigh
     the looser fp32 rounding: ~8e-6 per layer instead of 4e-7) and split-K of one
     anoddpm_igemm launch; shared by the inference plan and the training operators (train_ops).  Policy: fill the 256
@@ -453,6 +454,13 @@ def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None
     Winograd on small maps."""
     c0 = K if c0 is None else c0
     P = H * W
+    if (plain and ks == 1 and a_mode == 0 and b_mode == 0 and heads == 1 and K % 128 == 0 and K <= 512 and c0 % 32 == 0
+            and P % 32 == 0 and N % 64 == 0 and os.environ.get("ANODDPM_NO_STREAM1X1", "0") != "1"):
+        # cfg 4: streaming 1x1 (weights resident in LDS, one 32-pixel tile per wave pass) -- `plain` = no fused GroupNorm /
+        # activation / statistics; needs enough 32-pixel tiles x channel blocks for the 2048 waves of the chip
+        nb = 128 if (N % 128 == 0 and K <= 256) else 64
+        if (Z * P // 32) * (N // nb) >= 2048:
+            return 4, 1
 
     def ok128():
         if P % 128:
@@ -644,7 +652,8 @@ class _Plan:
         st.B, st.heads, st.alpha = B, heads, alpha
         Z = B * heads
         cfg, ksplit = choose_conv_cfg(H, W, K, N, Z, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads, c0=c0, c1=c1,
-                                      wino=bool(wino), f43=bool(wino43))
+                                      wino=bool(wino), f43=bool(wino43),
+                                      plain=(gn is None and act == 0 and not want_stats))
         bm = 128 if cfg == 0 else 64
         st.cfg, st.ksplit = cfg, ksplit
         _st, _bmat, _wino = self._pending_bmat

@@ -195,7 +195,9 @@ typedef struct {
     int32_t ksplit;                 /* >= 1 */
     int32_t cfg;                    /* 0: 128x128 tile, 1: 64x64 tile, 2: Winograd F(2x2,3x3): ks 3, a_mode 0/1, H,W % 16 == 0,
                                        bmat = transformed weights [16][K/4][N][4] (G g G^T); 3: Winograd F(4x4,3x3): as 2 with
-                                       N % 128 == 0, ksplit 1, bmat [36][K/4][N][4]; statistics: one row per 16x16 patch */
+                                       N % 64 == 0, ksplit 1, bmat [36][K/4][N][4]; statistics: one row per 16x16 patch;
+                                       4: streaming 1x1 for large maps (pointwise.hip): ks 1, a_mode 0, b_mode 0, heads 1, ksplit 1,
+                                       no gn / act / stats, K % 128 == 0, K <= 512, c0 % 32 == 0, H*W % 32 == 0, N % 64 == 0 */
     float alpha;
     int32_t gn_ld;                  /* row length of gn_scale/gn_shift (= K) */
     float *stats;                   /* or NULL: per-channel partial sums of the OUTPUT, [B][tiles*2][N][2]

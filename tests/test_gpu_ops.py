@@ -252,6 +252,58 @@ F43_CASES = [
 ]
 
 
+STREAM1X1_CASES = [
+    # B, (c0, c1), Cout, H, temb, res
+    (1, (128, 0), 128, 32, False, False),      # one chunk group, 128-channel workgroups
+    (2, (128, 128), 128, 64, False, False),    # the 256^2 skip shape in small: virtual concat, several tiles per wave
+    (4, (256, 0), 128, 96, True, True),        # tiles do not divide over the waves; all epilogue operands
+    (2, (256, 128), 128, 32, False, True),     # K = 384: 64-channel workgroups
+    (1, (512, 0), 256, 32, False, False),      # K = 512, four channel blocks
+    (2, (128, 0), 64, 32, False, True),        # N = 64
+    (3, (128, 0), 256, 16, False, False),      # 8 tiles per image: fewer tiles than waves
+]
+
+
+@pytest.mark.parametrize("case", STREAM1X1_CASES)
+def test_streaming_pointwise_conv(case):
+    """cfg = 4: the streaming 1x1 convolution (csrc/pointwise.hip; UNet.py:200 skip_connection on large maps) against fp64
+    conv2d.  Same fp32 MFMA chain as the direct kernel in a permuted k order: 1e-5 of the tensor magnitude."""
+    import hipops
+    B, (c0, c1), N, H, use_temb, use_res = case
+    C = c0 + c1
+    x = rnd(B, C, H, H, seed=191)
+    w = rnd(N, C, 1, 1, seed=192, scale=1.0 / math.sqrt(C))
+    b = rnd(N, seed=193, scale=0.1)
+    temb = rnd(B, N, seed=196) if use_temb else None
+    res = rnd(B, N, H, H, seed=197) if use_res else None
+    ref = F.conv2d(x.double(), w.double(), b.double())
+    if temb is not None:
+        ref = ref + temb[:, :, None, None].double()
+    if res is not None:
+        ref = ref + res.double()
+    xs = hipops.nhwc(x.to(dev()))
+    srcs = [xs[..., :c0].contiguous()] + ([xs[..., c0:].contiguous()] if c1 else [])
+    got = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), Hout=H, ks=1, temb=temb.to(dev()) if temb is not None else None,
+                            res=hipops.nhwc(res.to(dev())) if res is not None else None, cfg=4)
+    err = relerr(hipops.nchw(got), ref.float())
+    assert err < 1e-5, err
+    direct = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), Hout=H, ks=1, temb=temb.to(dev()) if temb is not None else None,
+                               res=hipops.nhwc(res.to(dev())) if res is not None else None, cfg=1)
+    assert relerr(got, direct) < 1e-5
+
+
+def test_streaming_pointwise_rejects_fused_operands():
+    """cfg = 4 has no GroupNorm / activation / statistics path: the entry point says so instead of ignoring them."""
+    import hipops
+    x = hipops.nhwc(rnd(1, 128, 32, 32, seed=5).to(dev()))
+    w = rnd(128, 128, 1, 1, seed=6).to(dev())
+    with pytest.raises(Exception, match="pointwise stream"):
+        hipops.conv_igemm([x], w, None, Hout=32, ks=1, act=1, cfg=4)
+    with pytest.raises(Exception, match="pointwise stream"):
+        hipops.conv_igemm([hipops.nhwc(rnd(1, 64, 32, 32, seed=5).to(dev()))], rnd(128, 64, 1, 1, seed=6).to(dev()), None,
+                          Hout=32, ks=1, cfg=4)
+
+
 @pytest.mark.parametrize("case", F43_CASES)
 def test_winograd_f43_conv(case):
     """cfg = 3: Winograd F(4x4,3x3) (csrc/winograd43.hip) against the direct 3x3 convolution.  fp32 with wider transforms:

@@ -158,5 +158,11 @@ def test_conv_launch_policy_on_config2_shapes():
     assert pick(64, 64, 256, 256, Z, f43=True) == (3, 1) and pick(128, 128, 128, 96, Z, f43=True)[0] == 2
     assert pick(32, 32, 256, 256, Z, f43=True) == (2, 4) and pick(64, 64, 128, 64, 1, f43=True)[0] != 3      # too few workgroups
     assert pick(128, 128, 128, 128, Z, a_mode=2, f43=True) == (0, 1)
+    # streaming 1x1 (cfg 4): plain operands only, enough 32-pixel tiles x channel blocks for the chip's 2048 waves
+    assert pick(256, 256, 256, 128, Z, ks=1, c0=128, c1=128, plain=True) == (4, 1)
+    assert pick(128, 128, 384, 128, Z, ks=1, c0=256, c1=128, plain=True) == (4, 1)
+    assert pick(64, 64, 512, 256, Z, ks=1, plain=True) == (4, 1)
+    assert pick(32, 32, 512, 256, Z, ks=1, plain=True)[0] != 4 and pick(16, 16, 512, 512, Z, ks=1, plain=True)[0] != 4
+    assert pick(256, 256, 256, 128, Z, ks=1)[0] == 0 and pick(256, 256, 192, 128, Z, ks=1, plain=True)[0] == 0
     cfg, ks = pick(32, 32, 768, 256, Z)
     assert cfg == 2 and (768 // 16) % 1 == 0 and (ks - 1) * -(-(768 // 16) // ks) < 768 // 16      # no empty K slice

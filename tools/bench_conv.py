@@ -9,13 +9,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import hipops  # noqa: E402
+import ctypes  # noqa: E402
+from anoddpm_amd._lib import lib, current_stream  # noqa: E402
 
 SHAPES = [  # B, (c0, c1), N, H
     (4, (128, 0), 128, 256), (4, (128, 128), 128, 256), (4, (128, 0), 128, 128), (4, (256, 0), 256, 128),
     (4, (256, 128), 128, 128), (4, (128, 0), 256, 128), (4, (256, 0), 256, 64), (4, (512, 0), 256, 64), (1, (128, 0), 128, 512),
 ]
 dev = torch.device("cuda:0")
-for (B, (c0, c1), N, H) in SHAPES:
+for (B, (c0, c1), N, H) in ([] if os.environ.get('PW') else SHAPES):
     C = c0 + c1
     x = torch.randn(B, H, H, C, device=dev)
     srcs = [x[..., :c0].contiguous()] + ([x[..., c0:].contiguous()] if c1 else [])
@@ -30,9 +32,7 @@ for (B, (c0, c1), N, H) in SHAPES:
         for _ in range(2):
             hipops.conv_igemm(srcs, w, b, Hout=H, ks=3, gn=gn, act=1, cfg=cfg, **extra)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        import ctypes
         # re-launch the prepared struct without the per-call packing of hipops: time 10 launches of the kernel alone
-        from anoddpm_amd._lib import lib, current_stream
         st = hipops.LAST_IGEMM
         e0.record()
         for _ in range(10):
@@ -43,3 +43,27 @@ for (B, (c0, c1), N, H) in SHAPES:
         gf = 2.0 * C * N * 9 * H * H * B / 1e9
         line += f"  cfg{cfg} {us:7.1f} us ({gf / us * 1e3:6.1f} alg TFLOP/s)"
     print(line, flush=True)
+
+if os.environ.get("PW"):                                 # PW=1: the 1x1 skip shapes, direct (cfg 0 / 1) vs streaming (cfg 4)
+    for (B, (c0, c1), N, H) in [(4, (128, 128), 128, 256), (4, (256, 0), 128, 128), (4, (256, 128), 128, 128), (4, (512, 0), 256, 64),
+                                (4, (256, 128), 256, 64), (4, (128, 0), 256, 256)]:
+        C = c0 + c1
+        x = torch.randn(B, H, H, C, device=dev)
+        srcs = [x[..., :c0].contiguous()] + ([x[..., c0:].contiguous()] if c1 else [])
+        w = torch.randn(N, C, 1, 1, device=dev) * 0.05
+        b = torch.zeros(N, device=dev)
+        line = f"1x1 B{B} {c0}+{c1}->{N} @{H}:"
+        for cfg in (0, 4):
+            for _ in range(2):
+                hipops.conv_igemm(srcs, w, b, Hout=H, ks=1, cfg=cfg)
+            st = hipops.LAST_IGEMM
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                lib().anoddpm_igemm(ctypes.byref(st), current_stream())
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 100
+            gf = 2.0 * C * N * H * H * B / 1e9
+            line += f"  cfg{cfg} {us:7.1f} us ({gf / us * 1e3:6.1f} TFLOP/s)"
+        print(line, flush=True)
