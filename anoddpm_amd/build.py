@@ -23,6 +23,7 @@ SOURCES = {
     "winograd.hip": [],
     "winograd43.hip": [],
     "pointwise.hip": [],
+    "attention.hip": [],
     "executor.hip": [],
     "optim.hip": [],
     "metrics.hip": ["-ffp-contract=off"],

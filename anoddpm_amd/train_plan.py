@@ -452,18 +452,19 @@ class TrainPlan(_Plan):
                        bmat=lambda: self.pack(prefix + ".to_qkv.weight", 2), bias=bias(prefix + ".to_qkv.bias"), out=qkv)
             Pm = self.buf(Z, L, L)                               # softmax output, kept for the backward
             qp = qkv.data_ptr()
-            self.igemm(srcs=[(qp, ch, 3 * C)], H=1, W=L, ks=1, N=L, b_mode=1, ldb=3 * C, heads=heads,
-                       bmat=qp + 4 * ch, alpha=alpha, kind="attn",
-                       a_strides=(L * 3 * C, 3 * ch), b_strides=(L * 3 * C, 3 * ch),
-                       out=Pm, out_ld=L, o_strides=(heads * L * L, L * L))
-            sm = SoftmaxArgs()
-            sm.x, sm.rows, sm.L = Pm.data_ptr(), Z * L, L
-            self.add(_lib.OP_SOFTMAX, sm)
             att = self.buf(B, L, C)
-            self.igemm(srcs=[(Pm.data_ptr(), L, L)], H=1, W=L, ks=1, N=ch, b_mode=2, ldb=3 * C, heads=heads,
-                       bmat=qp + 4 * 2 * ch, kind="attn",
-                       a_strides=(heads * L * L, L * L), b_strides=(L * 3 * C, 3 * ch),
-                       out=att, out_ld=C, o_strides=(L * C, ch))
+            if not self.attention(qkv, att, L, heads, ch, probs=Pm):
+                self.igemm(srcs=[(qp, ch, 3 * C)], H=1, W=L, ks=1, N=L, b_mode=1, ldb=3 * C, heads=heads,
+                           bmat=qp + 4 * ch, alpha=alpha, kind="attn",
+                           a_strides=(L * 3 * C, 3 * ch), b_strides=(L * 3 * C, 3 * ch),
+                           out=Pm, out_ld=L, o_strides=(heads * L * L, L * L))
+                sm = SoftmaxArgs()
+                sm.x, sm.rows, sm.L = Pm.data_ptr(), Z * L, L
+                self.add(_lib.OP_SOFTMAX, sm)
+                self.igemm(srcs=[(Pm.data_ptr(), L, L)], H=1, W=L, ks=1, N=ch, b_mode=2, ldb=3 * C, heads=heads,
+                           bmat=qp + 4 * 2 * ch, kind="attn",
+                           a_strides=(heads * L * L, L * L), b_strides=(L * 3 * C, 3 * ch),
+                           out=att, out_ld=C, o_strides=(L * C, ch))
             y = self.buf(B, L, C)
             self.igemm(srcs=[(att, C)], H=Hc, W=Hc, ks=1, N=C, kind="qkvproj",
                        bmat=lambda: self.pack(prefix + ".proj_out.weight", 2), bias=bias(prefix + ".proj_out.bias"),

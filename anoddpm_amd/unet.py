@@ -26,7 +26,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
-from ._lib import (ChanStatsArgs, GnFinalizeArgs, HeadArgs, IgemmArgs, LayoutArgs, LinearArgs, Op, PosembArgs,
+from ._lib import (AttentionArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, IgemmArgs, LayoutArgs, LinearArgs, Op, PosembArgs,
                    ResampleArgs, SoftmaxArgs, StemArgs, check, lib)
 
 __all__ = ["UNetModel", "update_ema_params", "zero_module", "GroupNorm32"]
@@ -444,6 +444,12 @@ def _use_winograd():
     return os.environ.get("ANODDPM_NO_WINOGRAD", "0") != "1"
 
 
+def fused_attention_ok(L, ch):
+    """Shapes anoddpm_attention takes: the score rows of a 16-query block live in LDS (L <= 1024), power-of-two head width."""
+    return (L % 16 == 0 and 16 <= L <= 1024 and 16 <= ch <= 512 and (ch & (ch - 1)) == 0
+            and os.environ.get("ANODDPM_NO_FUSED_ATTENTION", "0") != "1")
+
+
 def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None, c1=0, wino=True, f43=False, plain=False):
     """Tile configuration (0: 128x128 direct, 1: 64x64 direct, 4: streaming 1x1 for large maps, 2: Winograd F(2x2,3x3),
     3: Winograd F(4x4,3x3) -- only when the
@@ -604,6 +610,24 @@ class _Plan:
         st.c0, st.c1, st.P, st.B, st.groups, st.eps = c0, c1, P, B, 32, 1e-5
         self.add(_lib.OP_GN_FINALIZE, st)
         return scale, shift
+
+    def attention(self, qkv, att, L, heads, ch, probs=None):
+        """One fused launch for softmax(q^T k / sqrt(ch)) v (csrc/attention.hip) when the shape allows it; False otherwise (the
+        caller then emits the three-launch form).  ANODDPM_NO_FUSED_ATTENTION=1 disables it."""
+        if not fused_attention_ok(L, ch):
+            return False
+        st = AttentionArgs()
+        st.qkv, st.out = qkv.data_ptr(), att.data_ptr()
+        st.probs = probs.data_ptr() if probs is not None else None
+        st.B, st.L, st.heads, st.ch, st.scale = self.B, L, heads, ch, 1.0 / math.sqrt(ch)
+        self.add(_lib.OP_ATTENTION, st)
+        fl = 4.0 * L * L * ch * heads * self.B
+        if not hasattr(self, "attention_log"):
+            self.attention_log = []
+        self.attention_log.append(dict(kind="attn_fused", L=L, ch=ch, heads=heads, gflop=fl / 1e9))
+        self.flops["attn"] = self.flops.get("attn", 0.0) + fl
+        self.igemm_flops += fl
+        return True
 
     def igemm(self, *, srcs, H, W, ks, N, bmat, out, out_ld=None, gn=None, act=0, a_mode=0, bias=None,
               temb=None, temb_ld=0, res=None, res_ld=0, b_mode=0, ldb=0, heads=1, alpha=1.0,
@@ -817,21 +841,22 @@ class _Plan:
             self.igemm(srcs=[(x, C)], H=Hc, W=Hc, ks=1, N=3 * C, gn=g, act=0, kind="qkvproj",
                        bmat=self.packed(prefix + ".to_qkv.weight", _pack_conv),
                        bias=self.packed(prefix + ".to_qkv.bias", lambda t: t.detach().float()), out=qkv)
-            S_ = self.buf(B * heads, L, L)
-            qp = qkv.data_ptr()
-            # scores = (q*s)^T (k*s), s = ch^-1/4  ->  alpha = ch^-1/2 on the product (UNet.py:147-150)
-            self.igemm(srcs=[(qp, ch, 3 * C)], H=1, W=L, ks=1, N=L, b_mode=1, ldb=3 * C, heads=heads,
-                       bmat=qp + 4 * ch, alpha=1.0 / math.sqrt(ch), kind="attn",
-                       a_strides=(L * 3 * C, 3 * ch), b_strides=(L * 3 * C, 3 * ch),
-                       out=S_, out_ld=L, o_strides=(heads * L * L, L * L))
-            sm = SoftmaxArgs()
-            sm.x, sm.rows, sm.L = S_.data_ptr(), B * heads * L, L
-            self.add(_lib.OP_SOFTMAX, sm)
             att = self.buf(B, L, C)
-            self.igemm(srcs=[(S_.data_ptr(), L, L)], H=1, W=L, ks=1, N=ch, b_mode=2, ldb=3 * C, heads=heads,
-                       bmat=qp + 4 * 2 * ch, kind="attn",
-                       a_strides=(heads * L * L, L * L), b_strides=(L * 3 * C, 3 * ch),
-                       out=att, out_ld=C, o_strides=(L * C, ch))
+            if not self.attention(qkv, att, L, heads, ch):
+                S_ = self.buf(B * heads, L, L)
+                qp = qkv.data_ptr()
+                # scores = (q*s)^T (k*s), s = ch^-1/4  ->  alpha = ch^-1/2 on the product (UNet.py:147-150)
+                self.igemm(srcs=[(qp, ch, 3 * C)], H=1, W=L, ks=1, N=L, b_mode=1, ldb=3 * C, heads=heads,
+                           bmat=qp + 4 * ch, alpha=1.0 / math.sqrt(ch), kind="attn",
+                           a_strides=(L * 3 * C, 3 * ch), b_strides=(L * 3 * C, 3 * ch),
+                           out=S_, out_ld=L, o_strides=(heads * L * L, L * L))
+                sm = SoftmaxArgs()
+                sm.x, sm.rows, sm.L = S_.data_ptr(), B * heads * L, L
+                self.add(_lib.OP_SOFTMAX, sm)
+                self.igemm(srcs=[(S_.data_ptr(), L, L)], H=1, W=L, ks=1, N=ch, b_mode=2, ldb=3 * C, heads=heads,
+                           bmat=qp + 4 * 2 * ch, kind="attn",
+                           a_strides=(heads * L * L, L * L), b_strides=(L * 3 * C, 3 * ch),
+                           out=att, out_ld=C, o_strides=(L * C, ch))
             y = self.buf(B, L, C)
             self.igemm(srcs=[(att, C)], H=Hc, W=Hc, ks=1, N=C, kind="qkvproj",
                        bmat=self.packed(prefix + ".proj_out.weight", _pack_conv),

@@ -258,12 +258,14 @@ def run_reverse(c, args, cfg):
         L.anoddpm_prof_enable(0)
         # contraction classes: profiler slot, launches of the plan, fraction of the direct-convolution FLOPs the matrix pipe executes
         classes = {
-            "wino43_kernel (Winograd F(4x4,3x3) 3x3 convolutions on maps >= 128x128, v_mfma_f32_16x16x4_f32)":
+            "wino43_kernel (Winograd F(4x4,3x3) 3x3 convolutions on maps >= 64x64, v_mfma_f32_16x16x4_f32)":
                 (14, [e for e in plan.igemm_log if e.get("f43")], 36.0 / (16 * 9)),
             "wino_kernel (Winograd F(2x2,3x3) 3x3 convolutions, v_mfma_f32_32x32x2_f32)":
                 (12, [e for e in plan.igemm_log if e["wino"] and not e.get("f43")], 4.0 / 9.0),
-            "igemm_kernel (direct implicit GEMM: 1x1, pool-fused and 8x8 3x3, qkv/proj, attention; v_mfma_f32_32x32x2_f32)":
+            "igemm_kernel / pointwise_stream_kernel (direct implicit GEMM: 1x1, 8x8 3x3, qkv/proj; v_mfma_f32_32x32x2_f32)":
                 (_lib.OP_IGEMM, [e for e in plan.igemm_log if not e["wino"]], 1.0),
+            "attention_kernel (fused QK^T - softmax - AV per attention block, v_mfma_f32_16x16x4_f32)":
+                (_lib.OP_ATTENTION, getattr(plan, "attention_log", []), 1.0),
         }
         flops_per_step = plan.igemm_flops
 
@@ -304,7 +306,7 @@ def run_reverse(c, args, cfg):
                     "class_ms_per_step": {name: ms[code] / args.steps for name, code in
                                           (("winograd_f43", 14), ("winograd_f23", 12), ("igemm_direct", 1), ("gn_stats", 2), ("softmax", 3), ("resample", 4),
                                            ("linear", 5), ("posemb", 6), ("stem", 7), ("layout", 8), ("chan_stats", 9),
-                                           ("gn_finalize", 10), ("head", 11))},
+                                           ("gn_finalize", 10), ("head", 11), ("attention", 26))},
                     "instrumented_ms_per_step": prof_ms_per_step}
     metric = ("reverse-diffusion images/sec @256x256 T=1000 simplex" if cfg["img"] == 256 else
               f"reverse-diffusion images/sec @{cfg['img']}x{cfg['img']} T=1000 simplex")
@@ -391,7 +393,7 @@ def run_train(c, args, cfg):
             names = {1: "igemm_direct", 12: "winograd_f23", 14: "winograd_f43", 3: "softmax", 4: "resample", 5: "linear", 6: "posemb", 7: "stem", 9: "chan_stats",
                      10: "gn_finalize", 11: "head", 16: "wgrad3x3", 17: "wgrad_pointwise", 18: "gn_silu_backward", 19: "pack_weights",
                      20: "softmax_backward", 21: "transpose", 22: "linear_backward", 23: "stem_backward", 24: "head_backward",
-                     25: "colsum_fold"}
+                     25: "colsum_fold", 26: "attention"}
             ach = w_fl / (w_ms / 1000.0) / 1e12 if w_ms > 0 else 0.0
             roofline = {"bound": "mfma", "kernel": "wgrad_kernel (3x3 weight gradient, nine-tap MFMA tiles, v_mfma_f32_32x32x2_f32)",
                         "achieved": ach, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MATRIX_TFLOPS,

@@ -154,6 +154,7 @@ enum {
     ANODDPM_OP_STEM_BWD = 23,    /* anoddpm_stem_bwd_args     */
     ANODDPM_OP_HEAD_BWD = 24,    /* anoddpm_head_bwd_args     */
     ANODDPM_OP_COLSUM_FOLD = 25, /* anoddpm_colsum_fold_args  */
+    ANODDPM_OP_ATTENTION = 26,   /* anoddpm_attention_args    */
     ANODDPM_OP_MAX = 32
 };
 
@@ -261,6 +262,23 @@ typedef struct {
 } anoddpm_softmax_args;
 
 int anoddpm_softmax_rows(const anoddpm_softmax_args *a, void *stream);
+
+/* Fused QKVAttention core (UNet.py:137-153; QKVAttentionLegacy channel order): per (image, head)
+ *     weight = softmax(scale * q^T k),   a = weight v
+ * in one launch: qkv [B][L][3*heads*ch] holds, for head h, q at channel h*3*ch, k at +ch, v at +2*ch (the output of the to_qkv
+ * convolution, UNet.py:115,122); out [B][L][heads*ch]; probs (or NULL) receives the softmax [B*heads][L][L] (the training
+ * backward reads it).  scale = 1/sqrt(ch) (the reference scales q and k by ch^-1/4 each, UNet.py:147-150).
+ * Needs L % 16 == 0, 16 <= L <= 1024 (the score rows of a 16-query block live in LDS), ch a power of two in [16, 512].
+ * Other shapes: three anoddpm_igemm / anoddpm_softmax_rows launches (b_mode 1 / 2). */
+typedef struct {
+    const float *qkv;
+    float *out;
+    float *probs;
+    int32_t B, L, heads, ch;
+    float scale;
+} anoddpm_attention_args;
+
+int anoddpm_attention(const anoddpm_attention_args *a, void *stream);
 
 /* 2x resampling of an NHWC tensor (the x_upd path of ResBlock, UNet.py:177-181,207):
  * mode 1: nearest x2 up (in H x W -> out 2H x 2W); mode 2: 2x2 average pool (in -> H/2 x W/2).

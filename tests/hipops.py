@@ -156,6 +156,22 @@ def attention(qkv, heads, cfg=1):
     return out, S
 
 
+def attention_fused(qkv, heads, want_probs=False):
+    """qkv: [B, L, 3C] (legacy per-head q|k|v channel order) -> ([B, L, C], probs or None) through anoddpm_attention."""
+    from anoddpm_amd._lib import AttentionArgs
+    B, L, C3 = qkv.shape
+    C = C3 // 3
+    ch = C // heads
+    out = torch.full((B, L, C), float("nan"), device=qkv.device)
+    probs = torch.full((B * heads, L, L), float("nan"), device=qkv.device) if want_probs else None
+    st = AttentionArgs()
+    st.qkv, st.out, st.probs = qkv.data_ptr(), out.data_ptr(), probs.data_ptr() if want_probs else None
+    st.B, st.L, st.heads, st.ch, st.scale = B, L, heads, ch, 1.0 / math.sqrt(ch)
+    check(lib().anoddpm_attention(ctypes.byref(st), current_stream()), "attention")
+    torch.cuda.synchronize()
+    return out, probs
+
+
 def resample(x, mode):
     B, H, W, C = x.shape
     Ho = H * 2 if mode == 1 else H // 2

@@ -153,6 +153,49 @@ def test_attention_legacy_order(case):
         assert relerr(got.permute(0, 2, 1), ref) < TOL
 
 
+FUSED_ATTN_CASES = [
+    # B, L, C, heads
+    (2, 64, 64, 2),       # ch 32: two channel tiles, waves 2 and 3 idle in the P v phase
+    (1, 256, 512, 2),     # config 2 at 16^2
+    (4, 64, 512, 2),      # config 2 at 8^2
+    (1, 1024, 256, 2),    # config 5 at 32^2: the largest resident score block
+    (2, 16, 32, 2),       # one key tile, ch 16
+    (1, 64, 512, 1),      # ch 512
+    (3, 48, 64, 1),       # L not a multiple of 64: ragged split of the key tiles over the waves
+]
+
+
+@pytest.mark.parametrize("case", FUSED_ATTN_CASES)
+def test_fused_attention(case):
+    """anoddpm_attention (csrc/attention.hip) against QKVAttentionLegacy's expression (UNet.py:137-153) in fp64, and against
+    the three-launch form; the optional probability output is the softmax itself."""
+    import hipops
+    B, L, C, heads = case
+    qkv = rnd(B, 3 * C, L, seed=121) * 1.5
+    ch = C // heads
+    q, k, v = qkv.double().reshape(B * heads, 3 * ch, L).split(ch, dim=1)
+    s = 1 / math.sqrt(math.sqrt(ch))
+    wgt = torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s), dim=-1)
+    ref = torch.einsum("bts,bcs->bct", wgt, v).reshape(B, C, L)
+    d = qkv.permute(0, 2, 1).contiguous().to(dev())
+    got, P = hipops.attention_fused(d, heads, want_probs=True)
+    assert relerr(P, wgt.float()) < TOL
+    assert relerr(got.permute(0, 2, 1), ref.float()) < TOL
+    assert torch.allclose(P.sum(-1).cpu(), torch.ones(B * heads, L), atol=1e-5)
+    got2, none = hipops.attention_fused(d, heads)
+    assert none is None and torch.equal(got, got2)                       # the optional output does not change the result
+    old, _ = hipops.attention(d, heads, cfg=1)
+    assert relerr(got, old) < TOL
+
+
+def test_fused_attention_rejects_unsupported_shapes():
+    import hipops
+    with pytest.raises(Exception, match="attention"):
+        hipops.attention_fused(rnd(1, 40, 3 * 32, seed=1).to(dev()), 1)       # L % 16 != 0
+    with pytest.raises(Exception, match="attention"):
+        hipops.attention_fused(rnd(1, 64, 3 * 48, seed=1).to(dev()), 1)       # head width 48
+
+
 def test_softmax_spike_rows():
     import hipops, ctypes
     from anoddpm_amd._lib import SoftmaxArgs, check, lib, current_stream
