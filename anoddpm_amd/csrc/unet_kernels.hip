@@ -530,6 +530,79 @@ __global__ __launch_bounds__(256) void conv_head_kernel(anoddpm_head_args a)
     }
 }
 
+// Input-centric form of the same layer for C % 32 == 0 (the shipped models: C = base channels): a thread owns ONE input pixel
+// of a 16x16 tile (14x14 outputs + halo), reads its C channels once (128 bytes per request, whole cache lines), applies
+// GroupNorm + SiLU once and forms the nine tap products  t[tap][o] = sum_c act[c] w[tap][c][o]  in registers -- the weights and
+// the GroupNorm affine are wave-uniform, i.e. scalar loads.  The tile's products go through LDS once ([9*COUT][256] floats) and an
+// output pixel adds its nine neighbours' entries.  Against the output-centric kernel above (every output re-reads 9 x C activations
+// and weights from LDS: LDS-bound, 112 us at 256^2 x 128 x batch 4) this one is bound by the SiLU + tap arithmetic.
+constexpr int HT = 16;                                              // input tile edge; HT - 2 outputs per edge
+
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_head_taps_kernel(anoddpm_head_args a)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    __shared__ float T[9 * COUT][HT * HT];
+    const int C = a.C;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int tiles_x = (a.W + HT - 3) / (HT - 2);
+    const int b = blockIdx.y;
+    const int oy0 = (blockIdx.x / tiles_x) * (HT - 2), ox0 = (blockIdx.x % tiles_x) * (HT - 2);
+    const int gy = oy0 + ty - 1, gx = ox0 + tx - 1;                 // this thread's input pixel
+    const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    const float *__restrict__ xp = a.x + (((int64_t)b * a.H + (inside ? gy : 0)) * a.W + (inside ? gx : 0)) * C;
+    const float *__restrict__ sc = a.gn_scale + (int64_t)b * C, *__restrict__ sh = a.gn_shift + (int64_t)b * C;
+    f2 t[9][COUT];                                                  // even / odd channel partial sums (packed FMAs)
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) t[k][o] = f2{0.f, 0.f};
+    float4 buf[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) buf[0][i] = reinterpret_cast<const float4 *>(xp)[i];
+    const int nchunk = C >> 5;
+    for (int ch = 0; ch < nchunk; ch += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int cc = ch + half;
+            if (cc >= nchunk) break;
+            const int nx = cc + 1 < nchunk ? cc + 1 : cc;           // clamped prefetch of the next 32 channels
+#pragma unroll
+            for (int i = 0; i < 8; ++i) buf[half ^ 1][i] = reinterpret_cast<const float4 *>(xp + nx * 32)[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = cc * 32 + i * 4;                      // wave-uniform: scale / shift / weights are scalar loads
+                const float4 v = buf[half][i];
+                const f2 a01 = {silu_f(v.x * sc[c] + sh[c]), silu_f(v.y * sc[c + 1] + sh[c + 1])};
+                const f2 a23 = {silu_f(v.z * sc[c + 2] + sh[c + 2]), silu_f(v.w * sc[c + 3] + sh[c + 3])};
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+#pragma unroll
+                    for (int o = 0; o < COUT; ++o) {
+                        const float *w = a.w + ((int64_t)k * C + c) * COUT + o;        // [tap][c][o]
+                        t[k][o] = __builtin_elementwise_fma(a01, f2{w[0], w[COUT]}, t[k][o]);
+                        t[k][o] = __builtin_elementwise_fma(a23, f2{w[2 * COUT], w[3 * COUT]}, t[k][o]);
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) T[k * COUT + o][tid] = inside ? t[k][o][0] + t[k][o][1] : 0.f;   // zero padding of the ACTIVATED map
+    __syncthreads();
+    const int oy = oy0 + ty - 1, ox = ox0 + tx - 1;                 // thread (ty, tx), 1 <= ty, tx <= HT - 2, also owns output (oy, ox)
+    if (ty >= 1 && ty <= HT - 2 && tx >= 1 && tx <= HT - 2 && oy < a.H && ox < a.W) {
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            float r = a.bias ? a.bias[o] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) r += T[k * COUT + o][(ty + k / 3 - 1) * HT + tx + k % 3 - 1];
+            a.out[(((int64_t)b * COUT + o) * a.H + oy) * a.W + ox] = r;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(anoddpm_layout_args a)
 {
     const int64_t total = (int64_t)a.B * a.C * a.P;
@@ -643,6 +716,18 @@ extern "C" int anoddpm_conv_head(const anoddpm_head_args *a, void *stream)
 {
     ANODDPM_REQUIRE(a && a->x && a->w && a->out && a->gn_scale && a->gn_shift, "conv_head: null pointer");
     ANODDPM_REQUIRE(a->Cout >= 1 && a->Cout <= 4 && a->C % 4 == 0 && a->W % 8 == 0 && a->H % 8 == 0, "conv_head: need Cout<=4, C%%4==0, H,W%%8==0");
+    if (a->C % 32 == 0 && anoddpm::g_debug[4] != 1) {               // ANODDPM_DEBUG4=1: the output-centric kernel
+        const int tx = (a->W + HT - 3) / (HT - 2), tyy = (a->H + HT - 3) / (HT - 2);
+        dim3 grid(tx * tyy, a->B);
+        hipStream_t s = anoddpm::as_stream(stream);
+        switch (a->Cout) {
+            case 1: hipLaunchKernelGGL(conv_head_taps_kernel<1>, grid, dim3(256), 0, s, *a); break;
+            case 2: hipLaunchKernelGGL(conv_head_taps_kernel<2>, grid, dim3(256), 0, s, *a); break;
+            case 3: hipLaunchKernelGGL(conv_head_taps_kernel<3>, grid, dim3(256), 0, s, *a); break;
+            default: hipLaunchKernelGGL(conv_head_taps_kernel<4>, grid, dim3(256), 0, s, *a); break;
+        }
+        return anoddpm::check_launch("conv_head");
+    }
     const size_t lds = (size_t)(100 * (a->C + 16) + 9 * a->C * a->Cout) * sizeof(float);
     ANODDPM_REQUIRE(lds <= 64 * 1024, "conv_head: channel count too large for the 64 KiB dynamic LDS tile");
     dim3 grid((a->H / 8) * (a->W / 8), a->B);
