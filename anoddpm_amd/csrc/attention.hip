@@ -3,13 +3,13 @@
 // in ONE launch per attention block instead of QK^T (split-K + reduce) -> softmax_rows -> AV (split-K + reduce) with the
 // [B*heads, L, L] score matrix going through HBM twice.
 //
-// Workgroup = 16 query rows of one (image, head); 4 waves.
+// Workgroup = 16 query rows of one (image, head); 8 waves.
 //   1. the 16 x ch query block is staged in LDS once;
-//   2. wave w forms the 16 x 16 score tiles of key tiles w, w+4, ... with v_mfma_f32_16x16x4_f32 (A = q from LDS, one
+//   2. wave w forms the 16 x 16 score tiles of key tiles w, w+8, ... with v_mfma_f32_16x16x4_f32 (A = q from LDS, one
 //      ds_read_b128 per four MFMAs; B = k straight from L2, 16 bytes per lane, double-buffered in registers; the k index is
 //      permuted identically on both operands) and writes them, scaled, to the LDS score block S[16][L];
-//   3. softmax over the rows of S in LDS (16 threads per row, exact: the whole row is resident, L <= 1024);
-//   4. wave w forms the output channel tiles w*ch/64 ... of  P v  (A = P from LDS, B = v from L2, double-buffered) and stores
+//   3. softmax over the rows of S in LDS (32 threads per row, exact: the whole row is resident, L <= 1024);
+//   4. wave w forms the output channel tiles w*ch/128 ... of  P v  (A = P from LDS, B = v from L2, double-buffered) and stores
 //      them to a[b][row][head*ch + c].
 // Optionally P is also written to HBM (the training plan's backward reads it).  fp32 throughout, fixed summation order.
 #include "common.h"
@@ -19,13 +19,15 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int AT_LMAX = 1024;
+constexpr int AT_WAVES = 8;                                         // 16 query rows x (image, head) is all the parallelism there is:
+constexpr int AT_NT = AT_WAVES * 64;                                // 8 waves split the key tiles / output channel tiles of a block
 
 template <int CHQ>                                                  // ch / 16
-__global__ __launch_bounds__(256) void attention_kernel(const anoddpm_attention_args a)
+__global__ __launch_bounds__(AT_NT) void attention_kernel(const anoddpm_attention_args a)
 {
     constexpr int CH = CHQ * 16;
     constexpr int QP = CH + 4;                                      // query row pitch (floats)
-    constexpr int TPW = CHQ >= 4 ? CHQ / 4 : 1;                     // output channel tiles per wave
+    constexpr int TPW = CHQ >= AT_WAVES ? CHQ / AT_WAVES : 1;       // output channel tiles per wave
     __shared__ __attribute__((aligned(16))) float lds[16 * (AT_LMAX + 4) + 16 * QP];
     const int L = a.L, SP = L + 4;
     float *S = lds, *Qs = lds + 16 * (AT_LMAX + 4);
@@ -37,12 +39,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const anoddpm_attention_
     const int nkt = L >> 4;
 
     // ---- 1. query block -> LDS ----
-    for (int idx = tid; idx < 16 * (CH / 4); idx += 256) {
+    for (int idx = tid; idx < 16 * (CH / 4); idx += AT_NT) {
         const int r = idx / (CH / 4), c4 = idx - r * (CH / 4);
         *reinterpret_cast<f32x4 *>(Qs + r * QP + c4 * 4) = *reinterpret_cast<const f32x4 *>(qkv + (int64_t)(row0 + r) * C3 + c4 * 4);
     }
     // ---- 2. scores ----
-    f32x4 kb[2][CHQ];
+    constexpr bool DB = CHQ < 32;                                   // ch = 512: two key buffers would not fit the 256-VGPR budget
+    f32x4 kb[DB ? 2 : 1][CHQ];
     auto load_k = [&](f32x4 (&dst)[CHQ], int jt) {
         const float *kp = qkv + (int64_t)(jt * 16 + l16) * C3 + CH + kq * 4;
 #pragma unroll
@@ -61,12 +64,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const anoddpm_attention_
     };
     if (wave < nkt) load_k(kb[0], wave);
     __syncthreads();                                                // Q staged
-    for (int jt = wave; jt < nkt; jt += 8) {
-        if (jt + 4 < nkt) load_k(kb[1], jt + 4);
-        score_tile(kb[0], jt);
-        if (jt + 4 < nkt) {
-            if (jt + 8 < nkt) load_k(kb[0], jt + 8);
-            score_tile(kb[1], jt + 4);
+    if constexpr (DB) {
+        for (int jt = wave; jt < nkt; jt += 2 * AT_WAVES) {
+            if (jt + AT_WAVES < nkt) load_k(kb[1], jt + AT_WAVES);
+            score_tile(kb[0], jt);
+            if (jt + AT_WAVES < nkt) {
+                if (jt + 2 * AT_WAVES < nkt) load_k(kb[0], jt + 2 * AT_WAVES);
+                score_tile(kb[1], jt + AT_WAVES);
+            }
+        }
+    } else {
+        for (int jt = wave; jt < nkt; jt += AT_WAVES) {
+            if (jt != wave) load_k(kb[0], jt);
+            score_tile(kb[0], jt);
         }
     }
     // first v operands go out before the softmax so that their latency hides behind it
@@ -83,25 +93,26 @@ __global__ __launch_bounds__(256) void attention_kernel(const anoddpm_attention_
     if (pv_active) load_v(vb[0], 0);
     __syncthreads();                                                // S complete
 
-    // ---- 3. softmax over the 16 rows: 16 threads per row ----
+    // ---- 3. softmax over the 16 rows: 32 threads per row ----
     {
-        const int r = tid >> 4, sub = tid & 15;
+        constexpr int TPR = AT_NT / 16;                             // threads per row (32)
+        const int r = tid / TPR, sub = tid % TPR;
         float *srow = S + r * SP;
         float m = -INFINITY;
-        for (int j = sub; j < L; j += 16) m = fmaxf(m, srow[j]);
+        for (int j = sub; j < L; j += TPR) m = fmaxf(m, srow[j]);
 #pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+        for (int o = TPR / 2; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, TPR));
         float sum = 0.f;
-        for (int j = sub; j < L; j += 16) {
+        for (int j = sub; j < L; j += TPR) {
             const float e = __expf(srow[j] - m);
             srow[j] = e;
             sum += e;
         }
 #pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 16);
+        for (int o = TPR / 2; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, TPR);
         const float inv = 1.0f / sum;
         float *prow = a.probs ? a.probs + (((int64_t)b * a.heads + hd) * L + row0 + r) * L : nullptr;
-        for (int j = sub; j < L; j += 16) {
+        for (int j = sub; j < L; j += TPR) {
             const float p = srow[j] * inv;
             srow[j] = p;
             if (prow) prow[j] = p;
@@ -148,12 +159,12 @@ extern "C" int anoddpm_attention(const anoddpm_attention_args *a, void *stream)
     const dim3 grid((unsigned)(a->L / 16), (unsigned)a->heads, (unsigned)a->B);
     hipStream_t s = anoddpm::as_stream(stream);
     switch (a->ch / 16) {
-        case 1: hipLaunchKernelGGL((attention_kernel<1>), grid, dim3(256), 0, s, *a); break;
-        case 2: hipLaunchKernelGGL((attention_kernel<2>), grid, dim3(256), 0, s, *a); break;
-        case 4: hipLaunchKernelGGL((attention_kernel<4>), grid, dim3(256), 0, s, *a); break;
-        case 8: hipLaunchKernelGGL((attention_kernel<8>), grid, dim3(256), 0, s, *a); break;
-        case 16: hipLaunchKernelGGL((attention_kernel<16>), grid, dim3(256), 0, s, *a); break;
-        default: hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(256), 0, s, *a); break;
+        case 1: hipLaunchKernelGGL((attention_kernel<1>), grid, dim3(AT_NT), 0, s, *a); break;
+        case 2: hipLaunchKernelGGL((attention_kernel<2>), grid, dim3(AT_NT), 0, s, *a); break;
+        case 4: hipLaunchKernelGGL((attention_kernel<4>), grid, dim3(AT_NT), 0, s, *a); break;
+        case 8: hipLaunchKernelGGL((attention_kernel<8>), grid, dim3(AT_NT), 0, s, *a); break;
+        case 16: hipLaunchKernelGGL((attention_kernel<16>), grid, dim3(AT_NT), 0, s, *a); break;
+        default: hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(AT_NT), 0, s, *a); break;
     }
     return anoddpm::check_launch("attention");
 }
