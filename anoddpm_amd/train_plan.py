@@ -61,6 +61,8 @@ class TrainPlan(_Plan):
         self._bw = []                # closures emitting the backward of each forward stage (run in reverse)
         self._grads = {}             # data_ptr of an activation -> its gradient buffer
         self.gwritten = set()
+        self._touched = set()
+        self.bwd_marks = []          # (backward op count after a stage, parameter names whose gradient that stage wrote)
         self._ws_patch = []          # (struct, field, floats) sharing one training workspace
         self._tws_need = 0
         super().__init__(model, B, S, device)
@@ -107,6 +109,7 @@ class TrainPlan(_Plan):
         return self.pptr[key]
 
     def dW(self, key):
+        self._touched.add(key)                # backward stage that (last) writes this parameter's gradient: see bwd_marks
         return self.gptr[key]
 
     def pack(self, key, kind, bwd=0, k0=0, kc=0):
@@ -589,7 +592,9 @@ class TrainPlan(_Plan):
 
         # --- backward list: the stages in reverse
         for fn in reversed(self._bw):
+            self._touched = set()
             fn()
+            self.bwd_marks.append((len(self.bops), sorted(self._touched)))
         # split-K workspace of the inference emitters (forward and backward igemm launches) + the training workspace
         if self._ws_need:
             ws = self.buf(self._ws_need)
@@ -620,10 +625,51 @@ class TrainPlan(_Plan):
                     self.gview[k].zero_()
         self.dy.copy_(dy.reshape(self.dy.shape))
         self.stem_bwd_args.x = x.data_ptr()
-        check(lib().anoddpm_run_ops(self.bwd_array, len(self.bops), _lib.current_stream()), "UNet training backward")
+        red = getattr(self.model, "_grad_reducer", None)
+        red = red() if red is not None else None
+        if red is not None and red.hooks and not fresh:
+            # data parallel: the op list is cut where a gradient bucket becomes final, and the bucket's all-reduce is enqueued
+            # right there -- RCCL's stream picks it up behind the ops already launched and runs beside the rest of the backward
+            lo = 0
+            for hi, buckets in self.reduce_schedule(red):
+                if hi > lo:
+                    check(lib().anoddpm_run_ops(self._bwd_slice(lo), hi - lo, _lib.current_stream()),
+                          "UNet training backward")
+                for b in buckets:
+                    red.launch_bucket(b, ops_done=hi)
+                lo = hi
+            if lo < len(self.bops):
+                check(lib().anoddpm_run_ops(self._bwd_slice(lo), len(self.bops) - lo,
+                                            _lib.current_stream()), "UNet training backward")
+        else:
+            check(lib().anoddpm_run_ops(self.bwd_array, len(self.bops), _lib.current_stream()), "UNet training backward")
         for k in fresh:
             self.named[k].grad = self.gview[k]
         return self.dx
+
+    def _bwd_slice(self, lo):
+        return ctypes.cast(ctypes.addressof(self.bwd_array) + lo * ctypes.sizeof(Op), ctypes.POINTER(Op))
+
+    def reduce_schedule(self, red):
+        """[(backward op count, [bucket ids])]: after that many ops every gradient of those buckets of `red`
+        (training.GradAllReducer) is final.  A parameter's gradient is final after the LAST backward stage that wrote it
+        (bwd_marks); parameters no stage writes (unused) are final from the start."""
+        key = id(red)
+        hit = getattr(self, "_sched", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        final = {}
+        for end, keys in self.bwd_marks:
+            for k in keys:
+                final[k] = end
+        names = red.flat.names
+        at = {}
+        for b, (_, _, members) in enumerate(red.buckets):
+            end = max([final.get(names[i], 0) for i in members] + [0])
+            at.setdefault(end, []).append(b)
+        sched = sorted(at.items())
+        self._sched = (key, sched)
+        return sched
 
 
 class TrainPlanFunction(torch.autograd.Function):

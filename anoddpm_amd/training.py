@@ -103,6 +103,11 @@ class GradAllReducer:
         self.works = []
         self.hooks = []
         self.launched = 0            # buckets reduced by the last finish() (tests)
+        self.launch_log = []         # (bucket, backward ops already enqueued or None) of the step in flight
+        self.last_launch_log = []    # ... of the last finished step (tests)
+        if getattr(flat, "module", None) is not None:
+            import weakref
+            flat.module._grad_reducer = weakref.ref(self)     # the native training plan cuts its backward at our buckets
         # hooks whenever a process group exists (also at world size 1: the same RCCL path runs, each all-reduce is then
         # a device-side no-op) -- without torch.distributed the reducer is inert
         if dist.is_initialized():
@@ -122,6 +127,13 @@ class GradAllReducer:
                 self._launch(b)
         return hook
 
+    def launch_bucket(self, b, ops_done=None):
+        """Called by the native training plan (train_plan.TrainPlan.run_backward) once every gradient of bucket `b` is final."""
+        if self.pending[b] > 0:
+            self.pending[b] = 0
+            self.launch_log.append((b, ops_done))
+            self._launch(b)
+
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         view = self.flat.flat_grad[lo:hi]
@@ -134,10 +146,12 @@ class GradAllReducer:
         for b, left in enumerate(self.pending):
             if left > 0:                       # parameter unused this step: its grad is zero, still reduce
                 self.pending[b] = 0
+                self.launch_log.append((b, None))
                 self._launch(b)
         for work, view in self.works:
             work.wait()
         self.launched = len(self.works)
+        self.last_launch_log, self.launch_log = self.launch_log, []
         if self.world > 1:
             self.flat.flat_grad.mul_(1.0 / self.world)
         self.reset()

@@ -236,6 +236,8 @@ class UNetModel(nn.Module):
         for k, v in self.__dict__.items():
             if k in ("_plans", "_tplans"):
                 new.__dict__[k] = {}
+            elif k == "_grad_reducer":             # weak reference to the ORIGINAL's data-parallel reducer: not inherited
+                continue
             else:
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new
@@ -244,6 +246,7 @@ class UNetModel(nn.Module):
         d = dict(self.__dict__)
         d["_plans"] = {}
         d["_tplans"] = {}
+        d.pop("_grad_reducer", None)
         return d
 
     # ------------------------------------------------------------------ forward

@@ -259,6 +259,14 @@ def test_rccl_world_size_1_reducer_with_native_backward():
             loss, _ = train_step(model, diff, x, {"train_start": False}, flat, red, opt)
             if red is not None:
                 assert red.launched == len(red.buckets) and all(p == len(m) for p, (_, _, m) in zip(red.pending, red.buckets))
+                # the native backward is cut at the bucket boundaries: buckets go out while later ops are still to be
+                # enqueued (overlap), in backward order, and none is left for finish() to launch
+                log = red.last_launch_log
+                assert sorted(b for b, _ in log) == list(range(len(red.buckets)))
+                done = [d for _, d in log]
+                assert all(d is not None for d in done) and done == sorted(done)
+                plan = next(iter(model._tplans.values()))
+                assert done[0] < len(plan.bops) // 2 and len(set(done)) > 3
             results.append((loss.item(), flat.flat_param.clone(), flat.flat_grad.clone()))
         assert results[0][0] == results[1][0]
         assert torch.equal(results[0][2], results[1][2]) and torch.equal(results[0][1], results[1][1])
