@@ -276,6 +276,8 @@ __global__ __launch_bounds__(256) void resample2x_kernel(anoddpm_resample_args a
         float4 o;
         if (a.mode == 1) {
             o = in[((int64_t)(yo >> 1) * a.W + (xo >> 1)) * C4];
+        } else if (a.mode == 3) {                                  // stride-2 pick: the even pixels of a stride-1 result
+            o = in[((int64_t)(2 * yo) * a.W + 2 * xo) * C4];
         } else {
             const float4 v00 = in[((int64_t)(2 * yo) * a.W + 2 * xo) * C4];
             const float4 v01 = in[((int64_t)(2 * yo) * a.W + 2 * xo + 1) * C4];
@@ -665,7 +667,7 @@ extern "C" int anoddpm_softmax_rows(const anoddpm_softmax_args *a, void *stream)
 extern "C" int anoddpm_resample2x(const anoddpm_resample_args *a, void *stream)
 {
     ANODDPM_REQUIRE(a && a->in && a->out, "resample2x: null pointer");
-    ANODDPM_REQUIRE(a->C % 4 == 0 && (a->mode == 1 || (a->mode == 2 && a->H % 2 == 0 && a->W % 2 == 0)), "resample2x: bad shape/mode");
+    ANODDPM_REQUIRE(a->C % 4 == 0 && (a->mode == 1 || ((a->mode == 2 || a->mode == 3) && a->H % 2 == 0 && a->W % 2 == 0)), "resample2x: bad shape/mode");
     ANODDPM_REQUIRE(!a->out_act || (a->mode == 2 && a->gn_scale && a->gn_shift), "resample2x: the activated output needs mode 2 and a GroupNorm affine");
     const int Ho = a->mode == 1 ? a->H * 2 : a->H / 2, Wo = a->mode == 1 ? a->W * 2 : a->W / 2;
     const int64_t total = (int64_t)a->B * Ho * Wo * (a->C / 4);

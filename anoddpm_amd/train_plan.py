@@ -40,7 +40,8 @@ def eligible(model, B, S):
     autograd expression of unet.UNetModel._forward_autograd."""
     cfin, nout = model._final_cin, model.in_channels
     head_ok = nout <= 4 and S % 8 == 0 and (100 * (cfin + 16) + 9 * cfin * nout) * 4 <= 64 * 1024 and cfin <= 256
-    return head_ok and 1 <= B <= 16 and model.model_channels % 4 == 0 and model.model_channels <= 256
+    return (head_ok and 1 <= B <= 16 and model.model_channels % 4 == 0 and model.model_channels <= 256
+            and getattr(model, "biggan_updown", True))      # Downsample / Upsample layers: generic autograd expression
 
 
 def _op_array(ops):

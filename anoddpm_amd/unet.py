@@ -115,8 +115,10 @@ def update_ema_params(target, source, decay_rate=0.9999):
 
 
 # ----------------------------------------------------------------------------- topology
-def _topology(img_size, base, mults, num_res_blocks, attention_resolutions, in_channels):
-    """Block list of UNet.py:278-388: entries (prefix, kind, cin, cout, resample)."""
+def _topology(img_size, base, mults, num_res_blocks, attention_resolutions, in_channels, biggan_updown=True, conv_resample=True):
+    """Block list of UNet.py:278-388: entries (prefix, kind, cin, cout, resample).  With biggan_updown=False the level
+    transitions are Downsample / Upsample layers (UNet.py:60-92; kind "downsample" / "upsample", resample = "conv" when
+    conv_resample) instead of resampling ResBlocks."""
     attn_ds = [img_size // int(r) for r in attention_resolutions.split(",")]
     ch = int(mults[0] * base)
     down = [[("down.0.0", "stem", in_channels, base, None)]]
@@ -133,7 +135,10 @@ def _topology(img_size, base, mults, num_res_blocks, attention_resolutions, in_c
             down.append(blk)
             skip_ch.append(ch)
         if level != len(mults) - 1:
-            down.append([(f"down.{len(down)}.0", "res", ch, ch, "down")])
+            if biggan_updown:
+                down.append([(f"down.{len(down)}.0", "res", ch, ch, "down")])
+            else:
+                down.append([(f"down.{len(down)}.0", "downsample", ch, ch, "conv" if conv_resample else None)])
             ds *= 2
             skip_ch.append(ch)
     middle = [("middle.0", "res", ch, ch, None), ("middle.1", "attn", ch, ch, None),
@@ -151,7 +156,10 @@ def _topology(img_size, base, mults, num_res_blocks, attention_resolutions, in_c
                 blk.append((f"up.{n}.{m}", "attn", ch, ch, None))
                 m += 1
             if level and j == num_res_blocks:
-                blk.append((f"up.{n}.{m}", "res", ch, ch, "up"))
+                if biggan_updown:
+                    blk.append((f"up.{n}.{m}", "res", ch, ch, "up"))
+                else:
+                    blk.append((f"up.{n}.{m}", "upsample", ch, ch, "conv" if conv_resample else None))
                 ds //= 2
             up.append(blk)
     return down, middle, up, ch
@@ -167,8 +175,7 @@ class UNetModel(nn.Module):
             if img_size not in _DEFAULT_MULTS:
                 raise ValueError(f"unsupported image size: {img_size}")
             channel_mults = _DEFAULT_MULTS[img_size]
-        if not biggan_updown:
-            raise NotImplementedError("only the reference default biggan_updown=True is built (UNet.py:318,377)")
+        self.biggan_updown = bool(biggan_updown)
         self.image_size = img_size
         self.in_channels = in_channels
         self.model_channels = base_channels
@@ -184,7 +191,7 @@ class UNetModel(nn.Module):
         ted = base_channels * 4
         self._ted = ted
         down, middle, up, out_ch = _topology(img_size, base_channels, channel_mults, num_res_blocks,
-                                             attention_resolutions, in_channels)
+                                             attention_resolutions, in_channels, self.biggan_updown, conv_resample)
         self._blocks = (down, middle, up)
         self._final_cin = int(base_channels * channel_mults[0])
         assert out_ch == self._final_cin or True
@@ -199,6 +206,10 @@ class UNetModel(nn.Module):
                 return _Weights((cout, cin, 3, 3))
             if kind == "res":
                 return _ResBlockParams(cin, ted, cout)
+            if kind == "downsample":                   # Downsample(ch, conv_resample): keys `.downsample.weight/.bias` or none
+                return _indexed(downsample=_Weights((cout, cin, 3, 3))) if blk[4] == "conv" else nn.Module()
+            if kind == "upsample":                     # Upsample(ch, conv_resample): keys `.conv.weight/.bias` or none
+                return _indexed(conv=_Weights((cout, cin, 3, 3))) if blk[4] == "conv" else nn.Module()
             heads = n_heads if n_head_channels == -1 else None
             if heads is None:
                 assert cin % n_head_channels == 0, \
@@ -382,6 +393,13 @@ class UNetModel(nn.Module):
                     h = F.conv2d(h, P(p + ".weight"), P(p + ".bias"), padding=1)
                 elif kind == "res":
                     h = res(p, h, resample)
+                elif kind == "downsample":             # UNet.py:60-75
+                    h = (F.conv2d(h, P(p + ".downsample.weight"), P(p + ".downsample.bias"), stride=2, padding=1)
+                         if resample == "conv" else F.avg_pool2d(h, 2, 2))
+                elif kind == "upsample":               # UNet.py:77-92
+                    h = F.interpolate(h, scale_factor=2, mode="nearest")
+                    if resample == "conv":
+                        h = F.conv2d(h, P(p + ".conv.weight"), P(p + ".conv.bias"), padding=1)
                 else:
                     h = attn(p, h)
             return h
@@ -867,6 +885,42 @@ class _Plan:
                        res=x, out=y, want_stats=True)
             return y
 
+        def resample_layer(prefix, kind, x, Hc, C, conv):
+            """Downsample / Upsample of the biggan_updown=False topology (UNet.py:60-92) on raw activations (no norm, no
+            activation).  The stride-2 convolution runs as the stride-1 one on the existing kernels followed by the even-pixel
+            pick (its outputs are exactly those of the stride-1 result at (2i, 2j)): 4x the necessary work on a layer no
+            shipped configuration uses, zero new contraction code."""
+            def rs(inp, H, mode, out):
+                st = ResampleArgs()
+                st.inp, st.out = inp.data_ptr(), out.data_ptr()
+                st.B, st.H, st.W, st.C, st.mode, st.scale, st.accumulate = B, H, H, C, mode, 1.0, 0
+                self.add(_lib.OP_RESAMPLE, st)
+            if kind == "downsample":
+                Ho = Hc // 2
+                out = self.buf(B, Ho * Ho, C)
+                if not conv:
+                    rs(x, Hc, 2, out)                                   # nn.AvgPool2d(2, 2)
+                    return out, Ho
+                full = self.buf(B, Hc * Hc, C)
+                self.igemm(srcs=[(x, C)], H=Hc, W=Hc, ks=3, N=C, act=0,
+                           bmat=lambda p=prefix: self.packed(p + ".downsample.weight", _pack_conv),
+                           wino=lambda p=prefix: self.packed(p + ".downsample.weight", _pack_wino),
+                           wino43=lambda p=prefix: self.packed(p + ".downsample.weight", _pack_wino43),
+                           bias=self.packed(prefix + ".downsample.bias", lambda t: t.detach().float()), out=full)
+                rs(full, Hc, 3, out)
+                return out, Ho
+            Ho = Hc * 2
+            out = self.buf(B, Ho * Ho, C)
+            if not conv:
+                rs(x, Hc, 1, out)                                       # F.interpolate(scale_factor=2, mode="nearest")
+                return out, Ho
+            self.igemm(srcs=[(x, C)], H=Ho, W=Ho, ks=3, N=C, act=0, a_mode=1,      # nearest x2 fused into the operand load
+                       bmat=lambda p=prefix: self.packed(p + ".conv.weight", _pack_conv),
+                       wino=lambda p=prefix: self.packed(p + ".conv.weight", _pack_wino),
+                       wino43=lambda p=prefix: self.packed(p + ".conv.weight", _pack_wino43),
+                       bias=self.packed(prefix + ".conv.bias", lambda t: t.detach().float()), out=out, want_stats=True)
+            return out, Ho
+
         def run(blks, srcs, Hc):
             for (prefix, kind, cin, cout, resample) in blks:
                 if kind == "stem":
@@ -883,6 +937,9 @@ class _Plan:
                 elif kind == "res":
                     h, Hc = res_block(prefix, srcs, Hc, cout, resample)
                     srcs = [(h, cout)]
+                elif kind in ("downsample", "upsample"):
+                    h, Hc = resample_layer(prefix, kind, srcs[0][0], Hc, cin, resample == "conv")
+                    srcs = [(h, cin)]
                 else:
                     h = attn_block(prefix, srcs[0][0], Hc, cin)
                     srcs = [(h, cin)]

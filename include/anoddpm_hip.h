@@ -281,7 +281,8 @@ typedef struct {
 int anoddpm_attention(const anoddpm_attention_args *a, void *stream);
 
 /* 2x resampling of an NHWC tensor (the x_upd path of ResBlock, UNet.py:177-181,207):
- * mode 1: nearest x2 up (in H x W -> out 2H x 2W); mode 2: 2x2 average pool (in -> H/2 x W/2).
+ * mode 1: nearest x2 up (in H x W -> out 2H x 2W); mode 2: 2x2 average pool (in -> H/2 x W/2); mode 3: the even pixels
+ * (2i, 2j) -> H/2 x W/2, i.e. a stride-2 convolution's outputs picked from the stride-1 result (Downsample, UNet.py:60-75).
  * scale (0 is read as 1) multiplies the result and accumulate != 0 adds it to `out`: the backward of one mode is the
  * other one scaled -- d(avg pool) = nearest-up * 0.25, d(nearest-up) = avg pool * 4 (the sum of the four children). */
 typedef struct {

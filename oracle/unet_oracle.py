@@ -13,6 +13,7 @@ Restated pieces (reference file:line):
   layout()                 UNet.py:239-254, 278-388  (constructor: which blocks exist)
   timestep_features()      UNet.py:50-57             (PositionalEmbedding)
   res_block()              UNet.py:202-217 with :169-200 (ResBlock, BigGAN up/down variant)
+  resample_layer()         UNet.py:60-92             (Downsample / Upsample of biggan_updown=False)
   attention_block()        UNet.py:119-125, 137-153  (AttentionBlock + legacy QKVAttention)
   forward()                UNet.py:390-406
   fill_deterministic()     SURVEY.md 8c/8d recipe: RandomState(crc32(key)) parameter fill
@@ -29,10 +30,11 @@ DEFAULT_MULTS = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1,
 
 
 def layout(img_size, base_channels, channel_mults="", num_res_blocks=2,
-           attention_resolutions="32,16,8", in_channels=1):
+           attention_resolutions="32,16,8", in_channels=1, biggan_updown=True, conv_resample=True):
     """Block list of the network as (prefix, kind, cin, cout, resample) tuples.
 
-    kind: 'stem' | 'res' | 'attn' ; resample: None | 'down' | 'up'.
+    kind: 'stem' | 'res' | 'attn' | 'downsample' | 'upsample' (the last two: biggan_updown=False, UNet.py:318-320,
+    377-379); resample: None | 'down' | 'up' for ResBlocks, 'conv' | None for Downsample / Upsample (conv_resample).
     Returns dict(down=[[...],...], middle=[...], up=[[...],...], out_ch=int).
     """
     if channel_mults == "":
@@ -56,7 +58,10 @@ def layout(img_size, base_channels, channel_mults="", num_res_blocks=2,
             skip_ch.append(ch)
         if level != len(channel_mults) - 1:
             n = len(down)
-            down.append([(f"down.{n}.0", "res", ch, ch, "down")])
+            if biggan_updown:
+                down.append([(f"down.{n}.0", "res", ch, ch, "down")])
+            else:
+                down.append([(f"down.{n}.0", "downsample", ch, ch, "conv" if conv_resample else None)])
             ds *= 2
             skip_ch.append(ch)
     middle = [("middle.0", "res", ch, ch, None), ("middle.1", "attn", ch, ch, None),
@@ -74,7 +79,10 @@ def layout(img_size, base_channels, channel_mults="", num_res_blocks=2,
                 blk.append((f"up.{n}.{m}", "attn", ch, ch, None))
                 m += 1
             if level and j == num_res_blocks:
-                blk.append((f"up.{n}.{m}", "res", ch, ch, "up"))
+                if biggan_updown:
+                    blk.append((f"up.{n}.{m}", "res", ch, ch, "up"))
+                else:
+                    blk.append((f"up.{n}.{m}", "upsample", ch, ch, "conv" if conv_resample else None))
                 ds //= 2
             up.append(blk)
     return dict(down=down, middle=middle, up=up, out_ch=ch,
@@ -82,10 +90,10 @@ def layout(img_size, base_channels, channel_mults="", num_res_blocks=2,
 
 
 def param_shapes(img_size, base_channels, channel_mults="", num_res_blocks=2,
-                 attention_resolutions="32,16,8", in_channels=1):
+                 attention_resolutions="32,16,8", in_channels=1, biggan_updown=True, conv_resample=True):
     """Ordered {key: shape} of every parameter of the reference module for this config."""
     lay = layout(img_size, base_channels, channel_mults, num_res_blocks, attention_resolutions,
-                 in_channels)
+                 in_channels, biggan_updown, conv_resample)
     ted = base_channels * 4
     shapes = {}
 
@@ -113,6 +121,12 @@ def param_shapes(img_size, base_channels, channel_mults="", num_res_blocks=2,
             conv(p + ".out_layers.3", cout, cout, 3)
             if cin != cout:
                 conv(p + ".skip_connection", cout, cin, 1)
+        elif kind == "downsample":
+            if b[4] == "conv":
+                conv(p + ".downsample", cout, cin, 3)
+        elif kind == "upsample":
+            if b[4] == "conv":
+                conv(p + ".conv", cout, cin, 3)
         else:
             gn(p + ".norm", cin)
             shapes[p + ".to_qkv.weight"] = (3 * cin, cin, 1)
@@ -200,15 +214,27 @@ def attention_block(sd, p, x, n_heads, n_head_channels):
     return (xf + a).reshape(b, c, hh, ww)
 
 
+def resample_layer(sd, p, kind, conv, x):
+    """Downsample / Upsample (UNet.py:60-92): stride-2 3x3 conv or 2x2 average pool; nearest x2 (+ 3x3 conv)."""
+    if kind == "downsample":
+        if conv:
+            return F.conv2d(x, sd[p + ".downsample.weight"], sd[p + ".downsample.bias"], stride=2, padding=1)
+        return F.avg_pool2d(x, 2, 2)
+    x = F.interpolate(x, scale_factor=2, mode="nearest")
+    if conv:
+        x = F.conv2d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], padding=1)
+    return x
+
+
 def forward_autograd(sd, x, t, img_size, base_channels, channel_mults="", num_res_blocks=2,
                      attention_resolutions="32,16,8", in_channels=1, n_heads=1, n_head_channels=-1,
-                     record=None):
+                     record=None, biggan_updown=True, conv_resample=True):
     """Returns the model output; if `record` is a dict it receives per-block activations
     keyed by block prefix (NCHW fp32) for layer-wise parity checks.  Autograd is left on: with
     `requires_grad` leaves in `sd` this is the CPU checker for the training gradients
     (diffusion_training.py:102, pinned by tests/golden/train_*.npz)."""
     lay = layout(img_size, base_channels, channel_mults, num_res_blocks, attention_resolutions,
-                 in_channels)
+                 in_channels, biggan_updown, conv_resample)
     temb = timestep_features(t, base_channels)
     temb = F.linear(temb, sd["time_embedding.1.weight"], sd["time_embedding.1.bias"])
     temb = F.linear(F.silu(temb), sd["time_embedding.3.weight"], sd["time_embedding.3.bias"])
@@ -221,6 +247,8 @@ def forward_autograd(sd, x, t, img_size, base_channels, channel_mults="", num_re
                 h = F.conv2d(h, sd[p + ".weight"], sd[p + ".bias"], padding=1)
             elif kind == "res":
                 h = res_block(sd, p, h, temb, resample)
+            elif kind in ("downsample", "upsample"):
+                h = resample_layer(sd, p, kind, resample == "conv", h)
             else:
                 h = attention_block(sd, p, h, n_heads, n_head_channels)
             if record is not None:
@@ -256,11 +284,12 @@ def perturb(sd, scale=0.02, salt="train"):
 
 
 def flops_per_image(img_size, base_channels, channel_mults="", num_res_blocks=2,
-                    attention_resolutions="32,16,8", in_channels=1, n_heads=1, n_head_channels=-1):
+                    attention_resolutions="32,16,8", in_channels=1, n_heads=1, n_head_channels=-1,
+                    biggan_updown=True, conv_resample=True):
     """Algorithmic FLOPs of one forward for one image by the SURVEY 8d counting rule:
     2*Cin*Cout*k^2*Hout*Wout per conv, 2*in*out per linear, 4*C*L^2 per attention."""
     lay = layout(img_size, base_channels, channel_mults, num_res_blocks, attention_resolutions,
-                 in_channels)
+                 in_channels, biggan_updown, conv_resample)
     tot = dict(conv3=0.0, conv1=0.0, qkvproj=0.0, attn=0.0, linear=0.0)
     ted = 4 * base_channels
     tot["linear"] += 2 * base_channels * ted + 2 * ted * ted
@@ -280,6 +309,10 @@ def flops_per_image(img_size, base_channels, channel_mults="", num_res_blocks=2,
             tot["linear"] += 2 * ted * cout
             if cin != cout:
                 tot["conv1"] += 2 * cin * cout * res * res
+        elif kind in ("downsample", "upsample"):
+            res = res // 2 if kind == "downsample" else res * 2
+            if rs == "conv":
+                tot["conv3"] += 2 * cin * cout * 9 * res * res
         else:
             L = res * res
             tot["qkvproj"] += 2 * cin * 3 * cin * L + 2 * cin * cin * L

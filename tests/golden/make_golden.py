@@ -180,6 +180,10 @@ UNET_CASES = {
     # (sequence lengths 1024 / 256 / 64 as in the 512^2 model)
     "c5like_i128_b32": (dict(img_size=128, base_channels=32, n_heads=2, channel_mults=(1, 1, 2, 2, 4, 4),
                              attention_resolutions="32,16,8"), 2, [7, 640]),
+    # biggan_updown=False: Downsample / Upsample layers between the levels (UNet.py:60-92) with and without the convolutions
+    "convrs_i64_b32": (dict(img_size=64, base_channels=32, n_heads=2, attention_resolutions="16,8", biggan_updown=False,
+                            conv_resample=True), 2, [11, 870]),
+    "poolrs_i32_b32": (dict(img_size=32, base_channels=32, biggan_updown=False, conv_resample=False), 1, [333]),
 }
 
 
@@ -189,7 +193,8 @@ def run_unet_case(name, kw, batch, ts, probes=True):
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     oshapes = unet_oracle.param_shapes(
         kw["img_size"], kw["base_channels"], kw.get("channel_mults", ""), 2,
-        kw.get("attention_resolutions", "32,16,8"), kw.get("in_channels", 1))
+        kw.get("attention_resolutions", "32,16,8"), kw.get("in_channels", 1), kw.get("biggan_updown", True),
+        kw.get("conv_resample", True))
     assert list(shapes.items()) == list(oshapes.items()), "state-dict layout mismatch vs oracle.param_shapes"
     sd = unet_oracle.fill_deterministic(shapes)
     model.load_state_dict(sd)

@@ -227,6 +227,40 @@ def test_native_backward_matches_torch_autograd(kw, B, monkeypatch):
     assert worst[0] < 1e-3, worst
 
 
+@pytest.mark.parametrize("conv", [True, False])
+def test_conv_resample_variant_gradients_match_cpu_oracle(conv):
+    """biggan_updown=False (Downsample / Upsample layers, UNet.py:60-92): not a training-plan shape, so the step runs the
+    per-operator autograd expression (fused 3x3 blocks native, the resampling layers on PyTorch-ROCm).  Output, loss and every
+    gradient against the CPU oracle's autograd on the same weights."""
+    from UNet import UNetModel
+    from oracle import unet_oracle as uo
+    from anoddpm_amd import train_plan
+    kw = dict(img_size=32, base_channels=32, n_heads=2, attention_resolutions="16,8", biggan_updown=False, conv_resample=conv)
+    m = UNetModel(**kw)
+    assert not train_plan.eligible(m, 2, 32)
+    assert any(".downsample." in k for k in m.state_dict()) == conv and any(k.endswith(".conv.weight") for k in m.state_dict()) == conv
+    sd = uo.perturb(uo.fill_deterministic({k: tuple(v.shape) for k, v in m.state_dict().items()}))
+    m.load_state_dict(sd)
+    m.to(DEV).train()
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 1, 32, 32, generator=g) * 2 - 1
+    tgt = torch.randn(2, 1, 32, 32, generator=g)
+    t = torch.tensor([40, 911])
+    y = m(x.to(DEV), t.to(DEV))
+    loss = ((y - tgt.to(DEV)) ** 2).mean()
+    loss.backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    y_ref = uo.forward_autograd(leaves, x, t, **kw)
+    l_ref = ((y_ref - tgt) ** 2).mean()
+    l_ref.backward()
+    assert ((y.detach().cpu() - y_ref.detach()).abs().max() / y_ref.detach().abs().max()).item() < 1e-4
+    assert abs(loss.item() - l_ref.item()) < 1e-4 * abs(l_ref.item())
+    gmax = max(v.grad.abs().max().item() for v in leaves.values())
+    worst = max((((p.grad.cpu() - leaves[k].grad).abs().max() / max(leaves[k].grad.abs().max().item(), 1e-4 * gmax)).item(), k)
+                for k, p in m.named_parameters())
+    assert worst[0] < 1e-3, worst
+
+
 def test_rccl_world_size_1_reducer_with_native_backward():
     """The data-parallel machinery on the real backend: `nccl` (= RCCL) process group of one rank, GradAllReducer on a
     UNetModel whose backward runs the hand-written kernels (custom autograd Functions + post-accumulate hooks + flat

@@ -23,6 +23,10 @@ CASES = {
     "c5like_i128_b32": dict(img_size=128, base_channels=32, n_heads=2, channel_mults=(1, 1, 2, 2, 4, 4),
                             attention_resolutions="32,16,8"),
     "c2_256_b128": dict(img_size=256, base_channels=128, n_heads=2, attention_resolutions="16,8"),
+    # biggan_updown=False: Downsample / Upsample layers (UNet.py:60-92), with and without their convolutions
+    "convrs_i64_b32": dict(img_size=64, base_channels=32, n_heads=2, attention_resolutions="16,8", biggan_updown=False,
+                           conv_resample=True),
+    "poolrs_i32_b32": dict(img_size=32, base_channels=32, biggan_updown=False, conv_resample=False),
     # BASELINE config 5: 512^2, explicit mults (1,1,2,2,4,4), attention at 32/16/8 (sequence lengths 256 / 1024 / 4096)
     "c5_512_b128": dict(img_size=512, base_channels=128, n_heads=2, channel_mults=(1, 1, 2, 2, 4, 4),
                         attention_resolutions="32,16,8"),
@@ -58,7 +62,7 @@ def test_forward_matches_reference_output(name):
     assert torch.equal(y, y2) and y2.data_ptr() != y.data_ptr()
 
 
-@pytest.mark.parametrize("name", ["i64_b32_hc32", "c5like_i128_b32", "c2_256_b128", "c5_512_b128"])
+@pytest.mark.parametrize("name", ["i64_b32_hc32", "c5like_i128_b32", "c2_256_b128", "c5_512_b128", "convrs_i64_b32", "poolrs_i32_b32"])
 def test_layerwise_against_reference_probes(name):
     """Every per-block activation the fixture recorded from the REFERENCE model (forward hooks on each module of
     down / middle / up, tests/golden/make_golden.py:run_unet_case) against the HIP plan's NHWC buffer of that block."""

@@ -19,12 +19,17 @@ CASES = {
     "c5like_i128_b32": dict(img_size=128, base_channels=32, n_heads=2, channel_mults=(1, 1, 2, 2, 4, 4),
                             attention_resolutions="32,16,8"),
     "c2_256_b128": dict(img_size=256, base_channels=128, n_heads=2, attention_resolutions="16,8"),
+    # biggan_updown=False: Downsample / Upsample layers (UNet.py:60-92), with and without their convolutions
+    "convrs_i64_b32": dict(img_size=64, base_channels=32, n_heads=2, attention_resolutions="16,8", biggan_updown=False,
+                           conv_resample=True),
+    "poolrs_i32_b32": dict(img_size=32, base_channels=32, biggan_updown=False, conv_resample=False),
 }
 
 
 def shapes_of(kw):
     return uo.param_shapes(kw["img_size"], kw["base_channels"], kw.get("channel_mults", ""), 2,
-                           kw.get("attention_resolutions", "32,16,8"), kw.get("in_channels", 1))
+                           kw.get("attention_resolutions", "32,16,8"), kw.get("in_channels", 1), kw.get("biggan_updown", True),
+                           kw.get("conv_resample", True))
 
 
 @pytest.mark.parametrize("name", list(CASES))
