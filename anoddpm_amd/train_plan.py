@@ -23,6 +23,7 @@ of the reference loop body (p_loss, the loss expression) stays the reference's t
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -277,7 +278,7 @@ class TrainPlan(_Plan):
         c1 = srcs[1][1] if len(srcs) > 1 else 0
         C = c0 + c1
         P = Hs * Hs
-        nslab = max(1, min(64, P // 64))
+        nslab = max(1, min(int(os.environ.get("ANODDPM_GNBWD_SLABS", 256)), P // 16))     # >= 4 workgroups per CU on the large maps
         ga = GnBwdArgs()
         ga.x0 = srcs[0][0].data_ptr()
         ga.x1 = srcs[1][0].data_ptr() if c1 else None
