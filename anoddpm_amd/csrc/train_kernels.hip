@@ -148,7 +148,17 @@ __global__ __launch_bounds__(256) void wgrad1_fold_kernel(const anoddpm_wgrad1_a
     if (idx < (int64_t)K * N) {
         const int co = (int)(idx % N), ci = (int)(idx / N);
         float s = 0.f;
-        for (int it = 0; it < nitems; ++it) s += a.ws[((int64_t)it * K + ci) * N + co];
+        const float *p = a.ws + (int64_t)ci * N + co;
+        const int64_t item = (int64_t)K * N;
+        int it = 0;
+        for (; it + 16 <= nitems; it += 16) {                       // latency-bound: 16 independent loads in flight, item order kept
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[(it + u) * item];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; it < nitems; ++it) s += p[it * item];
         float *o = a.dw + (int64_t)co * K + ci;
         *o = a.accumulate ? *o + s : s;
     }
