@@ -66,11 +66,15 @@ def test_cpu_tensors_are_refused_not_emulated():
         m(torch.zeros(1, 1, 32, 32), torch.tensor([3]))      # autograd path is device-only as well
 
 
-@pytest.mark.parametrize("name", ["i32_b32_h1", "i64_b32_hc32", "i64_b64_c3"])
+@pytest.mark.parametrize("name", ["i32_b32_h1", "i64_b32_hc32", "i64_b64_c3", "convrs_i64_b32", "poolrs_i32_b32"])
 def test_state_dict_layout_matches_reference(name):
     cases = {"i32_b32_h1": dict(img_size=32, base_channels=32),
              "i64_b32_hc32": dict(img_size=64, base_channels=32, n_head_channels=32, attention_resolutions="16,8"),
-             "i64_b64_c3": dict(img_size=64, base_channels=64, n_heads=2, in_channels=3)}
+             "i64_b64_c3": dict(img_size=64, base_channels=64, n_heads=2, in_channels=3),
+             # biggan_updown=False: Downsample / Upsample layers with (`.downsample.*`, `.conv.*`) and without parameters
+             "convrs_i64_b32": dict(img_size=64, base_channels=32, n_heads=2, attention_resolutions="16,8", biggan_updown=False,
+                                    conv_resample=True),
+             "poolrs_i32_b32": dict(img_size=32, base_channels=32, biggan_updown=False, conv_resample=False)}
     g = np.load(os.path.join(GOLDEN, f"unet_{name}.npz"))
     m = UN.UNetModel(**cases[name])
     sd = m.state_dict()
@@ -80,6 +84,15 @@ def test_state_dict_layout_matches_reference(name):
     # zero-initialised modules (UNet.py:117,193,387,414-420)
     assert sd["out.2.weight"].abs().sum() == 0 and sd["down.1.0.out_layers.3.weight"].abs().sum() == 0
     assert sd["middle.1.proj_out.weight"].abs().sum() == 0 and sd["down.1.0.in_layers.2.weight"].abs().sum() > 0
+
+
+def test_fused_attention_shape_policy(monkeypatch):
+    """unet.fused_attention_ok: the shapes anoddpm_attention takes (score rows resident in LDS, power-of-two head width)."""
+    from anoddpm_amd.unet import fused_attention_ok as ok
+    assert ok(256, 256) and ok(64, 256) and ok(1024, 128) and ok(16, 16) and ok(64, 512)
+    assert not ok(4096, 128) and not ok(40, 32) and not ok(64, 48) and not ok(64, 8) and not ok(64, 1024)
+    monkeypatch.setenv("ANODDPM_NO_FUSED_ATTENTION", "1")
+    assert not ok(256, 256)
 
 
 def test_module_protocol():
