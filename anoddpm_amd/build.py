@@ -28,6 +28,7 @@ SOURCES = {
     "optim.hip": [],
     "metrics.hip": ["-ffp-contract=off"],
     "wgrad.hip": [],
+    "wgrad43.hip": [],
     "gn_backward.hip": [],
     "train_kernels.hip": [],
     "loader.hip": ["-ffp-contract=off"],

@@ -69,7 +69,7 @@ extern "C" int anoddpm_debug_set(int32_t key, int32_t value)
     return ANODDPM_OK;
 }
 
-extern "C" int anoddpm_abi_version(void) { return 13; }
+extern "C" int anoddpm_abi_version(void) { return 14; }
 
 extern "C" const char *anoddpm_last_error(void) { return g_err; }
 

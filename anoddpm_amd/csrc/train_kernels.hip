@@ -293,20 +293,34 @@ __global__ __launch_bounds__(1024) void linear_bwd_x_kernel(const anoddpm_linear
 }
 
 // ------------------------------------------------------------------------------------------------ column-sum fold
-// grid (ceil(N/64), B): 64 channels x 4 item lanes; then a second launch folds the batch into the bias gradient.
-__global__ __launch_bounds__(256) void colsum_fold_kernel(const anoddpm_colsum_fold_args a)
+// grid (ceil(N/64), B): 64 channels x 16 item lanes, eight rows in flight per thread (the Winograd-domain weight gradient emits
+// one row per 16x8 patch: 512 per image at 256^2); then a second launch folds the batch into the bias gradient.
+__global__ __launch_bounds__(1024) void colsum_fold_kernel(const anoddpm_colsum_fold_args a)
 {
-    __shared__ float red[4][64];
+    __shared__ float red[16][64];
     const int l = threadIdx.x & 63, il = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + l, b = blockIdx.y;
     float s = 0.f;
     if (n < a.N) {
         const float *p = a.colsum + ((int64_t)b * a.ipb) * a.N + n;
-        for (int i = il; i < a.ipb; i += 4) s += p[(int64_t)i * a.N];
+        int i = il;
+        for (; i + 7 * 16 < a.ipb; i += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(i + u * 16) * a.N];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; i < a.ipb; i += 16) s += p[(int64_t)i * a.N];
     }
     red[il][l] = s;
     __syncthreads();
-    if (il == 0 && n < a.N) a.dimg[(int64_t)b * a.N + n] = ((red[0][l] + red[1][l]) + red[2][l]) + red[3][l];
+    if (il == 0 && n < a.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][l];
+        a.dimg[(int64_t)b * a.N + n] = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void colsum_bias_kernel(const anoddpm_colsum_fold_args a)
@@ -586,7 +600,7 @@ extern "C" int anoddpm_linear_small_backward(const anoddpm_linear_bwd_args *a, v
 extern "C" int anoddpm_colsum_fold(const anoddpm_colsum_fold_args *a, void *stream)
 {
     ANODDPM_REQUIRE(a && a->colsum && a->dimg && a->B >= 1 && a->B <= 65535 && a->ipb >= 1 && a->N >= 1, "colsum_fold: bad arguments");
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((a->N + 63) / 64), (unsigned)a->B), dim3(256), 0, as_stream(stream), *a);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((a->N + 63) / 64), (unsigned)a->B), dim3(1024), 0, as_stream(stream), *a);
     if (a->dbias) hipLaunchKernelGGL(colsum_bias_kernel, dim3((unsigned)((a->N + 255) / 256)), dim3(256), 0, as_stream(stream), *a);
     return check_launch("colsum_fold");
 }

@@ -314,6 +314,8 @@ extern "C" int anoddpm_conv3x3_wgrad(const anoddpm_wgrad_args *a, void *stream)
     ANODDPM_REQUIRE(a->a0_ld % 4 == 0 && (a->c1 == 0 || a->a1_ld % 4 == 0) && a->dy_ld % 4 == 0 && (a->a0_bs | a->a1_bs | a->dy_bs) % 4 == 0,
                     "wgrad: strides must be multiples of 4 floats");
     ANODDPM_REQUIRE(!a->gn_scale || (a->gn_shift && a->gn_ld % 4 == 0), "wgrad: bad GroupNorm affine");
+    ANODDPM_REQUIRE(a->algo == 0 || a->algo == 1, "wgrad: algo must be 0 (direct) or 1 (Winograd F(4x4,3x3) domain)");
+    if (a->algo == 1) return launch_wgrad43(a, as_stream(stream));
     const int TW = a->W % 32 == 0 ? 32 : (a->W % 16 == 0 ? 16 : (a->W % 8 == 0 ? 8 : (a->W % 4 == 0 ? 4 : 2)));
     ANODDPM_REQUIRE(a->W % TW == 0, "wgrad: W must be even");
     const int nseg = a->W / TW, nband = (a->H + a->band - 1) / a->band;
@@ -330,6 +332,11 @@ extern "C" int anoddpm_conv3x3_wgrad(const anoddpm_wgrad_args *a, void *stream)
     const int64_t kn = (int64_t)K * a->N;
     hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((kn + 255) / 256), 3), dim3(256), 0, s, *a, (int)nitems);
     return check_launch("conv3x3_wgrad");
+}
+
+extern "C" int anoddpm_wgrad43_groups(int32_t K, int32_t N, int32_t B, int32_t H, int32_t W)
+{
+    return anoddpm::wgrad43_groups(K, N, B, H, W);
 }
 
 extern "C" int anoddpm_pack_conv3x3(const float *w, float *out, int32_t N, int32_t K, int32_t mode, int32_t bwd, void *stream)

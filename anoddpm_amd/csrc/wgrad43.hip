@@ -1,0 +1,376 @@
+// Weight gradient of the 3x3 convolutions in the Winograd F(4x4,3x3) domain (algo == 1 of anoddpm_conv3x3_wgrad), gfx950.
+//
+// The forward kernel (winograd43.hip) computes  Y = A^T [ sum_ci U(co,ci) (.) V(ci) ] A  per 4x4 output tile, with
+// U = G g G^T and V = B^T d B (d = the activated 6x6 input tile).  Its exact adjoint w.r.t. the weights is
+//     dU[pos][ci][co] = sum over tiles of  V[pos][tile][ci] * Z[pos][tile][co],     Z = A dY A^T  (6x6 from the 4x4 dY tile),
+//     dg (3x3)        = G^T dU G,
+// i.e. 36 multiplies per (ci, co) and tile instead of the 144 of the direct form (wgrad.hip): 4x fewer MFMAs, and the gradient
+// of exactly the function the forward kernel evaluates.  Replaces the autograd backward of nn.Conv2d w.r.t. its weight
+// (UNet.py:172,193; diffusion_training.py:102) for the layers the forward runs on the F(4x4,3x3) kernel.
+//
+// Mapping.  36 positions x (32 input x 64 output channels) of accumulators = 288 KB: one 768-thread workgroup per CU (12 waves,
+// wave w owns positions 3w..3w+2: 3 x 2 x 4 accumulator tiles of 16 x 16, v_mfma_f32_16x16x4_f32 with the reduction over tiles).
+// A workgroup = one (32 ci, 64 co) block x a strided set of 16x8-pixel output patches (8 tiles), which it walks one by one:
+//   1. the activated 18x10 input patch (2 chunks of 16 channels) and the dY patch (4 chunks of 16 channels, two at a time) are
+//      staged in LDS from registers loaded one phase ahead (GroupNorm-apply + SiLU, nearest-x2 / concat resolved on the load);
+//   2. all twelve waves transform: V = B^T d B (768 float2 items = 2 chunks x 8 tiles x 8 channel pairs x 6 rows) and
+//      Z = A dY A^T (2 rounds of 768 items); the row-sum role of the Z transform also emits the per-patch column sums of dY
+//      (bias / embedding gradients) for the workgroups of the first input-channel block;
+//   3. 48 MFMAs per wave: operands are 4-byte LDS reads of V / Z [pos][tile][channel] (16 channels x 4 tiles per wave read).
+// VALU (transforms) and MFMA phases alternate -- on this hardware they share the issue port anyway -- four barriers per patch.
+// The per-workgroup dU goes to a workspace [PG][36][K][N]; two small kernels sum the PG slabs and apply G^T . G.
+#include "common.h"
+
+using anoddpm::silu_f;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_g(const float *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7ffffffe, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bld4g(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned wave_bytes)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)wave_bytes, 0));
+}
+
+constexpr int G4_NT = 768;
+constexpr int G4_PW = 18;                          // input patch: 18 x 10 pixels (16 x 8 outputs + halo)
+constexpr int G4_PPIX = 180;
+constexpr int G4_PITCH = 5;                        // float4 per staged pixel (16 channels + pad)
+constexpr int G4_TILES = 8;                        // 4 x 2 tiles of 4 x 4 outputs
+constexpr int G4_V = 36 * G4_TILES * 4;            // float4 per transformed 16-channel chunk: [pos][tile][quad]
+constexpr int G4_KB = 32, G4_NB = 64;
+constexpr int G4_PIN = G4_PPIX * G4_PITCH;         // float4 per input staging buffer
+constexpr int G4_PDY = 128 * G4_PITCH;             // float4 per dY staging buffer
+constexpr int G4_AFF = 240;                        // float4: GroupNorm affine of the workgroup's 32 channels for up to 15 images
+constexpr int G4_LDS4 = 6 * G4_V + 2 * G4_PIN + 2 * G4_PDY + G4_AFF;      // 10,232 float4 = 163,712 B of the CU's 163,840
+static_assert(G4_LDS4 * 16 <= 160 * 1024, "wgrad43: LDS budget");
+
+__global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_args a, const int PG, const int tiles_x, const int tiles_y, const float inv_tx)
+{
+    __shared__ __attribute__((aligned(16))) f32x4 lds4[G4_LDS4];
+    f32x4 *ldsV = lds4, *ldsZ = lds4 + 2 * G4_V, *ldsPin = ldsZ + 4 * G4_V, *ldsPdy = ldsPin + 2 * G4_PIN, *ldsAff = ldsPdy + 2 * G4_PDY;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W, N = a.N, K = a.c0 + a.c1;
+    const int nkb = K / G4_KB;
+    const int kb = blockIdx.y % nkb, nb = blockIdx.y / nkb;
+    const int k0 = kb * G4_KB, n0 = nb * G4_NB;
+    const int ppi = tiles_x * tiles_y, patches = a.B * ppi;
+    const int pg = blockIdx.x;
+    const int a_mode = a.a_mode;
+
+    // GroupNorm affine of this block's 32 input channels for every image: [b][chunk][quad] {scale}, then {shift}
+    for (int i = tid; i < a.B * 8; i += G4_NT) {
+        const int b = i >> 3, q = i & 7;
+        ldsAff[i] = *reinterpret_cast<const f32x4 *>(a.gn_scale + (int64_t)b * a.gn_ld + k0 + q * 4);
+        ldsAff[a.B * 8 + i] = *reinterpret_cast<const f32x4 *>(a.gn_shift + (int64_t)b * a.gn_ld + k0 + q * 4);
+    }
+
+    // ---- staging geometry (fixed per thread) ----
+    const int sq = tid & 3, sp_pix = tid >> 2;                      // input slot: pixel 0..179 (tid < 720), quad
+    const bool in_slot = tid < G4_PPIX * 4;
+    const int spy = sp_pix / G4_PW, spx = sp_pix - spy * G4_PW;
+    // dY slots: s = tid + j*768 (j = 0, 1), 1024 per round: chunk-in-round = s >> 9, pixel = (s & 511) >> 2, quad = s & 3
+    f32x4 in_raw[2], dy_raw[2];
+    int in_valid = 0;
+    // patch coordinates are wave-uniform and advance incrementally (no integer division in the loop): image b, patch r of the image
+    struct Geo { int b, r, y0, x0; };
+    auto locate = [&](Geo &g) {
+        const int ty = (int)(((float)g.r + 0.5f) * inv_tx);           // exact for r < 2^23
+        g.y0 = ty * 8;
+        g.x0 = (g.r - ty * tiles_x) * 16;
+    };
+    auto advance = [&](Geo g) {
+        g.r += PG;
+        while (g.r >= ppi) { g.r -= ppi; ++g.b; }
+        if (g.b >= a.B) { g.b = a.B - 1; g.r = ppi - 1; }            // past the end: a valid patch, loaded and never used
+        locate(g);
+        return g;
+    };
+    // 32-bit buffer addressing (tensors < 2 GB, checked by the launcher): per-lane byte offset + wave-uniform byte offset
+    const __amdgpu_buffer_rsrc_t rA0 = rsrc_g(a.a0), rA1 = rsrc_g(a.a1 ? a.a1 : a.a0), rDY = rsrc_g(a.dy);
+    auto load_in = [&](const Geo &g) {
+        const int gy = g.y0 + spy - 1, gx = g.x0 + spx - 1;
+        const bool ok = in_slot && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        in_valid = ok ? 1 : 0;
+        const unsigned sp = ok ? (unsigned)((a_mode == 0) ? gy * W + gx : (gy >> 1) * (W >> 1) + (gx >> 1)) : 0u;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int kc = k0 + c * 16;
+            const bool first = kc < a.c0;                           // wave-uniform
+            const unsigned ld = (unsigned)(first ? a.a0_ld : a.a1_ld);
+            const unsigned wave_off = (unsigned)g.b * (unsigned)(first ? a.a0_bs : a.a1_bs) * 4u + (unsigned)(first ? kc : kc - a.c0) * 4u;
+            in_raw[c] = bld4g(first ? rA0 : rA1, (sp * ld + (unsigned)sq * 4u) * 4u, wave_off);
+        }
+    };
+    auto store_in = [&](const Geo &g) {
+        const int b = g.b;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const f32x4 sc = ldsAff[b * 8 + c * 4 + sq], sh = ldsAff[a.B * 8 + b * 8 + c * 4 + sq];
+            f32x4 v = in_raw[c] * sc + sh;
+            v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
+            if (!in_valid) v = f32x4{0.f, 0.f, 0.f, 0.f};            // zero padding of the ACTIVATED map
+            if (in_slot) ldsPin[c * G4_PIN + sp_pix * G4_PITCH + sq] = v;
+        }
+    };
+    // dY slot geometry is fixed per thread: chunk-in-round, pixel, quad of slots tid and tid + 768 (the second clamped to 1023)
+    unsigned dy_lane[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int s0 = tid + j * G4_NT;
+        const int sc = s0 < 1024 ? s0 : 1023;
+        const int p = (sc & 511) >> 2, q = sc & 3;
+        dy_lane[j] = ((unsigned)((p >> 4) * W + (p & 15)) * (unsigned)a.dy_ld + (unsigned)((sc >> 9) * 16 + q * 4)) * 4u;
+    }
+    auto load_dy = [&](const Geo &g, int round) {
+        const unsigned wave_off = ((unsigned)g.b * (unsigned)a.dy_bs + (unsigned)(g.y0 * W + g.x0) * (unsigned)a.dy_ld +
+                                   (unsigned)(n0 + round * 32)) * 4u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dy_raw[j] = bld4g(rDY, dy_lane[j], wave_off);
+    };
+    auto store_dy = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int s = tid + j * G4_NT;
+            if (s < 1024) ldsPdy[(s >> 9) * G4_PDY + ((s & 511) >> 2) * G4_PITCH + (s & 3)] = dy_raw[j];
+        }
+    };
+
+    // ---- transform roles: wave -> (row u = wave % 6, chunk slot = wave / 6); lane -> (channel pair = lane & 7, tile = lane >> 3)
+    const int tu = wave % 6, tslot = wave / 6;
+    const int tpair = lane & 7, ttile = lane >> 3;
+    // V = B^T d B: row u of B^T as (patch row, coefficient) pairs (see winograd43.hip)
+    const int tr0 = (tu == 0) ? 0 : 1, tr1 = (tu == 5) ? 3 : 2, tr2 = (tu == 0) ? 4 : ((tu == 5) ? 5 : 3), tr3 = 4;
+    const float tc0 = (tu == 0) ? 4.f : (tu == 1 ? -4.f : (tu == 2 ? 4.f : (tu == 3 ? -2.f : (tu == 4 ? 2.f : 4.f))));
+    const float tc1 = (tu == 0 || tu == 5) ? -5.f : ((tu == 1 || tu == 2) ? -4.f : -1.f);
+    const float tc2 = (tu == 0 || tu == 5) ? 1.f : (tu == 1 ? 1.f : (tu == 2 ? -1.f : (tu == 3 ? 2.f : -2.f)));
+    const float tc3 = (tu == 0 || tu == 5) ? 0.f : 1.f;
+    const int vin2 = ((4 * (ttile >> 2)) * G4_PW + 4 * (ttile & 3)) * G4_PITCH * 2 + tpair;       // float2 index of the tile corner
+    const int vrow = G4_PW * G4_PITCH * 2;
+    auto transform_v = [&]() {
+        const f32x2 *D = reinterpret_cast<const f32x2 *>(ldsPin + tslot * G4_PIN) + vin2;
+        f32x2 t[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            t[j] = tc0 * D[tr0 * vrow + j * G4_PITCH * 2] + tc1 * D[tr1 * vrow + j * G4_PITCH * 2] + tc2 * D[tr2 * vrow + j * G4_PITCH * 2] +
+                   tc3 * D[tr3 * vrow + j * G4_PITCH * 2];
+            __builtin_amdgcn_sched_barrier(0);                      // one column of reads in flight: the registers belong to the accumulators
+        }
+        const f32x2 p = t[4] - 4.f * t[2], q = t[3] - 4.f * t[1], r = t[4] - t[2], s = t[3] - t[1];
+        f32x2 *V = reinterpret_cast<f32x2 *>(ldsV + tslot * G4_V) + ((tu * 6) * G4_TILES + ttile) * 8 + tpair;
+        V[0 * 64] = 4.f * t[0] - 5.f * t[2] + t[4];
+        V[1 * 64] = p + q;
+        V[2 * 64] = p - q;
+        V[3 * 64] = r + 2.f * s;
+        V[4 * 64] = r - 2.f * s;
+        V[5 * 64] = 4.f * t[1] - 5.f * t[3] + t[5];
+    };
+    // Z = A dY A^T: row u of A (6 x 4): u0 (1,0,0,0) u1 (1,1,1,1) u2 (1,-1,1,-1) u3 (1,2,4,8) u4 (1,-2,4,-8) u5 (0,0,0,1)
+    const float zc0 = (tu == 5) ? 0.f : 1.f;
+    const float zc1 = (tu == 1) ? 1.f : (tu == 2 ? -1.f : (tu == 3 ? 2.f : (tu == 4 ? -2.f : 0.f)));
+    const float zc2 = (tu == 1 || tu == 2) ? 1.f : ((tu == 3 || tu == 4) ? 4.f : 0.f);
+    const float zc3 = (tu == 1) ? 1.f : (tu == 2 ? -1.f : (tu == 3 ? 8.f : (tu == 4 ? -8.f : (tu == 5 ? 1.f : 0.f))));
+    const int zin2 = ((4 * (ttile >> 2)) * 16 + 4 * (ttile & 3)) * G4_PITCH * 2 + tpair;
+    const int zrow = 16 * G4_PITCH * 2;
+    const bool want_cs = a.colsum != nullptr && kb == 0 && tu == 1;
+    const __amdgpu_buffer_rsrc_t rCS = rsrc_g(a.colsum ? a.colsum : a.dy);
+    auto transform_z = [&](int round, const Geo &g) {
+        const f32x2 *D = reinterpret_cast<const f32x2 *>(ldsPdy + tslot * G4_PDY) + zin2;
+        f32x2 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[j] = zc0 * D[j * G4_PITCH * 2] + zc1 * D[zrow + j * G4_PITCH * 2] + zc2 * D[2 * zrow + j * G4_PITCH * 2] + zc3 * D[3 * zrow + j * G4_PITCH * 2];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int zc = 2 * round + tslot;
+        f32x2 *Z = reinterpret_cast<f32x2 *>(ldsZ + zc * G4_V) + ((tu * 6) * G4_TILES + ttile) * 8 + tpair;
+        const f32x2 e02 = t[0] + t[2], o13 = t[1] + t[3], e024 = t[0] + 4.f * t[2], o138 = 2.f * t[1] + 8.f * t[3];
+        Z[0 * 64] = t[0];
+        Z[1 * 64] = e02 + o13;
+        Z[2 * 64] = e02 - o13;
+        Z[3 * 64] = e024 + o138;
+        Z[4 * 64] = e024 - o138;
+        Z[5 * 64] = t[3];
+        if (want_cs) {                                              // row role u = 1: t[j] are the column sums of the tile
+            f32x2 cs2 = e02 + o13;                                  // sum over the patch's 8 tiles: lanes differ in bits 3..5
+#pragma unroll
+            for (int o = 8; o <= 32; o <<= 1) {
+                cs2[0] += __shfl_xor(cs2[0], o);
+                cs2[1] += __shfl_xor(cs2[1], o);
+            }
+            if (ttile == 0) {
+                const unsigned wave_off = (((unsigned)g.b * (unsigned)ppi + (unsigned)g.r) * (unsigned)N + (unsigned)(n0 + zc * 16)) * 4u;
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cs2), rCS, (int)(tpair * 8), (int)wave_off, 0);
+            }
+        }
+    };
+
+    // ---- accumulators: positions 3*wave + p, 2 input-channel tiles x 4 output-channel tiles of 16 x 16
+    f32x4 acc[3][2][4];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[p][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, kq = lane >> 4;
+    const float *Vf = reinterpret_cast<const float *>(ldsV), *Zf = reinterpret_cast<const float *>(ldsZ);
+
+    Geo cur;
+    cur.b = pg / ppi;
+    cur.r = pg - cur.b * ppi;
+    locate(cur);
+    const int iters = (patches - pg + PG - 1) / PG;                  // pg < patches (launcher)
+    load_in(cur);
+    load_dy(cur, 0);
+    __syncthreads();                                                // affine table
+    for (int it = 0; it < iters; ++it) {
+        store_in(cur);
+        store_dy();
+        load_dy(cur, 1);
+        __syncthreads();
+        transform_v();
+        transform_z(0, cur);
+        __syncthreads();
+        store_dy();
+        const Geo nxt = advance(cur);                               // prefetch of the next patch
+        load_in(nxt);
+        load_dy(nxt, 0);
+        __syncthreads();
+        transform_z(1, cur);
+        cur = nxt;
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int pos = wave * 3 + p;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int off = ((pos * G4_TILES + 4 * e + kq) * 16 + l15);
+                float va[2], zb[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) va[i] = Vf[i * G4_V * 4 + off];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zb[j] = Zf[j * G4_V * 4 + off];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[i], zb[j], acc[p][i][j], 0, 0, 0);
+            }
+        }
+        // no barrier here: the next iteration only writes the staging buffers before its first barrier
+    }
+
+    // ---- partial dU of this workgroup: ws[pg][pos][k][n]
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int pos = wave * 3 + p;
+        float *dst = a.ws + (((int64_t)pg * 36 + pos) * K + k0 + 4 * kq) * N + n0 + l15;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(int64_t)(i * 16 + r) * N + j * 16] = acc[p][i][j][r];
+    }
+}
+
+// ws[0][pos][k][n] <- sum over the PG slabs, fixed order (thread = one (pos, k, n); 16 slabs in flight)
+__global__ __launch_bounds__(256) void wgrad43_sum_kernel(float *ws, const int64_t slab, const int PG)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= slab) return;
+    const float *p = ws + idx;
+    float s = 0.f;
+    int g = 0;
+    for (; g + 16 <= PG; g += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(g + u) * slab];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; g < PG; ++g) s += p[(int64_t)g * slab];
+    ws[idx] = s;
+}
+
+// dw[n][k][a][b] (+)= sum_u sum_v G[u][a] dU[u][v][k][n] G[v][b]   (thread = one (k, n))
+__global__ __launch_bounds__(256) void wgrad43_out_kernel(const anoddpm_wgrad_args a)
+{
+    const int K = a.c0 + a.c1, N = a.N;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)K * N) return;
+    const int n = (int)(idx % N), k = (int)(idx / N);
+    const float G[6][3] = {{1.f / 4, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    float r[6][3];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        float d[6];
+#pragma unroll
+        for (int v = 0; v < 6; ++v) d[v] = a.ws[((int64_t)(u * 6 + v) * K + k) * N + n];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float s = 0.f;
+#pragma unroll
+            for (int v = 0; v < 6; ++v) s += d[v] * G[v][b];
+            r[u][b] = s;
+        }
+    }
+    float *o = a.dw + ((int64_t)n * K + k) * 9;
+#pragma unroll
+    for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float s = 0.f;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) s += G[u][aa] * r[u][b];
+            o[aa * 3 + b] = a.accumulate ? o[aa * 3 + b] + s : s;
+        }
+}
+
+}  // namespace
+
+namespace anoddpm {
+
+// Patch groups of the Winograd-domain weight gradient: one workgroup per CU in total (shared with the host side through
+// anoddpm_wgrad43_groups so that the caller can size the workspace: PG * 36 * K * N floats).
+int wgrad43_groups(int K, int N, int B, int H, int W)
+{
+    const int blocks = (K / G4_KB) * (N / G4_NB);
+    const int patches = B * (H / 8) * (W / 16);
+    int pg = 256 / (blocks > 0 ? blocks : 1);
+    if (pg < 1) pg = 1;
+    if (pg > patches) pg = patches;
+    return pg;
+}
+
+int launch_wgrad43(const anoddpm_wgrad_args *a, hipStream_t s)
+{
+    const int K = a->c0 + a->c1;
+    ANODDPM_REQUIRE(a->gn_scale && a->gn_shift && a->act == 1, "wgrad (Winograd): needs the fused GroupNorm + SiLU operand");
+    ANODDPM_REQUIRE(a->a_mode == 0 || a->a_mode == 1, "wgrad (Winograd): a_mode must be 0 or 1");
+    ANODDPM_REQUIRE(a->H % 8 == 0 && a->W % 16 == 0 && K % G4_KB == 0 && a->N % G4_NB == 0 && (a->c1 == 0 || a->c0 % 16 == 0),
+                    "wgrad (Winograd): H %% 8, W %% 16, K %% 32, N %% 64, c0 %% 16 must be 0");
+    ANODDPM_REQUIRE(a->B <= 15, "wgrad (Winograd): batch > 15");
+    ANODDPM_REQUIRE((int64_t)a->B * a->H * a->W * (K > a->N ? K : a->N) * 4 < ((int64_t)1 << 31) &&
+                    (int64_t)a->B * a->a0_bs * 4 < ((int64_t)1 << 31) && (int64_t)a->B * a->dy_bs * 4 < ((int64_t)1 << 31),
+                    "wgrad (Winograd): tensors must stay below 2 GB (32-bit buffer offsets)");
+    const int pg = wgrad43_groups(K, a->N, a->B, a->H, a->W);
+    const int64_t slab = (int64_t)36 * K * a->N;
+    ANODDPM_REQUIRE(a->ws_floats >= (int64_t)pg * slab, "wgrad (Winograd): workspace too small");
+    const dim3 grid((unsigned)pg, (unsigned)((K / G4_KB) * (a->N / G4_NB)));
+    hipLaunchKernelGGL(wgrad43_kernel, grid, dim3(G4_NT), 0, s, *a, pg, a->W / 16, a->H / 8, 1.0f / (float)(a->W / 16));
+    if (pg > 1) hipLaunchKernelGGL(wgrad43_sum_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, a->ws, slab, pg);
+    hipLaunchKernelGGL(wgrad43_out_kernel, dim3((unsigned)(((int64_t)K * a->N + 255) / 256)), dim3(256), 0, s, *a);
+    return check_launch("conv3x3_wgrad (Winograd)");
+}
+
+}  // namespace anoddpm

@@ -226,12 +226,22 @@ class TrainPlan(_Plan):
         nband = -(-H // band)
         ipb = (W // TW) * nband
         nitems = B * ipb
+        # Winograd-domain weight gradient (csrc/wgrad43.hip: the adjoint of the F(4x4,3x3) forward kernel, 4x fewer MFMAs) on the
+        # maps where the forward uses that kernel; ANODDPM_NO_WGRAD43=1 keeps the direct nine-tap kernel everywhere
+        algo = int(a_mode in (0, 1) and H % 8 == 0 and W % 16 == 0 and K % 32 == 0 and N % 64 == 0 and (c1 == 0 or c0 % 16 == 0)
+                   and B <= 15 and H * W >= int(os.environ.get("ANODDPM_WGRAD43_MIN_PIXELS", 64 * 64))
+                   and os.environ.get("ANODDPM_NO_WGRAD43", "0") != "1")
         wa = WgradArgs()
         wa.a0 = srcs[0][0].data_ptr()
         wa.a1 = srcs[1][0].data_ptr() if c1 else None
         wa.gn_scale, wa.gn_shift = gn[0].data_ptr(), gn[1].data_ptr()
         wa.dy, wa.dw = dy.data_ptr(), self.dW(wkey)
-        wa.ws_floats = nitems * 9 * K * N
+        wa.algo = algo
+        if algo:
+            wa.ws_floats = lib().anoddpm_wgrad43_groups(K, N, B, H, W) * 36 * K * N
+            ipb = (H // 8) * (W // 16)                           # column sums per 16x8 output patch
+        else:
+            wa.ws_floats = nitems * 9 * K * N
         self.tws(wa, "ws", wa.ws_floats)
         Ps = Hs * Hs
         wa.a0_bs, wa.a1_bs, wa.dy_bs = Ps * c0, Ps * c1, H * W * N

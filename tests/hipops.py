@@ -232,7 +232,7 @@ def head(x, w, b, scale, shift):
     return out
 
 
-def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into=None, colsum_out=None):
+def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into=None, colsum_out=None, algo=0):
     """dW (OIHW) of a 3x3 conv whose input is the fused operand load of `conv_igemm` (anoddpm_conv3x3_wgrad).
     srcs: NHWC sources; dy: NHWC [B,H,W,N]."""
     from anoddpm_amd._lib import WgradArgs
@@ -245,7 +245,11 @@ def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into
     TW = next(t for t in (32, 16, 8, 4, 2) if W % t == 0)
     band = band or max(1, H // 4)
     nitems = B * (W // TW) * (-(-H // band))
-    ws = torch.empty(nitems * 9 * K * N, device=dev)
+    if algo == 1:                       # Winograd-domain weight gradient: PG slabs of [36][K][N]; column sums per 16x8 output patch
+        ws = torch.empty(lib().anoddpm_wgrad43_groups(K, N, B, H, W) * 36 * K * N, device=dev)
+        nitems = B * (H // 8) * (W // 16)
+    else:
+        ws = torch.empty(nitems * 9 * K * N, device=dev)
     dw = accumulate_into if accumulate_into is not None else torch.full((N, K, 3, 3), float("nan"), device=dev)
     st = WgradArgs()
     st.a0, st.a1 = srcs[0].data_ptr(), srcs[1].data_ptr() if c1 else None
@@ -257,6 +261,7 @@ def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into
     st.H, st.W, st.N, st.B = H, W, N, B
     st.a_mode, st.act, st.gn_ld, st.band = a_mode, act, K, band
     st.accumulate = 1 if accumulate_into is not None else 0
+    st.algo = algo
     if colsum_out is not None:
         cs = torch.full((B, nitems // B, N), float("nan"), device=dev)
         st.colsum = cs.data_ptr()

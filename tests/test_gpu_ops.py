@@ -493,6 +493,53 @@ def test_conv3x3_wgrad(case):
     assert relerr(acc, 2 * dw_ref) < 2e-5
 
 
+WGRAD43_CASES = [
+    # B, (c0, c1), Cout, Hout, a_mode, gn+act
+    (1, (32, 0), 64, 16, 0, True),          # one (32, 64) block, two patches
+    (2, (64, 0), 64, 32, 0, True),          # two input-channel blocks, images interleaved over the patch groups
+    (1, (128, 0), 128, 64, 0, True),        # 8 blocks x 32 patches
+    (2, (64, 64), 128, 32, 0, True),        # virtual concat
+    (1, (64, 0), 64, 32, 1, True),          # fused nearest x2
+    (1, (96, 32), 64, 48, 0, True),         # three patches per row (not a power of two), sources split at 96
+    (3, (32, 0), 128, 16, 0, True),         # fewer patches than the 256 / blocks group count
+]
+
+
+@pytest.mark.parametrize("case", WGRAD43_CASES)
+def test_conv3x3_wgrad_winograd_domain(case):
+    """algo = 1 of anoddpm_conv3x3_wgrad (csrc/wgrad43.hip): dU = sum_tiles V (.) Z, dg = G^T dU G -- the adjoint of the
+    F(4x4,3x3) forward kernel -- against fp64 autograd of F.conv2d and against the direct kernel.  fp32 with the wide
+    transforms: asserted 1e-4 of the gradient's magnitude (direct kernel: 2e-5)."""
+    import hipops
+    B, (c0, c1), N, Hout, a_mode, fused = case
+    x, w, gamma, beta, dy, dw_ref, _ = _bwd_reference(case)
+    xs = hipops.nhwc(x.to(dev()))
+    srcs = [xs[..., :c0].contiguous()] + ([xs[..., c0:].contiguous()] if c1 else [])
+    gn = hipops.gn_affine(srcs, gamma.to(dev()), beta.to(dev()))
+    dyn = hipops.nhwc(dy.to(dev())).contiguous()
+    cs = []
+    got = hipops.conv_wgrad(srcs, dyn, gn=gn, act=1, a_mode=a_mode, colsum_out=cs, algo=1)
+    assert relerr(got, dw_ref) < 1e-4, relerr(got, dw_ref)
+    direct = hipops.conv_wgrad(srcs, dyn, gn=gn, act=1, a_mode=a_mode)
+    assert relerr(got, direct) < 1e-4
+    # column sums of dY per 16x8 output patch -> per image sums over pixels (bias / embedding gradients)
+    assert cs[0].shape == (B, (Hout // 8) * (Hout // 16), N)
+    assert relerr(cs[0].sum(dim=1), dy.sum(dim=(2, 3))) < 1e-5
+    last = dy[:, :, Hout - 8:, Hout - 16:].sum(dim=(2, 3))              # the last patch (bottom right)
+    assert relerr(cs[0][:, -1, :], last) < 1e-5
+    acc = got.clone()
+    hipops.conv_wgrad(srcs, dyn, gn=gn, act=1, a_mode=a_mode, accumulate_into=acc, algo=1)
+    assert relerr(acc, 2 * dw_ref) < 1e-4
+
+
+def test_conv3x3_wgrad_winograd_domain_rejects_other_shapes():
+    import hipops
+    x = hipops.nhwc(rnd(1, 32, 16, 16, seed=3).to(dev()))
+    dyn = hipops.nhwc(rnd(1, 64, 16, 16, seed=4).to(dev())).contiguous()
+    with pytest.raises(Exception, match="Winograd"):
+        hipops.conv_wgrad([x], dyn, algo=1)                              # no fused GroupNorm + SiLU operand
+
+
 @pytest.mark.parametrize("case", [c for c in BWD_CASES if c[4] == 0])
 def test_conv3x3_dgrad_is_forward_kernel_on_flipped_weights(case):
     """The data gradient w.r.t. the (activated) conv input is anoddpm_igemm on dY with the spatially flipped,
