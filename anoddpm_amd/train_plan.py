@@ -229,7 +229,7 @@ class TrainPlan(_Plan):
         # Winograd-domain weight gradient (csrc/wgrad43.hip: the adjoint of the F(4x4,3x3) forward kernel, 4x fewer MFMAs) on the
         # maps where the forward uses that kernel; ANODDPM_NO_WGRAD43=1 keeps the direct nine-tap kernel everywhere
         algo = int(a_mode in (0, 1) and H % 8 == 0 and W % 16 == 0 and K % 32 == 0 and N % 64 == 0 and (c1 == 0 or c0 % 16 == 0)
-                   and B <= 15 and H * W >= int(os.environ.get("ANODDPM_WGRAD43_MIN_PIXELS", 64 * 64))
+                   and B <= 15 and H * W >= int(os.environ.get("ANODDPM_WGRAD43_MIN_PIXELS", 32 * 32))
                    and os.environ.get("ANODDPM_NO_WGRAD43", "0") != "1")
         wa = WgradArgs()
         wa.a0 = srcs[0][0].data_ptr()

@@ -17,7 +17,7 @@ SHAPES = [  # B, (c0, c1), N, H
     (4, (256, 128), 128, 128), (4, (128, 0), 256, 128), (4, (256, 0), 256, 64), (4, (512, 0), 256, 64), (1, (128, 0), 128, 512),
 ]
 dev = torch.device("cuda:0")
-for (B, (c0, c1), N, H) in ([] if os.environ.get('PW') else SHAPES):
+for (B, (c0, c1), N, H) in ([] if (os.environ.get('PW') or os.environ.get('WG')) else SHAPES):
     C = c0 + c1
     x = torch.randn(B, H, H, C, device=dev)
     srcs = [x[..., :c0].contiguous()] + ([x[..., c0:].contiguous()] if c1 else [])
@@ -66,4 +66,44 @@ if os.environ.get("PW"):                                 # PW=1: the 1x1 skip sh
             us = e0.elapsed_time(e1) * 100
             gf = 2.0 * C * N * H * H * B / 1e9
             line += f"  cfg{cfg} {us:7.1f} us ({gf / us * 1e3:6.1f} TFLOP/s)"
+        print(line, flush=True)
+
+if os.environ.get("WG"):                                 # WG=1: 3x3 weight gradient, direct (algo 0) vs Winograd domain (algo 1)
+    from anoddpm_amd._lib import WgradArgs, check
+    for (B, (c0, c1), N, H) in [(4, (128, 0), 128, 256), (4, (128, 128), 128, 256), (4, (128, 0), 128, 128), (4, (256, 0), 256, 128),
+                                (4, (256, 128), 128, 128), (4, (256, 0), 256, 64), (4, (512, 0), 256, 64)]:
+        K = c0 + c1
+        x = torch.randn(B, H, H, K, device=dev)
+        srcs = [x[..., :c0].contiguous()] + ([x[..., c0:].contiguous()] if c1 else [])
+        dy = torch.randn(B, H, H, N, device=dev)
+        gn = hipops.gn_affine(srcs, torch.ones(K, device=dev), torch.zeros(K, device=dev))
+        line = f"wgrad B{B} {c0}+{c1}->{N} @{H}:"
+        for algo in (0, 1):
+            TW = 32
+            tiles = -(-K // 64) * -(-N // 64)
+            per_band = tiles * B * (H // TW)
+            nband = max(1, min(H, round(512 / per_band)))
+            band = -(-H // nband)
+            nitems = B * (H // TW) * -(-H // band)
+            nws = lib().anoddpm_wgrad43_groups(K, N, B, H, H) * 36 * K * N if algo else nitems * 9 * K * N
+            ws = torch.empty(nws, device=dev)
+            dw = torch.zeros(N, K, 3, 3, device=dev)
+            st = WgradArgs()
+            st.a0, st.a1 = srcs[0].data_ptr(), srcs[1].data_ptr() if c1 else None
+            st.gn_scale, st.gn_shift = gn[0].data_ptr(), gn[1].data_ptr()
+            st.dy, st.dw, st.ws, st.ws_floats = dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel()
+            st.a0_bs, st.a1_bs, st.dy_bs = H * H * c0, H * H * c1, H * H * N
+            st.c0, st.c1, st.a0_ld, st.a1_ld, st.dy_ld = c0, c1, c0, max(c1, 4), N
+            st.H, st.W, st.N, st.B, st.a_mode, st.act, st.gn_ld, st.band, st.accumulate, st.algo = H, H, N, B, 0, 1, K, band, 0, algo
+            for _ in range(2):
+                check(lib().anoddpm_conv3x3_wgrad(ctypes.byref(st), current_stream()), "wgrad")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                lib().anoddpm_conv3x3_wgrad(ctypes.byref(st), current_stream())
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 200
+            gf = 2.0 * K * N * 9 * H * H * B / 1e9
+            line += f"  algo{algo} {us:7.1f} us ({gf / us * 1e3:6.1f} alg TFLOP/s)"
         print(line, flush=True)
