@@ -375,7 +375,8 @@ int anoddpm_run_ops(const anoddpm_op *ops, int32_t n, void *stream);
 /* Per-class kernel timing with HIP events on the launch stream (bench.py roofline leg).
  * enable=1 starts recording one event pair per launched op; collect() synchronises the events
  * and returns accumulated milliseconds and launch counts per op code (arrays of ANODDPM_OP_MAX = 32); ANODDPM_OP_IGEMM
- * launches that run the Winograd kernel (cfg == 2) are booked under index 12 instead of 1. */
+ * launches that run the Winograd kernels are booked under index 12 (cfg 2) / 14 (cfg 3) instead of 1, and the Winograd-domain
+ * launches of ANODDPM_OP_WGRAD3 (algo 1) under index 15 instead of 16. */
 int anoddpm_prof_enable(int32_t enable);
 int anoddpm_prof_active(void);             /* 1 while event recording is on (graph capture must be avoided) */
 int anoddpm_prof_collect(double *ms_per_code, int64_t *launches_per_code);
