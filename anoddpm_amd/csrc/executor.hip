@@ -54,6 +54,7 @@ static int dispatch(const anoddpm_op &op, void *stream)
         case ANODDPM_OP_HEAD_BWD: return anoddpm_conv_head_backward(static_cast<const anoddpm_head_bwd_args *>(op.args), stream);
         case ANODDPM_OP_COLSUM_FOLD: return anoddpm_colsum_fold(static_cast<const anoddpm_colsum_fold_args *>(op.args), stream);
         case ANODDPM_OP_ATTENTION: return anoddpm_attention(static_cast<const anoddpm_attention_args *>(op.args), stream);
+        case ANODDPM_OP_PACK_BATCH: return anoddpm_pack_batch(static_cast<const anoddpm_pack_batch_args *>(op.args), stream);
         default: set_error("run_ops: unknown op code %d", op.code); return ANODDPM_EINVAL;
     }
 }
@@ -69,7 +70,7 @@ extern "C" int anoddpm_debug_set(int32_t key, int32_t value)
     return ANODDPM_OK;
 }
 
-extern "C" int anoddpm_abi_version(void) { return 14; }
+extern "C" int anoddpm_abi_version(void) { return 15; }
 
 extern "C" const char *anoddpm_last_error(void) { return g_err; }
 
@@ -185,6 +186,7 @@ extern "C" int anoddpm_struct_size(int32_t which)
         case 27: return (int)sizeof(anoddpm_mri_slice_args);
         case 28: return (int)sizeof(anoddpm_resize_args);
         case 29: return (int)sizeof(anoddpm_attention_args);
+        case 30: return (int)sizeof(anoddpm_pack_batch_args);
         default: return -1;
     }
 }

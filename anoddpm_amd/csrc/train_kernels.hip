@@ -8,6 +8,7 @@
 // Reference semantics: torch autograd of the same expressions.  All reductions are two-stage with a fixed fold order
 // (deterministic); fp32 arithmetic, fp32 accumulation.
 #include "common.h"
+#include "pack_items.h"
 
 using anoddpm::silu_f;
 
@@ -173,26 +174,30 @@ __global__ __launch_bounds__(256) void wgrad1_fold_kernel(const anoddpm_wgrad1_a
 // ------------------------------------------------------------------------------------------------ weight packing
 __global__ __launch_bounds__(256) void pack_pointwise_kernel(const anoddpm_pack_args a)
 {
-    // fwd: out[(k>>2)*N*4 + n*4 + (k&3)] = w[n][k];  bwd: I = N, O = kc: out[(n>>2)*kc*4 + o*4 + (n&3)] = w[n][k0 + o]
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (!a.bwd) {
-        if (idx >= (int64_t)a.N * a.K) return;
-        const int n = (int)(idx % a.N), k = (int)(idx / a.N);
-        a.out[((int64_t)(k >> 2) * a.N + n) * 4 + (k & 3)] = a.w[(int64_t)n * a.K + k];
-    } else {
-        if (idx >= (int64_t)a.N * a.kc) return;
-        const int o = (int)(idx % a.kc), n = (int)(idx / a.kc);
-        a.out[((int64_t)(n >> 2) * a.kc + o) * 4 + (n & 3)] = a.w[(int64_t)n * a.K + a.k0 + o];
-    }
+    anoddpm::pack_pointwise_item(a, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void pack_small_conv_kernel(const anoddpm_pack_args a)
 {
-    // OIHW [N][K][3][3] -> [9][K][N]
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)9 * a.K * a.N) return;
-    const int n = (int)(idx % a.N), k = (int)((idx / a.N) % a.K), t = (int)(idx / ((int64_t)a.N * a.K));
-    a.out[idx] = a.w[((int64_t)n * a.K + k) * 9 + t];
+    anoddpm::pack_small_conv_item(a, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// Every pack job of a model in ONE launch (the training forward re-packs ~270 weights per step: launch-latency bound as separate
+// kernels).  jobs / block0 live in device memory; a block finds its job by bisection over the prefix sums of the jobs' block counts.
+__global__ __launch_bounds__(256) void pack_batch_kernel(const anoddpm_pack_batch_args b)
+{
+    int lo = 0, hi = b.njobs;                                       // block0[lo] <= blockIdx.x < block0[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (b.block0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const anoddpm_pack_args a = b.jobs[lo];
+    const int64_t idx = (int64_t)((int)blockIdx.x - b.block0[lo]) * 256 + threadIdx.x;
+    if (a.kind <= 1) anoddpm::pack_conv3x3_item(a.w, a.out, a.N, a.K, a.kind, a.bwd, idx);
+    else if (a.kind == 5) anoddpm::pack_conv3x3_item(a.w, a.out, a.N, a.K, 2, a.bwd, idx);
+    else if (a.kind == 2) anoddpm::pack_pointwise_item(a, idx);
+    else if (a.kind == 3) anoddpm::pack_small_conv_item(a, idx);
+    else if (idx < (int64_t)a.N * a.K) a.out[idx] = a.w[idx];
 }
 
 __global__ __launch_bounds__(256) void copy_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t n)
@@ -539,6 +544,18 @@ extern "C" int anoddpm_wgrad_pointwise(const anoddpm_wgrad1_args *a, void *strea
     const int64_t kn = (int64_t)K * a->N;
     hipLaunchKernelGGL(wgrad1_fold_kernel, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, s, *a, (int)nitems);
     return check_launch("wgrad_pointwise");
+}
+
+extern "C" int anoddpm_pack_batch(const anoddpm_pack_batch_args *b, void *stream)
+{
+    ANODDPM_REQUIRE(b && b->jobs && b->block0 && b->njobs >= 1 && b->nblocks >= 1, "pack_batch: bad arguments");
+    hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)b->nblocks), dim3(256), 0, as_stream(stream), *b);
+    return check_launch("pack_batch");
+}
+
+extern "C" int64_t anoddpm_pack_job_blocks(const anoddpm_pack_args *a)
+{
+    return a ? anoddpm::pack_job_blocks(*a) : -1;
 }
 
 extern "C" int anoddpm_pack_weights(const anoddpm_pack_args *a, void *stream)

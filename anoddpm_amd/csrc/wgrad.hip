@@ -12,6 +12,7 @@
 // Split-K over (image, column segment, row band): partial tiles go to a workspace, a second kernel folds them in a
 // fixed order into the OIHW gradient (deterministic).  fp32 throughout (v_mfma_f32_32x32x2_f32).
 #include "common.h"
+#include "pack_items.h"
 
 using anoddpm::silu_f;
 
@@ -239,66 +240,7 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const anoddpm_wgrad_arg
 __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float *__restrict__ w, float *__restrict__ out,
                                                            int N, int K, int mode, int bwd)
 {
-    // thread = (o, input-channel QUAD): every store is one 16-byte slot of the [..][I/4][O][4] layout (consecutive threads ->
-    // consecutive slots), and the forward layout reads 4 x 9 contiguous floats
-    const int O = bwd ? K : N, I = bwd ? N : K;
-    const int I4 = I >> 2;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)O * I4) return;
-    const int o = (int)(idx % O), i4 = (int)(idx / O);
-    double g[4][3][3];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = i4 * 4 + e;
-        const float *src = bwd ? w + ((int64_t)i * K + o) * 9 : w + ((int64_t)o * K + i) * 9;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) g[e][t / 3][t % 3] = (double)src[bwd ? 8 - t : t];
-    }
-    float4 *dst = reinterpret_cast<float4 *>(out) + (int64_t)i4 * O + o;
-    const int64_t plane = (int64_t)I4 * O;                           // float4 slots per position
-    if (mode == 0) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-            dst[t * plane] = make_float4((float)g[0][t / 3][t % 3], (float)g[1][t / 3][t % 3], (float)g[2][t / 3][t % 3], (float)g[3][t / 3][t % 3]);
-    } else if (mode == 2) {
-        // Winograd F(4x4,3x3): U = G g G^T with the 6x3 G of interpolation points 0, +-1, +-2, inf; [36 xi = 6u+v][I/4][O][4]
-        const double G6[6][3] = {{1.0 / 4, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            double t1[4][3];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int b2 = 0; b2 < 3; ++b2) t1[e][b2] = G6[u][0] * g[e][0][b2] + G6[u][1] * g[e][1][b2] + G6[u][2] * g[e][2][b2];
-#pragma unroll
-            for (int v = 0; v < 6; ++v) {
-                float4 o4;
-                o4.x = (float)(t1[0][0] * G6[v][0] + t1[0][1] * G6[v][1] + t1[0][2] * G6[v][2]);
-                o4.y = (float)(t1[1][0] * G6[v][0] + t1[1][1] * G6[v][1] + t1[1][2] * G6[v][2]);
-                o4.z = (float)(t1[2][0] * G6[v][0] + t1[2][1] * G6[v][1] + t1[2][2] * G6[v][2]);
-                o4.w = (float)(t1[3][0] * G6[v][0] + t1[3][1] * G6[v][1] + t1[3][2] * G6[v][2]);
-                dst[(u * 6 + v) * plane] = o4;
-            }
-        }
-    } else {
-        const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
-        float U[4][16];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            double t1[4][3];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int b2 = 0; b2 < 3; ++b2) t1[u][b2] = G[u][0] * g[e][0][b2] + G[u][1] * g[e][1][b2] + G[u][2] * g[e][2][b2];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) U[e][u * 4 + v] = (float)(t1[u][0] * G[v][0] + t1[u][1] * G[v][1] + t1[u][2] * G[v][2]);
-        }
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) dst[xi * plane] = make_float4(U[0][xi], U[1][xi], U[2][xi], U[3][xi]);
-    }
+    anoddpm::pack_conv3x3_item(w, out, N, K, mode, bwd, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
 }  // namespace

@@ -29,7 +29,7 @@ import torch
 
 from . import _lib
 from ._lib import (ChanStatsArgs, ColsumFoldArgs, GnBwdArgs, GnFinalizeArgs, HeadArgs, HeadBwdArgs, LinearArgs, LinearBwdArgs,
-                   Op, PackArgs, PosembArgs, ResampleArgs, SoftmaxArgs, SoftmaxBwdArgs, StemArgs, StemBwdArgs, TransposeArgs,
+                   Op, PackArgs, PackBatchArgs, PosembArgs, ResampleArgs, SoftmaxArgs, SoftmaxBwdArgs, StemArgs, StemBwdArgs, TransposeArgs,
                    Wgrad1Args, WgradArgs, check, lib)
 from .unet import _Plan, _posemb_freqs
 
@@ -68,9 +68,26 @@ class TrainPlan(_Plan):
         self._ws_patch = []          # (struct, field, floats) sharing one training workspace
         self._tws_need = 0
         super().__init__(model, B, S, device)
-        self.fwd_list = self.pack_ops + self.ops
+        self.fwd_list = self._batched_packs() + self.ops
         self.fwd_array = _op_array(self.fwd_list)
         self.bwd_array = _op_array(self.bops)
+
+    def _batched_packs(self):
+        """The ~270 per-weight pack launches of a forward as ONE launch (anoddpm_pack_batch: device-resident job table, a block finds
+        its job by bisection); ANODDPM_PACK_BATCH=0 keeps one launch per weight."""
+        if os.environ.get("ANODDPM_PACK_BATCH", "1") == "0" or not self.pack_ops:
+            return list(self.pack_ops)
+        jobs = (PackArgs * len(self.pack_ops))()
+        block0 = [0]
+        for i, (_, st) in enumerate(self.pack_ops):
+            ctypes.memmove(ctypes.addressof(jobs[i]), ctypes.addressof(st), ctypes.sizeof(PackArgs))
+            block0.append(block0[-1] + int(lib().anoddpm_pack_job_blocks(ctypes.byref(st))))
+        raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self.device)
+        b0 = torch.tensor(block0, dtype=torch.int32, device=self.device)
+        pb = PackBatchArgs()
+        pb.jobs, pb.block0, pb.njobs, pb.nblocks = raw.data_ptr(), b0.data_ptr(), len(self.pack_ops), block0[-1]
+        self.keep += [raw, b0, pb]
+        return [(_lib.OP_PACK_BATCH, pb)]
 
     # ------------------------------------------------------------------ parameters
     def _bind_params(self):

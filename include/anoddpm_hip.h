@@ -155,6 +155,7 @@ enum {
     ANODDPM_OP_HEAD_BWD = 24,    /* anoddpm_head_bwd_args     */
     ANODDPM_OP_COLSUM_FOLD = 25, /* anoddpm_colsum_fold_args  */
     ANODDPM_OP_ATTENTION = 26,   /* anoddpm_attention_args    */
+    ANODDPM_OP_PACK_BATCH = 27,  /* anoddpm_pack_batch_args   */
     ANODDPM_OP_MAX = 32
 };
 
@@ -570,6 +571,18 @@ typedef struct anoddpm_pack_args {
 } anoddpm_pack_args;
 
 int anoddpm_pack_weights(const anoddpm_pack_args *a, void *stream);
+
+/* All pack jobs of a model in one launch: `jobs` is a DEVICE array of njobs anoddpm_pack_args (each validated on the host the way
+ * anoddpm_pack_weights does), `block0` a DEVICE array of njobs + 1 prefix sums of anoddpm_pack_job_blocks(job) (256-thread blocks),
+ * nblocks = block0[njobs]. */
+typedef struct anoddpm_pack_batch_args {
+    const anoddpm_pack_args *jobs;
+    const int32_t *block0;
+    int32_t njobs, nblocks;
+} anoddpm_pack_batch_args;
+
+int anoddpm_pack_batch(const anoddpm_pack_batch_args *b, void *stream);
+int64_t anoddpm_pack_job_blocks(const anoddpm_pack_args *a);
 
 /* Backward of the row softmax (UNet.py:151), in place on the incoming gradient:
  *   ds[r][j] = p[r][j] * (dp[r][j] - sum_j dp[r][j] p[r][j]) */
