@@ -13,7 +13,7 @@ ABI_VERSION = 15
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 (OP_WGRAD3, OP_WGRAD1, OP_GN_BWD, OP_PACK, OP_SOFTMAX_BWD, OP_TRANSPOSE, OP_LINEAR_BWD, OP_STEM_BWD, OP_HEAD_BWD,
- OP_COLSUM_FOLD, OP_ATTENTION, OP_PACK_BATCH) = range(16, 28)
+ OP_COLSUM_FOLD, OP_ATTENTION, OP_PACK_BATCH, OP_LINEAR_BWD_BATCH) = range(16, 29)
 OP_MAX = 32
 
 
@@ -75,6 +75,11 @@ class HeadArgs(Structure):
 
 class SoftmaxArgs(Structure):
     _fields_ = [("x", c_void_p), ("rows", c_int64), ("L", c_int32)]
+
+
+class LinearBwdBatchArgs(Structure):
+    _fields_ = [("jobs", c_void_p), ("x", c_void_p), ("dx", c_void_p), ("ws", c_void_p), ("njobs", c_int32), ("max_n", c_int32),
+                ("B", c_int32), ("K", c_int32), ("act_in", c_int32), ("acc_w", c_int32), ("acc_x", c_int32)]
 
 
 class PackBatchArgs(Structure):
@@ -222,7 +227,7 @@ ANOMALY_BLOCKS = 64
 _STRUCTS = [SimplexArgs, PUpdateArgs, IgemmArgs, GnArgs, SoftmaxArgs, ResampleArgs, LinearArgs,
             PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, AnomalyArgs, VlbArgs, WgradArgs, GnBwdArgs,
             Wgrad1Args, PackArgs, SoftmaxBwdArgs, TransposeArgs, LinearBwdArgs, StemBwdArgs, HeadBwdArgs, ColsumFoldArgs,
-            MriSliceArgs, ResizeArgs, AttentionArgs, PackBatchArgs]
+            MriSliceArgs, ResizeArgs, AttentionArgs, PackBatchArgs, LinearBwdBatchArgs]
 
 # every symbol include/anoddpm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -236,7 +241,7 @@ SYMBOLS = [
     "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map", "anoddpm_vlb_terms", "anoddpm_conv3x3_wgrad", "anoddpm_gn_silu_backward", "anoddpm_pack_conv3x3",
     "anoddpm_wgrad_pointwise", "anoddpm_pack_weights", "anoddpm_softmax_rows_backward", "anoddpm_transpose_square",
     "anoddpm_linear_small_backward", "anoddpm_conv_stem_backward", "anoddpm_conv_head_backward", "anoddpm_colsum_fold",
-    "anoddpm_volume_normalise", "anoddpm_mri_slice_prepare", "anoddpm_resize_bilinear_pil", "anoddpm_attention", "anoddpm_wgrad43_groups", "anoddpm_pack_batch", "anoddpm_pack_job_blocks",
+    "anoddpm_volume_normalise", "anoddpm_mri_slice_prepare", "anoddpm_resize_bilinear_pil", "anoddpm_attention", "anoddpm_wgrad43_groups", "anoddpm_pack_batch", "anoddpm_pack_job_blocks", "anoddpm_linear_small_backward_batch",
 ]
 
 _lib = None
@@ -298,6 +303,7 @@ def lib():
     L.anoddpm_softmax_rows.argtypes = [POINTER(SoftmaxArgs), c_void_p]
     L.anoddpm_attention.argtypes = [POINTER(AttentionArgs), c_void_p]
     L.anoddpm_pack_batch.argtypes = [POINTER(PackBatchArgs), c_void_p]
+    L.anoddpm_linear_small_backward_batch.argtypes = [POINTER(LinearBwdBatchArgs), c_void_p]
     L.anoddpm_pack_job_blocks.argtypes = [POINTER(PackArgs)]
     L.anoddpm_pack_job_blocks.restype = c_int64
     L.anoddpm_resample2x.argtypes = [POINTER(ResampleArgs), c_void_p]

@@ -297,44 +297,111 @@ __global__ __launch_bounds__(1024) void linear_bwd_x_kernel(const anoddpm_linear
     }
 }
 
+// Batched form for the 42 per-block embedding projections (UNet.py:185-188): they share the input silu(temb) and were one launch in
+// the forward; their backward as separate launches was 86 launches of 8-workgroup kernels (1.5 ms per config-3 step).
+// jobs: DEVICE array of anoddpm_linear_bwd_args (w, dy, dw, db, N per job; x / B / K / act_in / acc_w taken from the batch header).
+__global__ __launch_bounds__(256) void linear_bwd_w_batch_kernel(const anoddpm_linear_bwd_batch_args h)
+{
+    anoddpm_linear_bwd_args a = h.jobs[blockIdx.y];
+    a.x = h.x; a.B = h.B; a.K = h.K; a.act_in = h.act_in; a.acc_w = h.acc_w;
+    const int K4 = a.K >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)a.N * K4) return;
+    const int k4 = (int)(idx % K4), n = (int)(idx / K4);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    float sb = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        f32x4 x = *reinterpret_cast<const f32x4 *>(a.x + (int64_t)b * a.K + k4 * 4);
+        if (a.act_in) { x[0] = silu_f(x[0]); x[1] = silu_f(x[1]); x[2] = silu_f(x[2]); x[3] = silu_f(x[3]); }
+        const float d = a.dy[(int64_t)b * a.N + n];
+        s += x * d;
+        sb += d;
+    }
+    f32x4 *o = reinterpret_cast<f32x4 *>(a.dw + (int64_t)n * a.K + k4 * 4);
+    *o = a.acc_w ? *o + s : s;
+    if (k4 == 0 && a.db) a.db[n] = a.acc_w ? a.db[n] + sb : sb;
+}
+
+// partial dx of one job: ws[job][b][k] = sum_n dy[b][n] w[n][k]   (grid (K/64, njobs), 1024 threads; as linear_bwd_x_kernel)
+template <int NB>
+__global__ __launch_bounds__(1024) void linear_bwd_x_batch_kernel(const anoddpm_linear_bwd_batch_args h)
+{
+    __shared__ float red[16][NB][64];
+    const anoddpm_linear_bwd_args a = h.jobs[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane;
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    if (k < h.K)
+#pragma unroll 8
+        for (int n = wave; n < a.N; n += 16) {
+            const float w = a.w[(int64_t)n * h.K + k];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                if (b < h.B) acc[b] += a.dy[(int64_t)b * a.N + n] * w;
+        }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) red[wave][b][lane] = acc[b];
+    __syncthreads();
+    for (int i = threadIdx.x; i < h.B * 64; i += 1024) {
+        const int b = i >> 6, l = i & 63;
+        const int kk = blockIdx.x * 64 + l;
+        if (kk >= h.K) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += red[w][b][l];
+        h.ws[((int64_t)blockIdx.y * h.B + b) * h.K + kk] = s;
+    }
+}
+
+// dx[b][k] (+)= act_in'(x) * sum over the jobs (fixed order) of their partials
+__global__ __launch_bounds__(256) void linear_bwd_x_fold_kernel(const anoddpm_linear_bwd_batch_args h)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t bk = (int64_t)h.B * h.K;
+    if (idx >= bk) return;
+    float s = 0.f;
+    for (int j = 0; j < h.njobs; ++j) s += h.ws[(int64_t)j * bk + idx];
+    if (h.act_in) s *= silu_grad(h.x[idx]);
+    h.dx[idx] = h.acc_x ? h.dx[idx] + s : s;
+}
+
 // ------------------------------------------------------------------------------------------------ column-sum fold
-// grid (ceil(N/64), B): 64 channels x 16 item lanes, eight rows in flight per thread (the Winograd-domain weight gradient emits
-// one row per 16x8 patch: 512 per image at 256^2); then a second launch folds the batch into the bias gradient.
+// grid (ceil(N/64)): 64 channels x 16 item lanes, eight rows in flight per thread (the Winograd-domain weight gradient emits one
+// row per 16x8 patch: 512 per image at 256^2); the images are walked in order, so the block also owns the batch sum = bias gradient.
 __global__ __launch_bounds__(1024) void colsum_fold_kernel(const anoddpm_colsum_fold_args a)
 {
     __shared__ float red[16][64];
     const int l = threadIdx.x & 63, il = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + l, b = blockIdx.y;
-    float s = 0.f;
-    if (n < a.N) {
-        const float *p = a.colsum + ((int64_t)b * a.ipb) * a.N + n;
-        int i = il;
-        for (; i + 7 * 16 < a.ipb; i += 8 * 16) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(i + u * 16) * a.N];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        for (; i < a.ipb; i += 16) s += p[(int64_t)i * a.N];
-    }
-    red[il][l] = s;
-    __syncthreads();
-    if (il == 0 && n < a.N) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][l];
-        a.dimg[(int64_t)b * a.N + n] = t;
-    }
-}
-
-__global__ __launch_bounds__(256) void colsum_bias_kernel(const anoddpm_colsum_fold_args a)
-{
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= a.N) return;
+    const int n = blockIdx.x * 64 + l;
     float tot = 0.f;
-    for (int b = 0; b < a.B; ++b) tot += a.dimg[(int64_t)b * a.N + n];
-    a.dbias[n] += tot;
+    for (int b = 0; b < a.B; ++b) {
+        float s = 0.f;
+        if (n < a.N) {
+            const float *p = a.colsum + ((int64_t)b * a.ipb) * a.N + n;
+            int i = il;
+            for (; i + 7 * 16 < a.ipb; i += 8 * 16) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(i + u * 16) * a.N];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+            for (; i < a.ipb; i += 16) s += p[(int64_t)i * a.N];
+        }
+        red[il][l] = s;
+        __syncthreads();
+        if (il == 0 && n < a.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][l];
+            a.dimg[(int64_t)b * a.N + n] = t;
+            tot += t;
+        }
+        __syncthreads();
+    }
+    if (il == 0 && n < a.N && a.dbias) a.dbias[n] += tot;
 }
 
 // ------------------------------------------------------------------------------------------------ stem backward
@@ -614,11 +681,28 @@ extern "C" int anoddpm_linear_small_backward(const anoddpm_linear_bwd_args *a, v
     return check_launch("linear_small_backward");
 }
 
+extern "C" int anoddpm_linear_small_backward_batch(const anoddpm_linear_bwd_batch_args *h, void *stream)
+{
+    ANODDPM_REQUIRE(h && h->jobs && h->x && h->njobs >= 1 && h->njobs <= 65535 && h->max_n >= 1, "linear_small_backward_batch: bad arguments");
+    ANODDPM_REQUIRE(h->B >= 1 && h->B <= 16 && h->K % 4 == 0 && h->K >= 4, "linear_small_backward_batch: need 1<=B<=16, K%%4==0");
+    ANODDPM_REQUIRE(!h->dx || h->ws, "linear_small_backward_batch: dx needs the partial-sum workspace [njobs][B][K]");
+    hipStream_t s = as_stream(stream);
+    const int64_t tw = (int64_t)h->max_n * (h->K / 4);
+    hipLaunchKernelGGL(linear_bwd_w_batch_kernel, dim3((unsigned)((tw + 255) / 256), (unsigned)h->njobs), dim3(256), 0, s, *h);
+    if (h->dx) {
+        const dim3 g((unsigned)((h->K + 63) / 64), (unsigned)h->njobs);
+        if (h->B <= 4) hipLaunchKernelGGL(linear_bwd_x_batch_kernel<4>, g, dim3(1024), 0, s, *h);
+        else if (h->B <= 8) hipLaunchKernelGGL(linear_bwd_x_batch_kernel<8>, g, dim3(1024), 0, s, *h);
+        else hipLaunchKernelGGL(linear_bwd_x_batch_kernel<16>, g, dim3(1024), 0, s, *h);
+        hipLaunchKernelGGL(linear_bwd_x_fold_kernel, dim3((unsigned)(((int64_t)h->B * h->K + 255) / 256)), dim3(256), 0, s, *h);
+    }
+    return check_launch("linear_small_backward_batch");
+}
+
 extern "C" int anoddpm_colsum_fold(const anoddpm_colsum_fold_args *a, void *stream)
 {
     ANODDPM_REQUIRE(a && a->colsum && a->dimg && a->B >= 1 && a->B <= 65535 && a->ipb >= 1 && a->N >= 1, "colsum_fold: bad arguments");
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((a->N + 63) / 64), (unsigned)a->B), dim3(1024), 0, as_stream(stream), *a);
-    if (a->dbias) hipLaunchKernelGGL(colsum_bias_kernel, dim3((unsigned)((a->N + 255) / 256)), dim3(256), 0, as_stream(stream), *a);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((a->N + 63) / 64)), dim3(1024), 0, as_stream(stream), *a);
     return check_launch("colsum_fold");
 }
 

@@ -29,7 +29,7 @@ import torch
 
 from . import _lib
 from ._lib import (ChanStatsArgs, ColsumFoldArgs, GnBwdArgs, GnFinalizeArgs, HeadArgs, HeadBwdArgs, LinearArgs, LinearBwdArgs,
-                   Op, PackArgs, PackBatchArgs, PosembArgs, ResampleArgs, SoftmaxArgs, SoftmaxBwdArgs, StemArgs, StemBwdArgs, TransposeArgs,
+                   LinearBwdBatchArgs, Op, PackArgs, PackBatchArgs, PosembArgs, ResampleArgs, SoftmaxArgs, SoftmaxBwdArgs, StemArgs, StemBwdArgs, TransposeArgs,
                    Wgrad1Args, WgradArgs, check, lib)
 from .unet import _Plan, _posemb_freqs
 
@@ -215,6 +215,22 @@ class TrainPlan(_Plan):
         st.acc_x = self.gacc(dx) if dx is not None else 0
         self.badd(_lib.OP_LINEAR_BWD, st)
 
+    def linear_bwd_batch(self, x, jobs, K, dx):
+        """Backward of several linear layers that share the input x (anoddpm_linear_small_backward_batch)."""
+        if not jobs:
+            return
+        arr = (LinearBwdArgs * len(jobs))()
+        for i, (wkey, bkey, dy, N) in enumerate(jobs):
+            arr[i].w, arr[i].dy, arr[i].dw, arr[i].db, arr[i].N = self.W(wkey), dy.data_ptr(), self.dW(wkey), self.dW(bkey), N
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        ws = self.buf(len(jobs) * self.B * K)
+        st = LinearBwdBatchArgs()
+        st.jobs, st.x, st.dx, st.ws = raw.data_ptr(), x.data_ptr(), dx.data_ptr(), ws.data_ptr()
+        st.njobs, st.max_n = len(jobs), max(j[3] for j in jobs)
+        st.B, st.K, st.act_in, st.acc_w, st.acc_x = self.B, K, 1, 1, self.gacc(dx)
+        self.keep.append(raw)
+        self.badd(_lib.OP_LINEAR_BWD_BATCH, st)
+
     def in_backward(self):
         """Context: igemm / resample ops emitted inside go to the backward list."""
         plan = self
@@ -359,7 +375,15 @@ class TrainPlan(_Plan):
         self.temb = temb
         g_temb, g_z1 = self.G(temb), self.G(z1)
 
+        self._emb_jobs = []          # (weight key, bias key, d_emb buffer, cout) of every ResBlock's embedding projection
+        # One batched launch for all of them at the END of the backward -- unless a data-parallel reducer is attached: every gradient
+        # bucket holds some block's embedding weights, so finishing them last would hold every all-reduce back to the end.
+        red = getattr(m, "_grad_reducer", None)
+        red = red() if red is not None else None
+        self._batch_emb = not (red is not None and red.hooks) and os.environ.get("ANODDPM_BATCH_EMB_BWD", "1") != "0"
+
         def time_bwd():
+            self.linear_bwd_batch(temb, self._emb_jobs, ted, g_temb)        # all embedding projections at once
             self.linear_bwd(z1, "time_embedding.3.weight", "time_embedding.3.bias", g_temb, ted, ted, 1, g_z1)
             self.linear_bwd(pe, "time_embedding.1.weight", "time_embedding.1.bias", g_z1, base, ted, 0, None)
         self._bw.append(time_bwd)
@@ -462,7 +486,10 @@ class TrainPlan(_Plan):
                     # 5. in_layers weight gradient; its dy column sums are the conv bias and the embedding gradients
                     d_emb = self.buf(B, cout)
                     self.wgrad3(srcs, Hin, Hout, g1, am, gh1, cout, prefix + ".in_layers.2.weight", prefix + ".in_layers.2.bias", d_emb=d_emb)
-                    self.linear_bwd(temb, prefix + ".embed_layers.1.weight", prefix + ".embed_layers.1.bias", d_emb, ted, cout, 1, g_temb)
+                    if self._batch_emb:
+                        self._emb_jobs.append((prefix + ".embed_layers.1.weight", prefix + ".embed_layers.1.bias", d_emb, cout))
+                    else:
+                        self.linear_bwd(temb, prefix + ".embed_layers.1.weight", prefix + ".embed_layers.1.bias", d_emb, ted, cout, 1, g_temb)
                     # 6-7. data gradient and the fused operand load's backward into the block inputs
                     da1 = dgrad3(gh1, Hout, cin, cout, prefix + ".in_layers.2.weight")
                     self.gn_bwd(srcs, Hin, da1, Pout, g1, prefix + ".in_layers.0", 1, am,

@@ -389,7 +389,7 @@ def run_train(c, args, cfg):
                 return 2.0 * (st.c0 + st.c1) * st.N * 9 * st.H * st.W * st.B
             names = {1: "igemm_direct", 12: "winograd_f23", 14: "winograd_f43", 3: "softmax", 4: "resample", 5: "linear", 6: "posemb", 7: "stem", 9: "chan_stats",
                      10: "gn_finalize", 11: "head", 15: "wgrad3x3_winograd", 16: "wgrad3x3_direct", 17: "wgrad_pointwise", 18: "gn_silu_backward",
-                     19: "pack_weights", 27: "pack_weights_batched", 20: "softmax_backward", 21: "transpose", 22: "linear_backward", 23: "stem_backward", 24: "head_backward",
+                     19: "pack_weights", 27: "pack_weights_batched", 28: "linear_backward_batched", 20: "softmax_backward", 21: "transpose", 22: "linear_backward", 23: "stem_backward", 24: "head_backward",
                      25: "colsum_fold", 26: "attention"}
             igs = [st for code, st in plan.ops + plan.bops if code == _lib.OP_IGEMM]
             wgs = [st for code, st in plan.bops if code == _lib.OP_WGRAD3]

@@ -156,6 +156,7 @@ enum {
     ANODDPM_OP_COLSUM_FOLD = 25, /* anoddpm_colsum_fold_args  */
     ANODDPM_OP_ATTENTION = 26,   /* anoddpm_attention_args    */
     ANODDPM_OP_PACK_BATCH = 27,  /* anoddpm_pack_batch_args   */
+    ANODDPM_OP_LINEAR_BWD_BATCH = 28, /* anoddpm_linear_bwd_batch_args */
     ANODDPM_OP_MAX = 32
 };
 
@@ -618,6 +619,20 @@ typedef struct anoddpm_linear_bwd_args {
 } anoddpm_linear_bwd_args;
 
 int anoddpm_linear_small_backward(const anoddpm_linear_bwd_args *a, void *stream);
+
+/* The same for njobs linear layers that share the input x (the per-block embedding projections, UNet.py:185-188, 213: one launch in
+ * the forward): `jobs` is a DEVICE array of anoddpm_linear_bwd_args of which w, dy, dw, db and N are read; x, B, K, act_in, acc_w
+ * come from this header.  dx (or NULL) receives act_in'(x) * sum over the jobs, folded in job order through ws [njobs][B][K]. */
+typedef struct anoddpm_linear_bwd_batch_args {
+    const anoddpm_linear_bwd_args *jobs;
+    const float *x;
+    float *dx;
+    float *ws;
+    int32_t njobs, max_n;           /* max_n: the largest N among the jobs */
+    int32_t B, K, act_in, acc_w, acc_x;
+} anoddpm_linear_bwd_batch_args;
+
+int anoddpm_linear_small_backward_batch(const anoddpm_linear_bwd_batch_args *h, void *stream);
 
 /* Backward of anoddpm_conv_stem (UNet.py:280): dw (OIHW [Cout][Cin][3][3]) += x (*) dy, db[co] += sum dy, and optionally
  * dx (NCHW) = dy (*) flipped w.  ws: >= nblk * (Cin * 9 + 1) * Cout floats with nblk = B * ceil(H*W / 1024). */
