@@ -53,7 +53,8 @@ def test_bench_line_simplex_and_training_configs():
     r = d["roofline"]
     # the dominant contraction class of the training step (forward + data-gradient F(4x4,3x3), or one of the weight-gradient
     # kernels) priced by the FLOPs the matrix pipe EXECUTES: a pipe utilisation, never above 1
-    assert ("wino" in r["kernel"] or "wgrad" in r["kernel"]) and 0 < r["frac"] <= 1.0 and r["launches_per_step"] > 20
+    # (at batch 1 the small-map GEMMs can be the largest class, at batch 4 it is the F(4x4,3x3) kernel)
+    assert any(k in r["kernel"] for k in ("wino", "wgrad", "igemm")) and 0 < r["frac"] <= 1.0 and r["launches_per_step"] > 20
     kernels = [r["kernel"]] + [k["kernel"] for k in r["other_contraction_kernels"]]
     assert any("wgrad43_kernel" in k for k in kernels) and all(0 < k["achieved"] <= r["peak"] for k in r["other_contraction_kernels"])
 
