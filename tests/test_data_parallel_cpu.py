@@ -71,6 +71,61 @@ def test_two_rank_gradient_allreduce_matches_large_batch(tmp_path):
     assert [o["range"] for o in outs] == [(0, 4), (4, 8)]
 
 
+def _worker_cut_backward(rank, world, port, out_dir):
+    """The protocol of the native training plan (train_plan.TrainPlan.run_backward): gradients are written straight into the
+    flat buffer (no autograd hooks fire) and every bucket is handed to the reducer as soon as its last gradient is final."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(123)
+    x = torch.randn(8, 1, 12, 12)
+    tgt = torch.randn(8, 1, 12, 12)
+    model = _toy()
+    flat = FlatBuffers(model)
+    red = GradAllReducer(flat, bucket_bytes=256)
+    assert model._grad_reducer() is red                      # what the plan looks up
+    lo, hi = shard_range(8, rank, world)
+    shadow = _toy()                                          # same weights, plain autograd: stands in for the HIP backward
+    (shadow(x[lo:hi]) - tgt[lo:hi]).square().mean().backward()
+    grads = [p.grad for p in shadow.parameters()]
+    logs = []
+    for step in range(2):
+        flat.zero_grad()
+        order = list(range(len(red.buckets)))                # buckets are in backward order already
+        held_back = order[-1] if step == 0 else None         # first step: leave one bucket for finish()
+        for i, b in enumerate(order):
+            for pi in red.buckets[b][2]:
+                flat.params[pi].grad.copy_(grads[pi])        # "kernels" write in place: no post-accumulate hook
+            if b != held_back:
+                red.launch_bucket(b, ops_done=10 * (i + 1))
+                red.launch_bucket(b, ops_done=-1)            # a second call for the same bucket is a no-op
+        red.finish()
+        logs.append(list(red.last_launch_log))
+    torch.save({"grad": flat.flat_grad.clone(), "logs": logs, "nb": len(red.buckets)}, os.path.join(out_dir, f"c{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_cut_backward_protocol_matches_large_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker_cut_backward, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / f"c{r}.pt") for r in range(world)]
+    torch.manual_seed(123)
+    x = torch.randn(8, 1, 12, 12)
+    tgt = torch.randn(8, 1, 12, 12)
+    model = _toy()
+    flat = FlatBuffers(model)
+    (model(x) - tgt).square().mean().backward()
+    for o in outs:
+        assert torch.allclose(o["grad"], flat.flat_grad, rtol=1e-5, atol=1e-7)
+        nb = o["nb"]
+        first, second = o["logs"]
+        # step 0: every bucket once, the held-back one launched by finish() (ops_done None); step 1: all from the cut backward, in order
+        assert sorted(b for b, _ in first) == list(range(nb)) and first[-1] == (nb - 1, None)
+        assert [b for b, _ in second] == list(range(nb)) and [d for _, d in second] == [10 * (i + 1) for i in range(nb)]
+    assert torch.equal(outs[0]["grad"], outs[1]["grad"])
+
+
 def test_shard_range_tiles_any_batch():
     for n in (0, 1, 7, 8, 32, 33):
         for world in (1, 2, 3, 8):
