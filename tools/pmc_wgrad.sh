@@ -1,0 +1,10 @@
+#!/bin/bash
+# Run ON the MI355X box: SQ counters of the two 3x3 weight-gradient kernels on the layer shapes of config 3 (tools/bench_conv.py WG=1).
+cd /tmp && export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/${1:-wgrad_pmc}
+mkdir -p $O
+WG=1 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $O/sq -o wg -- python $GRAFT_REPO_ROOT/tools/bench_conv.py > $O/sq.log 2>&1
+python $GRAFT_REPO_ROOT/tools/summarize_prof.py counter $(find $O/sq -name "*counter_collection.csv" | head -1) > $O/wgrad_sq_by_kernel.csv
+python $GRAFT_REPO_ROOT/tools/summarize_prof.py trace $(find $O/sq -name "*kernel_trace.csv" | head -1) > $O/wgrad_by_shape.csv
+rm -rf $O/sq
+grep -i "wgrad" $O/wgrad_sq_by_kernel.csv | head -40
