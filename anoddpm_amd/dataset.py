@@ -106,7 +106,13 @@ class MRIDataset(torch.utils.data.Dataset):
         self.ROOT_DIR = ROOT_DIR
         self.random_slice = random_slice
         self.augment = augment
-        self.device = torch.device(device if device is not None else "cuda:0")
+        # default: the CALLING process's current device (one process per GPU sets it with torch.cuda.set_device(local_rank));
+        # a hard-wired cuda:0 would make ranks > 0 upload their volumes to, and launch on, somebody else's GPU
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cuda:0")
+        self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
         self._vols = {}
         self._coef = {}
 
@@ -166,6 +172,10 @@ class MRIDataset(torch.utils.data.Dataset):
         if self.transform is not None:
             items = [self[i] for i in indices]
             return torch.stack([it["image"] for it in items]), [it["filenames"] for it in items]
+        with torch.cuda.device(self.device):                                 # launches go to THIS dataset's device and its stream
+            return self._get_batch_on_device(indices)
+
+    def _get_batch_on_device(self, indices):
         draws = [self._draw(i) for i in indices]
         B = len(draws)
         X, Z = draws[0][1].shape[0], draws[0][1].shape[2]
@@ -201,7 +211,8 @@ class MRIDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, idx):
         if self.transform is not None:                                       # the reference's contract: numpy slice in, anything out
-            name, vol, slice_idx, _ = self._draw(idx)
+            with torch.cuda.device(self.device):
+                name, vol, slice_idx, _ = self._draw(idx)
             image = vol[:, slice_idx:slice_idx + 1, :].reshape(vol.shape[0], vol.shape[2]).cpu().numpy()
             return {"image": self.transform(image), "filenames": name}
         out, names = self.get_batch([idx])

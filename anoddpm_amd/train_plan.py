@@ -376,11 +376,10 @@ class TrainPlan(_Plan):
         g_temb, g_z1 = self.G(temb), self.G(z1)
 
         self._emb_jobs = []          # (weight key, bias key, d_emb buffer, cout) of every ResBlock's embedding projection
-        # One batched launch for all of them at the END of the backward -- unless a data-parallel reducer is attached: every gradient
-        # bucket holds some block's embedding weights, so finishing them last would hold every all-reduce back to the end.
-        red = getattr(m, "_grad_reducer", None)
-        red = red() if red is not None else None
-        self._batch_emb = not (red is not None and red.hooks) and os.environ.get("ANODDPM_BATCH_EMB_BWD", "1") != "0"
+        # One batched launch for all of them at the END of the backward.  With a data-parallel reducer attached that is still
+        # right: training.FlatBuffers stores the embedding projections (and the timestep MLP) at the bottom of the flat buffer,
+        # so they share the last gradient bucket(s) and no other bucket's all-reduce waits for them.
+        self._batch_emb = os.environ.get("ANODDPM_BATCH_EMB_BWD", "1") != "0"
 
         def time_bwd():
             self.linear_bwd_batch(temb, self._emb_jobs, ted, g_temb)        # all embedding projections at once
@@ -681,9 +680,15 @@ class TrainPlan(_Plan):
                     self.gview[k].zero_()
         self.dy.copy_(dy.reshape(self.dy.shape))
         self.stem_bwd_args.x = x.data_ptr()
-        red = getattr(self.model, "_grad_reducer", None)
-        red = red() if red is not None else None
-        if red is not None and red.hooks and not fresh:
+        from .training import reducer_of
+        red = reducer_of(self.model)
+        if red is not None and fresh:
+            # every rank must cut its backward at the same places (the collectives are issued in bucket order): with a reducer
+            # attached the gradients are bound to the flat views before the forward (UNetModel._forward_autograd), so a
+            # missing .grad here means they were dropped between forward and backward
+            raise _lib.AnoddpmError("UNetModel training plan: .grad of some parameters was set to None between forward and backward "
+                                    "while a GradAllReducer is attached")
+        if red is not None:
             # data parallel: the op list is cut where a gradient bucket becomes final, and the bucket's all-reduce is enqueued
             # right there -- RCCL's stream picks it up behind the ops already launched and runs beside the rest of the backward
             lo = 0
@@ -710,7 +715,7 @@ class TrainPlan(_Plan):
         """[(backward op count, [bucket ids])]: after that many ops every gradient of those buckets of `red`
         (training.GradAllReducer) is final.  A parameter's gradient is final after the LAST backward stage that wrote it
         (bwd_marks); parameters no stage writes (unused) are final from the start."""
-        key = id(red)
+        key = (red.bounds, tuple(red.flat.names))      # not id(red): CPython reuses ids, a stale schedule would reduce too early
         hit = getattr(self, "_sched", None)
         if hit is not None and hit[0] == key:
             return hit[1]

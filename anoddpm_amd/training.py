@@ -28,7 +28,21 @@ import torch
 from . import _lib
 from ._lib import AdamwArgs, check, current_stream, lib, ptr
 
-__all__ = ["shard_range", "FlatBuffers", "GradAllReducer", "FusedAdamWEMA", "train_step"]
+__all__ = ["shard_range", "FlatBuffers", "GradAllReducer", "FusedAdamWEMA", "train_step", "reducer_of"]
+
+# module -> weak reference to the GradAllReducer working on its flat gradient buffer.  Kept OUTSIDE the module (a weakref stored as
+# a module attribute would break torch.save(module) / pickle for every nn.Module that is not UNetModel); the native training plan
+# looks its reducer up here to cut the backward at the bucket boundaries.
+import weakref
+
+_REDUCERS = weakref.WeakKeyDictionary()
+
+
+def reducer_of(module):
+    """The live, ACTIVE GradAllReducer attached to `module`'s flat buffers, or None."""
+    ref = _REDUCERS.get(module)
+    red = ref() if ref is not None else None
+    return red if (red is not None and red.active) else None
 
 
 def shard_range(n_items, rank, world):
@@ -42,9 +56,19 @@ class FlatBuffers:
     """Re-homes a module's parameters (and their .grad) into contiguous fp32 buffers.
 
     Parameter i occupies flat[offset_i : offset_i + numel_i]; `param.data` and `param.grad` become views,
-    so state_dict / load_state_dict / checkpoints keep working unchanged."""
+    so state_dict / load_state_dict / checkpoints keep working unchanged.
 
-    def __init__(self, module):
+    `names` / `params` keep the module's parameter order (the order torch.optim.AdamW's state_dict indexes by); the STORAGE
+    order (`layout`, ascending offsets) puts the parameters whose gradients become final last in the backward first: the
+    timestep MLP and every block's embedding projection (`late`, by default a name test).  The gradient buckets of the
+    data-parallel reducer are cut from the top of the buffer down, so those parameters share the LAST bucket(s) and the native
+    backward can finish all embedding projections in one batched launch at its very end without holding any other bucket back."""
+
+    @staticmethod
+    def _late(name):
+        return "embed_layers." in name or name.startswith("time_embedding.")
+
+    def __init__(self, module, late=None):
         self.module = module          # owner: told when a raw kernel rewrites the flat buffer (mark_weights_changed)
         self.names = [k for k, p in module.named_parameters() if p.requires_grad]
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -52,11 +76,14 @@ class FlatBuffers:
             raise ValueError("module has no trainable parameters")
         dev, dt = self.params[0].device, self.params[0].dtype
         assert dt == torch.float32 and all(p.device == dev and p.dtype == dt for p in self.params)
-        self.offsets = []
+        late = late or self._late
+        idx = range(len(self.params))
+        self.layout = [i for i in idx if late(self.names[i])] + [i for i in idx if not late(self.names[i])]
+        self.offsets = [0] * len(self.params)
         n = 0
-        for p in self.params:
-            self.offsets.append(n)
-            n += (p.numel() + 3) // 4 * 4            # keep every view 16-byte aligned
+        for i in self.layout:
+            self.offsets[i] = n
+            n += (self.params[i].numel() + 3) // 4 * 4   # keep every view 16-byte aligned
         self.numel = n
         self.flat_param = torch.zeros(n, device=dev, dtype=dt)
         self.flat_grad = torch.zeros(n, device=dev, dtype=dt)
@@ -66,35 +93,56 @@ class FlatBuffers:
                 p.data = self.flat_param[o:o + p.numel()].view(p.shape)
                 p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
 
+    def bind_grads(self):
+        """Re-attach any `.grad` that is not the flat view (optimiser.zero_grad(set_to_none=True) drops them); a re-attached
+        slice is zeroed.  Returns the number of re-attached gradients."""
+        n = 0
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                v = self.flat_grad[o:o + p.numel()].view(p.shape)
+                v.zero_()
+                p.grad = v
+                n += 1
+        return n
+
     def zero_grad(self):
         self.flat_grad.zero_()
-        for p, o in zip(self.params, self.offsets):       # optimiser.zero_grad() may have dropped the views
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
-                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+        self.bind_grads()
 
 
 class GradAllReducer:
-    """Bucketed, backward-overlapped all-reduce of `FlatBuffers.flat_grad` (mean over ranks)."""
+    """Bucketed, backward-overlapped all-reduce of `FlatBuffers.flat_grad` (mean over ranks).
 
-    def __init__(self, flat, process_group=None, bucket_bytes=64 << 20):
+    Active (hooks registered, the native backward cut at the bucket boundaries) when a process group with more than one
+    rank exists; at world size 1 every all-reduce would be a no-op that still costs its launches, so the reducer stays
+    inert unless `force=True` (tests / `ANODDPM_BENCH_FORCE_DIST=1` exercise the RCCL path on one GPU that way).
+    Backend "gloo" with device tensors (two test ranks sharing one GPU -- RCCL cannot do that) stages each bucket through
+    host memory: correct, slow, test-only."""
+
+    def __init__(self, flat, process_group=None, bucket_bytes=64 << 20, force=False):
         import torch.distributed as dist
         self.dist = dist
         self.flat = flat
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        # buckets in REVERSE parameter order (gradients arrive roughly last-layer first)
+        self.staged = bool(dist.is_initialized() and dist.get_backend(process_group) == "gloo" and flat.flat_grad.is_cuda)
+        # buckets from the TOP of the flat buffer down: storage order is roughly forward order (FlatBuffers.layout), so the
+        # gradients of the highest offsets are final first in the backward
         self.buckets = []            # (lo, hi, [param indices])
         cap = max(1, bucket_bytes // 4)
         hi, members = None, []
-        for i in reversed(range(len(flat.params))):
+        order = list(flat.layout)
+        for pos in reversed(range(len(order))):
+            i = order[pos]
             o = flat.offsets[i]
-            end = flat.offsets[i + 1] if i + 1 < len(flat.params) else flat.numel
+            end = flat.offsets[order[pos + 1]] if pos + 1 < len(order) else flat.numel
             if hi is None:
                 hi = end
             members.append(i)
-            if hi - o >= cap or i == 0:
+            if hi - o >= cap or pos == 0:
                 self.buckets.append((o, hi, members))
                 hi, members = None, []
+        self.bounds = tuple((lo, hi) for lo, hi, _ in self.buckets)
         self.bucket_of = {}
         for b, (_, _, mem) in enumerate(self.buckets):
             for i in mem:
@@ -105,12 +153,10 @@ class GradAllReducer:
         self.launched = 0            # buckets reduced by the last finish() (tests)
         self.launch_log = []         # (bucket, backward ops already enqueued or None) of the step in flight
         self.last_launch_log = []    # ... of the last finished step (tests)
+        self.active = bool(dist.is_initialized() and (self.world > 1 or force))
         if getattr(flat, "module", None) is not None:
-            import weakref
-            flat.module._grad_reducer = weakref.ref(self)     # the native training plan cuts its backward at our buckets
-        # hooks whenever a process group exists (also at world size 1: the same RCCL path runs, each all-reduce is then
-        # a device-side no-op) -- without torch.distributed the reducer is inert
-        if dist.is_initialized():
+            _REDUCERS[flat.module] = weakref.ref(self)        # the native training plan cuts its backward at our buckets
+        if self.active:
             for i, p in enumerate(flat.params):
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.reset()
@@ -137,19 +183,25 @@ class GradAllReducer:
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         view = self.flat.flat_grad[lo:hi]
-        self.works.append((self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True), view))
+        if self.staged:
+            host = view.cpu()                                  # stream-ordered copy + host sync: the bucket's kernels are done
+            self.works.append((self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True), view, host))
+        else:
+            self.works.append((self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True), view, None))
 
     def finish(self):
         """Wait for every bucket (launching any the hooks did not see) and turn sums into means."""
-        if not self.hooks:
+        if not self.active:
             return
         for b, left in enumerate(self.pending):
             if left > 0:                       # parameter unused this step: its grad is zero, still reduce
                 self.pending[b] = 0
                 self.launch_log.append((b, None))
                 self._launch(b)
-        for work, view in self.works:
+        for work, view, host in self.works:
             work.wait()
+            if host is not None:
+                view.copy_(host)
         self.launched = len(self.works)
         self.last_launch_log, self.launch_log = self.launch_log, []
         if self.world > 1:

@@ -247,8 +247,6 @@ class UNetModel(nn.Module):
         for k, v in self.__dict__.items():
             if k in ("_plans", "_tplans"):
                 new.__dict__[k] = {}
-            elif k == "_grad_reducer":             # weak reference to the ORIGINAL's data-parallel reducer: not inherited
-                continue
             else:
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new
@@ -257,7 +255,6 @@ class UNetModel(nn.Module):
         d = dict(self.__dict__)
         d["_plans"] = {}
         d["_tplans"] = {}
-        d.pop("_grad_reducer", None)
         return d
 
     # ------------------------------------------------------------------ forward
@@ -316,6 +313,10 @@ class UNetModel(nn.Module):
             from . import train_plan
             params = list(self.parameters())
             if train_plan.eligible(self, x.shape[0], x.shape[2]) and all(p.requires_grad for p in params):
+                from .training import reducer_of
+                red = reducer_of(self)
+                if red is not None:
+                    red.flat.bind_grads()      # data parallel: gradients live in the flat views on EVERY rank -> same cut backward
                 plan = self._train_plan_for(x.shape[0], x.shape[2], x.device, x.requires_grad)
                 return train_plan.TrainPlanFunction.apply(x, time, params[0], plan)
         sd = dict(self.named_parameters())

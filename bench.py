@@ -171,23 +171,58 @@ class Ctx:
     pass
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: re-exec under `torch.distributed.run` with one rank per
+    GPU (the same command line the driver uses for its scaling runs).  Fewer visible devices than ranks is an error, never a
+    silent single-rank run -- except with ANODDPM_BENCH_SHARE_GPU=1 (tests on a 1-GPU box: the ranks share the devices
+    round-robin and talk over gloo, because RCCL cannot place two ranks on one device)."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < args.gpus and os.environ.get("ANODDPM_BENCH_SHARE_GPU") != "1":
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} HIP device(s) visible; refusing to run fewer ranks than asked for")
+    if ndev == 0:
+        raise SystemExit("bench.py needs an MI355X (HIP) device; there is no CPU fallback for the product path")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def setup_dist(args):
     c = Ctx()
     c.world = int(os.environ.get("WORLD_SIZE", "1"))
     c.rank = int(os.environ.get("RANK", "0"))
     c.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     c.dist = None
+    if c.world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={c.world} ranks")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (HIP) device; there is no CPU fallback for the product path")
+    ndev = torch.cuda.device_count()
+    c.shared = False
+    if c.local_rank >= ndev:
+        if os.environ.get("ANODDPM_BENCH_SHARE_GPU") != "1":
+            raise SystemExit(f"bench.py: rank {c.rank} has no device of its own ({ndev} visible for {c.world} ranks)")
+        c.shared = True
+    c.shared = c.shared or (c.world > ndev)
+    dev_index = c.local_rank % ndev
     if c.world > 1 or os.environ.get("ANODDPM_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", c.local_rank), rank=c.rank, world_size=c.world)
+        if c.shared:
+            dist.init_process_group("gloo", rank=c.rank, world_size=c.world)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), rank=c.rank, world_size=c.world)
         c.dist = dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (HIP) device; there is no CPU fallback for the product path")
-    torch.cuda.set_device(c.local_rank)
-    c.dev = torch.device("cuda", c.local_rank)
+    torch.cuda.set_device(dev_index)
+    c.dev = torch.device("cuda", dev_index)
     return c
 
 
@@ -207,7 +242,7 @@ def timed(c, args, step_fn):
     elapsed = time.perf_counter() - t0
     if c.dist is not None:
         c.dist.barrier()
-        el = torch.tensor([elapsed], device=c.dev, dtype=torch.float64)
+        el = torch.tensor([elapsed], device=("cpu" if c.shared else c.dev), dtype=torch.float64)
         c.dist.all_reduce(el, op=c.dist.ReduceOp.MAX)
         elapsed = el.item()
     return elapsed
@@ -355,7 +390,7 @@ def run_train(c, args, cfg):
     model.to(c.dev).train()
     ema = copy.deepcopy(model)
     flat, flat_ema = FlatBuffers(model), FlatBuffers(ema)
-    reducer = GradAllReducer(flat) if c.dist is not None else None
+    reducer = GradAllReducer(flat, force=True) if c.dist is not None else None
     opt = FusedAdamWEMA(flat, flat_ema, lr=1e-4, weight_decay=0.0)
     diff = GD.GaussianDiffusionModel([cfg["img"]] * 2, GD.get_beta_schedule(T_STEPS, "linear"), noise="simplex")
     targs = {"train_start": True, "sample_distance": 800, "Batch_Size": B}
@@ -519,6 +554,10 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--dump-plan", default="", help="write the igemm launch list of the compiled plan (JSON) here")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
     c = setup_dist(args)
     cfg = dict(CONFIGS[args.config])
     run = {"reverse": run_reverse, "train": run_train, "simplex": run_simplex}[cfg["kind"]]
@@ -527,6 +566,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": out.pop("ms_per_step"), "higher_is_better": True,
             "scaling": out.pop("scaling"), "vs_baseline": None, "dtype": out.pop("dtype"), "data": "synthetic",
             "config": out.pop("config")}
+    if c.shared:
+        # test-only layout (ANODDPM_BENCH_SHARE_GPU=1): the ranks do NOT each own a GPU, so this is not a scaling point
+        line["config"]["ranks_share_devices"] = True
     if roofline:
         line["roofline"] = roofline
     if c.rank == 0 and c.world == 1 and not args.no_cpu_baseline:

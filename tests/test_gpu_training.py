@@ -286,7 +286,7 @@ def test_rccl_world_size_1_reducer_with_native_backward():
             model = copy.deepcopy(base)
             flat = FlatBuffers(model)
             opt = FusedAdamWEMA(flat, None, lr=1e-3)
-            red = GradAllReducer(flat, bucket_bytes=1 << 20) if use_reducer else None
+            red = GradAllReducer(flat, bucket_bytes=1 << 20, force=True) if use_reducer else None
             if red is not None:
                 assert len(red.buckets) > 3 and len(red.hooks) == len(flat.params)
             torch.manual_seed(77)                                  # same t draw inside p_loss
