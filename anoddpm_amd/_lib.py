@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 (OP_WGRAD3, OP_WGRAD1, OP_GN_BWD, OP_PACK, OP_SOFTMAX_BWD, OP_TRANSPOSE, OP_LINEAR_BWD, OP_STEM_BWD, OP_HEAD_BWD,
@@ -144,6 +144,15 @@ class VlbArgs(Structure):
                 ("n", c_int64), ("B", c_int32), ("T", c_int32)]
 
 
+class LossArgs(Structure):
+    _fields_ = [("eps", c_void_p), ("noise", c_void_p), ("x0", c_void_p), ("xt", c_void_p), ("t", c_void_p), ("weights", c_void_p),
+                ("c_recip", c_void_p), ("c_recipm1", c_void_p), ("c_coef1", c_void_p), ("c_coef2", c_void_p),
+                ("c_post_logvar", c_void_p), ("c_model_logvar", c_void_p),
+                ("per_sample", c_void_p), ("vlb", c_void_p), ("total", c_void_p), ("workspace", c_void_p), ("workspace_doubles", c_int64),
+                ("g_per", c_void_p), ("g_vlb", c_void_p), ("g_total", c_void_p), ("d_eps", c_void_p),
+                ("n", c_int64), ("B", c_int32), ("T", c_int32), ("kind", c_int32)]
+
+
 class WgradArgs(Structure):
     _fields_ = [("a0", c_void_p), ("a1", c_void_p), ("gn_scale", c_void_p), ("gn_shift", c_void_p), ("dy", c_void_p),
                 ("dw", c_void_p), ("ws", c_void_p), ("ws_floats", c_int64),
@@ -227,7 +236,7 @@ ANOMALY_BLOCKS = 64
 _STRUCTS = [SimplexArgs, PUpdateArgs, IgemmArgs, GnArgs, SoftmaxArgs, ResampleArgs, LinearArgs,
             PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, AnomalyArgs, VlbArgs, WgradArgs, GnBwdArgs,
             Wgrad1Args, PackArgs, SoftmaxBwdArgs, TransposeArgs, LinearBwdArgs, StemBwdArgs, HeadBwdArgs, ColsumFoldArgs,
-            MriSliceArgs, ResizeArgs, AttentionArgs, PackBatchArgs, LinearBwdBatchArgs]
+            MriSliceArgs, ResizeArgs, AttentionArgs, PackBatchArgs, LinearBwdBatchArgs, LossArgs]
 
 # every symbol include/anoddpm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -242,6 +251,7 @@ SYMBOLS = [
     "anoddpm_wgrad_pointwise", "anoddpm_pack_weights", "anoddpm_softmax_rows_backward", "anoddpm_transpose_square",
     "anoddpm_linear_small_backward", "anoddpm_conv_stem_backward", "anoddpm_conv_head_backward", "anoddpm_colsum_fold",
     "anoddpm_volume_normalise", "anoddpm_mri_slice_prepare", "anoddpm_resize_bilinear_pil", "anoddpm_attention", "anoddpm_wgrad43_groups", "anoddpm_pack_batch", "anoddpm_pack_job_blocks", "anoddpm_linear_small_backward_batch",
+    "anoddpm_loss_forward", "anoddpm_loss_backward",
 ]
 
 _lib = None
@@ -319,6 +329,8 @@ def lib():
     L.anoddpm_sumsq.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
     L.anoddpm_anomaly_map.argtypes = [POINTER(AnomalyArgs), c_void_p]
     L.anoddpm_vlb_terms.argtypes = [POINTER(VlbArgs), c_void_p]
+    L.anoddpm_loss_forward.argtypes = [POINTER(LossArgs), c_void_p]
+    L.anoddpm_loss_backward.argtypes = [POINTER(LossArgs), c_void_p]
     L.anoddpm_conv3x3_wgrad.argtypes = [POINTER(WgradArgs), c_void_p]
     L.anoddpm_wgrad43_groups.argtypes = [c_int32] * 5
     L.anoddpm_gn_silu_backward.argtypes = [POINTER(GnBwdArgs), c_void_p]

@@ -71,7 +71,7 @@ extern "C" int anoddpm_debug_set(int32_t key, int32_t value)
     return ANODDPM_OK;
 }
 
-extern "C" int anoddpm_abi_version(void) { return 15; }
+extern "C" int anoddpm_abi_version(void) { return 16; }
 
 extern "C" const char *anoddpm_last_error(void) { return g_err; }
 
@@ -189,6 +189,7 @@ extern "C" int anoddpm_struct_size(int32_t which)
         case 29: return (int)sizeof(anoddpm_attention_args);
         case 30: return (int)sizeof(anoddpm_pack_batch_args);
         case 31: return (int)sizeof(anoddpm_linear_bwd_batch_args);
+        case 32: return (int)sizeof(anoddpm_loss_args);
         default: return -1;
     }
 }

@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import PUpdateArgs, VlbArgs, check, current_stream, lib, ptr
+from ._lib import LossArgs, PUpdateArgs, VlbArgs, check, current_stream, lib, ptr
 from .simplex import Simplex_CLASS, perm_tables
 
 __all__ = ["SimplexNoiseFn", "ReverseChain", "get_beta_schedule", "extract", "mean_flat", "normal_kl", "approx_standard_normal_cdf",
@@ -57,38 +57,44 @@ def get_beta_schedule(num_diffusion_steps, name="cosine"):
 def extract(arr, timesteps, broadcast_shape, device):
     """GaussianDiffusion.py:32-36: gather in fp64, then cast to fp32, broadcast to `broadcast_shape`."""
     res = torch.from_numpy(np.asarray(arr)).to(device=timesteps.device)[timesteps].float()
-    while len(res.shape) < len(broadcast_shape):
-        res = res[..., None]
-    return res.expand(broadcast_shape).to(device)
+    return res.reshape(res.shape + (1,) * (len(broadcast_shape) - res.dim())).expand(broadcast_shape).to(device)
 
 
 def mean_flat(tensor):
-    return torch.mean(tensor, dim=list(range(1, len(tensor.shape))))
+    """GaussianDiffusion.py:39-40: mean over everything but the batch dimension."""
+    if tensor.dim() < 2:
+        return torch.mean(tensor, dim=[])                        # what the reference's empty dim list does
+    return tensor.reshape(tensor.shape[0], -1).mean(dim=1)
 
 
 def normal_kl(mean1, logvar1, mean2, logvar2):
-    """KL(N(mean1, e^logvar1) || N(mean2, e^logvar2)) -- GaussianDiffusion.py:43-53."""
-    return 0.5 * (-1 + logvar2 - logvar1 + torch.exp(logvar1 - logvar2) + ((mean1 - mean2) ** 2) * torch.exp(-logvar2))
+    """KL(N(mean1, e^logvar1) || N(mean2, e^logvar2)) in nats, elementwise (GaussianDiffusion.py:43-53).  API surface only: the
+    training / logging paths evaluate this inside anoddpm_vlb_terms / anoddpm_loss_forward."""
+    dl = logvar2 - logvar1
+    return 0.5 * (dl - 1.0 + torch.exp(-dl) + torch.exp(-logvar2) * (mean1 - mean2) ** 2)
+
+
+_SQRT_2_OVER_PI = float(np.sqrt(2.0 / np.pi))
 
 
 def approx_standard_normal_cdf(x):
-    return 0.5 * (1.0 + torch.tanh(np.sqrt(2.0 / np.pi) * (x + 0.044715 * torch.pow(x, 3))))
+    """tanh approximation of the standard normal CDF (GaussianDiffusion.py:56-61)."""
+    return 0.5 * (1.0 + torch.tanh(_SQRT_2_OVER_PI * (x + 0.044715 * x * x * x)))
 
 
 def discretised_gaussian_log_likelihood(x, means, log_scales):
-    """GaussianDiffusion.py:64-93."""
-    assert x.shape == means.shape == log_scales.shape
-    centered = x - means
-    inv_std = torch.exp(-log_scales)
-    cdf_plus = approx_standard_normal_cdf(inv_std * (centered + 1.0 / 255.0))
-    cdf_min = approx_standard_normal_cdf(inv_std * (centered - 1.0 / 255.0))
-    log_cdf_plus = torch.log(cdf_plus.clamp(min=1e-12))
-    log_one_minus_cdf_min = torch.log((1.0 - cdf_min).clamp(min=1e-12))
-    cdf_delta = cdf_plus - cdf_min
-    log_probs = torch.where(x < -0.999, log_cdf_plus,
-                            torch.where(x > 0.999, log_one_minus_cdf_min, torch.log(cdf_delta.clamp(min=1e-12))))
-    assert log_probs.shape == x.shape
-    return log_probs
+    """log-likelihood of a Gaussian discretised to 8-bit bins of width 2/255 on [-1, 1], open-ended at +-1
+    (GaussianDiffusion.py:64-93).  API surface only (see normal_kl)."""
+    if not (x.shape == means.shape == log_scales.shape):
+        raise AssertionError("discretised_gaussian_log_likelihood: shape mismatch")
+    z = torch.exp(-log_scales)
+    upper = approx_standard_normal_cdf(z * (x - means + 1.0 / 255.0))
+    lower = approx_standard_normal_cdf(z * (x - means - 1.0 / 255.0))
+    floor = 1e-12
+    inner = torch.log((upper - lower).clamp(min=floor))
+    left = torch.log(upper.clamp(min=floor))                     # x at the lower edge: everything below counts
+    right = torch.log((1.0 - lower).clamp(min=floor))            # x at the upper edge: everything above counts
+    return torch.where(x < -0.999, left, torch.where(x > 0.999, right, inner))
 
 
 def generate_simplex_noise(Simplex_instance, x, t, random_param=False, octave=6, persistence=0.8, frequency=64,
@@ -265,6 +271,78 @@ class _DeviceTables:
         self.sigma = torch.exp(0.5 * torch.from_numpy(model_logvar).float()).to(device)
 
 
+class _FusedLoss(torch.autograd.Function):
+    """(per-sample loss [B], vlb [B], weighted batch mean []) of calc_loss / p_loss from the model output, and in backward the
+    gradient with respect to the model output -- anoddpm_loss_forward / anoddpm_loss_backward.  kind: 0 l1, 1 l2, 2 hybrid,
+    3 = the VLB term alone (calc_vlb_xt).  Only `eps` is differentiable."""
+
+    @staticmethod
+    def _args(owner, eps, noise, x0, xt, t, weights, kind):
+        tb = owner._tables(eps.device)
+        a = LossArgs()
+        a.eps, a.noise = ptr(eps), ptr(noise if noise is not None else eps)
+        a.weights = ptr(weights) if weights is not None else None
+        if kind >= 2:
+            a.x0, a.xt, a.t = ptr(x0), ptr(xt), ptr(t)
+            a.c_recip, a.c_recipm1 = ptr(tb.sqrt_recip_alphas_cumprod), ptr(tb.sqrt_recipm1_alphas_cumprod)
+            a.c_coef1, a.c_coef2 = ptr(tb.posterior_mean_coef1), ptr(tb.posterior_mean_coef2)
+            a.c_post_logvar, a.c_model_logvar = ptr(tb.posterior_log_variance_clipped), ptr(tb.model_log_variance)
+        B = eps.shape[0]
+        a.n, a.B, a.T, a.kind = (eps[0].numel() if B else 0), B, owner.num_timesteps, min(kind, 2)
+        return a
+
+    @staticmethod
+    def forward(ctx, eps, noise, x0, xt, t, weights, owner, kind):
+        _lib.require_cuda(eps, "GaussianDiffusionModel loss")
+        f32 = owner._f32
+        e = f32(eps.detach())
+        nz = f32(noise.detach()) if noise is not None else None
+        x0c, xtc, tt = (f32(x0.detach()), f32(xt.detach()), owner._t64(t, e.device)) if kind >= 2 else (None, None, None)
+        w = f32(weights.detach().to(e.device)) if weights is not None else None
+        B = e.shape[0]
+        out = torch.empty((2 * B + 1,), dtype=torch.float32, device=e.device)
+        ws = torch.empty((max(B, 1) * 64 * 2,), dtype=torch.float64, device=e.device)
+        a = _FusedLoss._args(owner, e, nz, x0c, xtc, tt, w, kind)
+        a.per_sample, a.vlb, a.total = ptr(out[:B]), ptr(out[B:2 * B]), ptr(out[2 * B:])
+        a.workspace, a.workspace_doubles = ptr(ws), ws.numel()
+        if B:
+            check(lib().anoddpm_loss_forward(ctypes.byref(a), current_stream()), "loss_forward")
+        ctx.owner, ctx.kind, ctx.saved = owner, kind, (e, nz, x0c, xtc, tt, w)
+        ctx.set_materialize_grads(False)
+        per, vlb, total = out[:B], out[B:2 * B], out[2 * B]
+        if kind == 3:
+            # the VLB term alone: the fused kernel's per-sample value is vlb + mse(eps, eps) = vlb
+            return per, vlb, total
+        return per, vlb, total
+
+    @staticmethod
+    def backward(ctx, g_per, g_vlb, g_total):
+        e, nz, x0c, xtc, tt, w = ctx.saved
+        kind = ctx.kind
+        a = _FusedLoss._args(ctx.owner, e, nz, x0c, xtc, tt, w, kind)
+        keep = []
+
+        def dev(g):
+            if g is None:
+                return None
+            g = g.detach().float().contiguous()
+            keep.append(g)
+            return ptr(g)
+        if kind == 3:
+            # per == vlb here (no main term): fold both upstream gradients into g_vlb, and leave the main-term coefficient at zero
+            gv = g_vlb if g_per is None else (g_per if g_vlb is None else g_per + g_vlb)
+            a.g_per, a.g_vlb, a.g_total = None, dev(gv), None
+            if g_total is not None:
+                raise _lib.AnoddpmError("calc_vlb_xt: only the per-sample output is differentiable")
+        else:
+            a.g_per, a.g_vlb, a.g_total = dev(g_per), dev(g_vlb), dev(g_total)
+        d = torch.empty_like(e)
+        a.d_eps = ptr(d)
+        if e.shape[0]:
+            check(lib().anoddpm_loss_backward(ctypes.byref(a), current_stream()), "loss_backward")
+        return d, None, None, None, None, None, None, None
+
+
 class GaussianDiffusionModel:
     def __init__(self, img_size, betas, img_channels=1, loss_type="l2", loss_weight='none', noise="gauss"):
         super().__init__()
@@ -364,45 +442,49 @@ class GaussianDiffusionModel:
 
     # ------------------------------------------------------------------ reference API
     def sample_t_with_weights(self, b_size, device):
-        p = self.weights / np.sum(self.weights)
-        indices_np = np.random.choice(len(p), size=b_size, p=p)
-        indices = torch.from_numpy(indices_np).long().to(device)
-        weights_np = 1 / len(p) * p[indices_np]
-        weights = torch.from_numpy(weights_np).float().to(device)
-        return indices, weights
+        """GaussianDiffusion.py:220-226: timesteps drawn with probability proportional to `self.weights` from the global numpy
+        stream, plus the importance weights p[t] / T (fp64 product, then fp32)."""
+        prob = self.weights / np.sum(self.weights)
+        drawn = np.random.choice(prob.size, size=b_size, p=prob)
+        return (torch.from_numpy(drawn).long().to(device),
+                torch.from_numpy(1 / prob.size * prob[drawn]).float().to(device))
+
+    def _at(self, table, t, like):
+        """extract() on a host table: gather in fp64, cast, shape [B,1,...] broadcastable against `like`."""
+        return extract(table, t, like.shape, like.device)
 
     def predict_x_0_from_eps(self, x_t, t, eps):
-        return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape, x_t.device) * x_t
-                - extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape, x_t.device) * eps)
+        """GaussianDiffusion.py:228-230 (differentiable API form; the sampling path fuses it into anoddpm_p_sample_update)."""
+        a, b = self._at(self.sqrt_recip_alphas_cumprod, t, x_t), self._at(self.sqrt_recipm1_alphas_cumprod, t, x_t)
+        return a * x_t - b * eps
 
     def predict_eps_from_x_0(self, x_t, t, pred_x_0):
-        return (extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape, x_t.device) * x_t - pred_x_0) \
-               / extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape, x_t.device)
+        """GaussianDiffusion.py:232-235."""
+        a, b = self._at(self.sqrt_recip_alphas_cumprod, t, x_t), self._at(self.sqrt_recipm1_alphas_cumprod, t, x_t)
+        return (a * x_t - pred_x_0) / b
 
     def q_mean_variance(self, x_0, t):
-        mean = extract(self.sqrt_alphas_cumprod, t, x_0.shape, x_0.device) * x_0
-        variance = extract(1.0 - self.alphas_cumprod, t, x_0.shape, x_0.device)
-        log_variance = extract(self.log_one_minus_alphas_cumprod, t, x_0.shape, x_0.device)
-        return mean, variance, log_variance
+        """q(x_t | x_0): mean, variance, log-variance (GaussianDiffusion.py:237-251)."""
+        return (self._at(self.sqrt_alphas_cumprod, t, x_0) * x_0, self._at(1.0 - self.alphas_cumprod, t, x_0),
+                self._at(self.log_one_minus_alphas_cumprod, t, x_0))
 
     def q_posterior_mean_variance(self, x_0, x_t, t):
-        posterior_mean = (extract(self.posterior_mean_coef1, t, x_t.shape, x_t.device) * x_0
-                          + extract(self.posterior_mean_coef2, t, x_t.shape, x_t.device) * x_t)
-        posterior_var = extract(self.posterior_variance, t, x_t.shape, x_t.device)
-        posterior_log_var_clipped = extract(self.posterior_log_variance_clipped, t, x_t.shape, x_t.device)
-        return posterior_mean, posterior_var, posterior_log_var_clipped
+        """q(x_{t-1} | x_t, x_0): mean, variance, clipped log-variance (GaussianDiffusion.py:253-267)."""
+        c1, c2 = self._at(self.posterior_mean_coef1, t, x_t), self._at(self.posterior_mean_coef2, t, x_t)
+        return (c1 * x_0 + c2 * x_t, self._at(self.posterior_variance, t, x_t),
+                self._at(self.posterior_log_variance_clipped, t, x_t))
 
     def p_mean_variance(self, model, x_t, t, estimate_noise=None):
         """GaussianDiffusion.py:269-296; mean / pred_x_0 come from the fused update kernel."""
         if estimate_noise is None:
             estimate_noise = model(x_t, t)
-        if x_t.requires_grad or estimate_noise.requires_grad:
-            # differentiable form (hybrid loss, :413) -- same expressions on device tensors
-            model_var = np.append(self.posterior_variance[1], self.betas[1:])
-            pred_x_0 = self.predict_x_0_from_eps(x_t, t, estimate_noise).clamp(-1, 1)
-            model_mean, _, _ = self.q_posterior_mean_variance(pred_x_0, x_t, t)
-            return {"mean": model_mean, "variance": extract(model_var, t, x_t.shape, x_t.device),
-                    "log_variance": extract(np.log(model_var), t, x_t.shape, x_t.device), "pred_x_0": pred_x_0}
+        if torch.is_grad_enabled() and (x_t.requires_grad or estimate_noise.requires_grad):
+            # differentiable API form (the training losses do not come through here: anoddpm_loss_backward carries the VLB
+            # term's gradient); fixed-large variance of :282-283
+            fixed_var = np.append(self.posterior_variance[1], self.betas[1:])
+            pred_x_0 = torch.clamp(self.predict_x_0_from_eps(x_t, t, estimate_noise), -1, 1)
+            return {"mean": self.q_posterior_mean_variance(pred_x_0, x_t, t)[0], "variance": self._at(fixed_var, t, x_t),
+                    "log_variance": self._at(np.log(fixed_var), t, x_t), "pred_x_0": pred_x_0}
         tb = self._tables(x_t.device)
         tt = self._t64(t, x_t.device)
         _, pred, mean = self._reverse_update(x_t, tt, estimate_noise, None, want_pred=True, want_mean=True)
@@ -477,9 +559,8 @@ class GaussianDiffusionModel:
 
     def sample_q(self, x_0, t, noise):
         """q(x_t | x_0), GaussianDiffusion.py:361-371 -- one fused launch."""
-        if x_0.requires_grad or noise.requires_grad:
-            return (extract(self.sqrt_alphas_cumprod, t, x_0.shape, x_0.device) * x_0 +
-                    extract(self.sqrt_one_minus_alphas_cumprod, t, x_0.shape, x_0.device) * noise)
+        if torch.is_grad_enabled() and (x_0.requires_grad or noise.requires_grad):
+            return self._at(self.sqrt_alphas_cumprod, t, x_0) * x_0 + self._at(self.sqrt_one_minus_alphas_cumprod, t, x_0) * noise
         _lib.require_cuda(x_0, "GaussianDiffusionModel.sample_q")
         tb = self._tables(x_0.device)
         return self._axpby(tb.sqrt_alphas_cumprod, tb.sqrt_one_minus_alphas_cumprod, x_0, t, noise)
@@ -516,56 +597,56 @@ class GaussianDiffusionModel:
         return out[0], out[1], out[2], pred
 
     def calc_vlb_xt(self, model, x_0, x_t, t, estimate_noise=None):
-        """GaussianDiffusion.py:384-397.  Without autograd (calc_total_vlb, logging) the whole term is one fused
-        launch after the model call; with autograd recording (the hybrid loss) it stays differentiable torch ops."""
-        if not torch.is_grad_enabled():
-            eps = model(x_t, t) if estimate_noise is None else estimate_noise
-            vlb, _, _, pred = self.vlb_terms(x_0, x_t, t, eps)
+        """GaussianDiffusion.py:384-397: KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) or, at t = 0, the discretised decoder NLL, in
+        bits per dimension -- one fused launch after the model call (anoddpm_vlb_terms).  With autograd recording the term is
+        differentiable with respect to the model output (anoddpm_loss_backward); `pred_x_0` is returned detached."""
+        eps = model(x_t, t) if estimate_noise is None else estimate_noise
+        if torch.is_grad_enabled() and eps.requires_grad:
+            _, vlb, _ = _FusedLoss.apply(eps, None, x_0, x_t, t, None, self, 3)
+            with torch.no_grad():
+                pred = self._reverse_update(x_t, t, eps, None, want_pred=True)[1]
             return {"output": vlb, "pred_x_0": pred}
-        true_mean, _, true_log_var = self.q_posterior_mean_variance(x_0, x_t, t)
-        output = self.p_mean_variance(model, x_t, t, estimate_noise)
-        kl = normal_kl(true_mean, true_log_var, output["mean"], output["log_variance"])
-        kl = mean_flat(kl) / np.log(2.0)
-        decoder_nll = -discretised_gaussian_log_likelihood(x_0, output["mean"], log_scales=0.5 * output["log_variance"])
-        decoder_nll = mean_flat(decoder_nll) / np.log(2.0)
-        nll = torch.where((t == 0), decoder_nll, kl)
-        return {"output": nll, "pred_x_0": output["pred_x_0"]}
+        vlb, _, _, pred = self.vlb_terms(x_0, x_t, t, eps)
+        return {"output": vlb, "pred_x_0": pred}
 
-    def calc_loss(self, model, x_0, t):
+    _LOSS_KINDS = {"l1": 0, "l2": 1, "hybrid": 2}
+
+    def _loss_terms(self, model, x_0, t, weights=None):
+        """calc_loss + the weighted batch mean of p_loss: noise draw, q-sample, model call, then ONE fused launch (+ fold) for the
+        per-sample terms and the scalar; its autograd backward is one more launch producing d(loss)/d(eps)."""
         noise = self.noise_fn(x_0, t).float()
         x_t = self.sample_q(x_0, t, noise)
-        estimate_noise = model(x_t, t)
-        loss = {}
-        if self.loss_type == "l1":
-            loss["loss"] = mean_flat((estimate_noise - noise).abs())
-        elif self.loss_type == "l2":
-            loss["loss"] = mean_flat((estimate_noise - noise).square())
-        elif self.loss_type == "hybrid":
-            loss["vlb"] = self.calc_vlb_xt(model, x_0, x_t, t, estimate_noise)["output"]
-            loss["loss"] = loss["vlb"] + mean_flat((estimate_noise - noise).square())
-        else:
-            loss["loss"] = mean_flat((estimate_noise - noise).square())
-        return loss, x_t, estimate_noise
+        eps = model(x_t, t)
+        kind = self._LOSS_KINDS.get(self.loss_type, 1)           # unknown strings mean l2, as upstream's final else (:415-416)
+        per, vlb, total = _FusedLoss.apply(eps, noise, x_0, x_t, t, weights, self, kind)
+        terms = {"loss": per}
+        if kind == 2:
+            terms = {"vlb": vlb, "loss": per}
+        return terms, x_t, eps, total
+
+    def calc_loss(self, model, x_0, t):
+        """GaussianDiffusion.py:399-417 -> (loss dict, x_t, estimate_noise)."""
+        terms, x_t, eps, _ = self._loss_terms(model, x_0, t)
+        return terms, x_t, eps
 
     def p_loss(self, model, x_0, args):
+        """GaussianDiffusion.py:419-434: draws t (torch.randint, or the weighted numpy draw), returns
+        (mean over the batch of loss * weights, (loss dict, x_t, estimate_noise))."""
+        B = x_0.shape[0]
         if self.loss_weight == "none":
-            if args["train_start"]:
-                t = torch.randint(0, min(args["sample_distance"], self.num_timesteps), (x_0.shape[0],), device=x_0.device)
-            else:
-                t = torch.randint(0, self.num_timesteps, (x_0.shape[0],), device=x_0.device)
-            weights = 1
+            hi = min(args["sample_distance"], self.num_timesteps) if args["train_start"] else self.num_timesteps
+            t, weights = torch.randint(0, hi, (B,), device=x_0.device), None
         else:
-            t, weights = self.sample_t_with_weights(x_0.shape[0], x_0.device)
-        loss, x_t, eps_t = self.calc_loss(model, x_0, t)
-        loss = ((loss["loss"] * weights).mean(), (loss, x_t, eps_t))
-        return loss
+            t, weights = self.sample_t_with_weights(B, x_0.device)
+        terms, x_t, eps, total = self._loss_terms(model, x_0, t, weights)
+        return total, (terms, x_t, eps)
 
     def prior_vlb(self, x_0, args):
-        t = torch.tensor([self.num_timesteps - 1] * args["Batch_Size"], device=x_0.device)
-        qt_mean, _, qt_log_variance = self.q_mean_variance(x_0, t)
-        kl_prior = normal_kl(mean1=qt_mean, logvar1=qt_log_variance, mean2=torch.tensor(0.0, device=x_0.device),
-                             logvar2=torch.tensor(0.0, device=x_0.device))
-        return mean_flat(kl_prior) / np.log(2.0)
+        """GaussianDiffusion.py:436-443: KL(q(x_T | x_0) || N(0, I)) in bits per dimension."""
+        t = torch.full((args["Batch_Size"],), self.num_timesteps - 1, device=x_0.device, dtype=torch.int64)
+        mean, _, logvar = self.q_mean_variance(x_0, t)
+        zero = torch.zeros((), device=x_0.device)
+        return mean_flat(normal_kl(mean, logvar, zero, zero)) / np.log(2.0)
 
     def calc_total_vlb(self, x_0, model, args):
         """GaussianDiffusion.py:445-478: T model calls; everything after each call (KL / decoder NLL, the two MSE

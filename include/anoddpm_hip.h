@@ -458,6 +458,35 @@ typedef struct anoddpm_vlb_args {
 
 int anoddpm_vlb_terms(const anoddpm_vlb_args *a, void *stream);
 
+/* Training loss of one batch and its gradient (GaussianDiffusion.py:399-417 calc_loss, :419-434 p_loss; the hybrid loss's
+ * VLB term is calc_vlb_xt :384-397):
+ *   kind 0 (l1):  per_sample[b] = mean_flat(|eps - noise|)
+ *   kind 1 (l2):  per_sample[b] = mean_flat((eps - noise)^2)
+ *   kind 2 (hybrid): vlb[b] as anoddpm_vlb_terms' out[0]; per_sample[b] = vlb[b] + mean_flat((eps - noise)^2)
+ *   total[0] = mean_b(per_sample[b] * weights[b])                          (weights NULL = 1: loss_weight "none")
+ * anoddpm_loss_backward writes d_eps[b][i] = d( sum_b g_per[b] per_sample[b] + sum_b g_vlb[b] vlb[b] + g_total total ) / d eps[b][i]
+ * (each upstream gradient may be NULL = 0) -- the tensor loss.backward() hands to the UNet's backward.
+ * Element math fp32, per-sample sums fp64 folded in a fixed order (deterministic).  workspace: >= 64 * B * 2 doubles [dev]. */
+typedef struct anoddpm_loss_args {
+    const float *eps, *noise;       /* [B][n] */
+    const float *x0, *xt;           /* [B][n], hybrid only */
+    const int64_t *t;               /* [B], hybrid only */
+    const float *weights;           /* [B] or NULL */
+    const float *c_recip, *c_recipm1, *c_coef1, *c_coef2, *c_post_logvar, *c_model_logvar;   /* fp32[T], hybrid only */
+    float *per_sample;              /* [B] */
+    float *vlb;                     /* [B] or NULL */
+    float *total;                   /* [1] or NULL */
+    double *workspace;
+    int64_t workspace_doubles;
+    const float *g_per, *g_vlb, *g_total;   /* backward: upstream gradients [B], [B], [1]; each may be NULL */
+    float *d_eps;                   /* backward: [B][n] */
+    int64_t n;
+    int32_t B, T, kind;
+} anoddpm_loss_args;
+
+int anoddpm_loss_forward(const anoddpm_loss_args *a, void *stream);
+int anoddpm_loss_backward(const anoddpm_loss_args *a, void *stream);
+
 /* ------------------------------------------------------------------ backward twins (training, diffusion_training.py:102)
  * Weight gradient of a 3x3 / stride 1 / pad 1 convolution whose input the forward consumed through the fused operand
  * load of anoddpm_igemm (GroupNorm-apply + SiLU, nearest x2, two-source concat):

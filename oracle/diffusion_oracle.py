@@ -128,3 +128,72 @@ def vlb_terms(tb, x0, x_t, t, eps, noise=None):
         eps_rec = (gather(tb["sqrt_recip_alphas_cumprod"], t, s) * x_t - pred) / gather(tb["sqrt_recipm1_alphas_cumprod"], t, s)
         mse = _mean_flat((eps_rec - noise) ** 2)
     return vlb, x0_mse, mse, pred
+
+
+# ---------------------------------------------------------------------------- training loss (calc_loss / p_loss)
+def loss_terms(tb, x0, t, eps, noise, weights=None, kind="l2"):
+    """GaussianDiffusion.py:399-417 (calc_loss) + the weighted mean of :419-434 (p_loss) as differentiable torch-CPU ops:
+    returns (per-sample loss [B], vlb [B] or None, scalar).  `eps` may require grad: scalar.backward() is the checker for
+    anoddpm_loss_backward."""
+    x_t = q_sample(tb, x0, t, noise)
+    vlb = None
+    if kind == "l1":
+        per = _mean_flat((eps - noise).abs())
+    elif kind == "hybrid":
+        vlb = vlb_terms(tb, x0, x_t, t, eps)[0]
+        per = vlb + _mean_flat((eps - noise).square())
+    else:
+        per = _mean_flat((eps - noise).square())
+    w = 1 if weights is None else weights
+    return per, vlb, (per * w).mean()
+
+
+def loss_grad_analytic(tb, x0, t, eps, noise, weights=None, kind="l2", dtype=np.float32):
+    """d(scalar of loss_terms)/d(eps) in closed form -- the formulas csrc/diffusion.hip (loss_bwd_kernel, vlb_element) evaluates,
+    restated in numpy so that the derivation itself is pinned against the reference's autograd (loss_kat.npz) on CPU.
+    Evaluated in fp32 like the kernel and the reference: at t = 0 the decoder NLL saturates (cdf_plus - cdf_min rounds to 0 in
+    fp32 and hits the 1e-12 floor, whose gradient is zero), which an fp64 evaluation would not reproduce."""
+    f = dtype
+    x0, eps, noise = (np.asarray(a, dtype=f) for a in (x0, eps, noise))
+    tn = np.asarray(t)
+    B = x0.shape[0]
+    n = f(x0[0].size)
+    w = np.ones(B, dtype=f) if weights is None else np.asarray(weights, dtype=f)
+    sh = (B,) + (1,) * (x0.ndim - 1)
+
+    def g(name):
+        return np.asarray(tb[name], dtype=np.float64)[tn].astype(np.float32).astype(f).reshape(sh)
+    d = eps - noise
+    cb = (w / f(B)).reshape(sh)
+    grad = cb * (np.sign(d) if kind == "l1" else f(2.0) * d) / n
+    if kind != "hybrid":
+        return grad
+    x_t = g("sqrt_alphas_cumprod") * x0 + g("sqrt_one_minus_alphas_cumprod") * noise
+    recip, recipm1, c1, c2 = g("sqrt_recip_alphas_cumprod"), g("sqrt_recipm1_alphas_cumprod"), g("posterior_mean_coef1"), g("posterior_mean_coef2")
+    lv1, lv2 = g("posterior_log_variance_clipped"), g("model_log_variance")
+    raw = recip * x_t - recipm1 * eps
+    pred = np.clip(raw, f(-1), f(1))
+    dpred = np.where((raw >= -1) & (raw <= 1), -recipm1, f(0))
+    mean = c1 * pred + c2 * x_t
+    dmean_kl = -((c1 * x0 + c2 * x_t) - mean) * np.exp(-lv2)
+    inv_std = np.exp(f(-0.5) * lv2)
+    cen = x0 - mean
+    c = f(np.sqrt(2.0 / np.pi))
+    k3 = f(0.044715)
+
+    def cdf(z):
+        return f(0.5) * (f(1) + np.tanh(c * (z + k3 * z * z * z)))
+
+    def dcdf(z):
+        th = np.tanh(c * (z + k3 * z * z * z))
+        return f(0.5) * (f(1) - th * th) * (c * (f(1) + f(3) * k3 * z * z))
+    zp, zm = inv_std * (cen + f(1 / 255)), inv_std * (cen - f(1 / 255))
+    cp, cm = cdf(zp), cdf(zm)
+    floor = f(1e-12)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        lo = np.where(cp >= floor, dcdf(zp) * inv_std / cp, f(0))
+        hi = np.where(f(1) - cm >= floor, -(dcdf(zm) * inv_std) / (f(1) - cm), f(0))
+        mid = np.where(cp - cm >= floor, (dcdf(zp) - dcdf(zm)) * inv_std / (cp - cm), f(0))
+    dmean_nll = np.where(x0 < f(-0.999), lo, np.where(x0 > f(0.999), hi, mid))
+    dmean = np.where((tn == 0).reshape(sh), dmean_nll, dmean_kl)
+    return grad + cb * dmean * c1 * dpred / (n * f(np.log(2.0)))

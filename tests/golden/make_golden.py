@@ -11,6 +11,8 @@ recipe from SURVEY.md 8c).  Outputs are DATA (inputs + expected outputs), never 
     metrics_kat.npz      evaluation.py metrics + the mean / mse / threshold images of detection_A/B
     simplex2_kat.npz     2-D noise2 point KATs (bit patterns), a coordinate grid, octave fields
     vlb_kat.npz          calc_vlb_xt (KL and decoder-NLL branches) and the MSE curves of calc_total_vlb
+    loss_kat.npz         p_loss / calc_loss for l1, l2, hybrid (uniform and prop-t weights): per-sample terms, the scalar,
+                         and d(scalar)/d(model output) from the reference's own autograd
     train_<name>.npz     two optimiser steps of the reference loop body (diffusion_training.py:99-107): p_loss scalars,
                          gradient probes / norms of every parameter, parameter + EMA probes after each step
     detection_fixedT.npz detection_A_fixedT (GaussianDiffusion.py:596-623) on a 32^2 model, seeded numpy stream
@@ -487,6 +489,53 @@ def gen_vlb():
     print("vlb_kat.npz:", len(out), "arrays")
 
 
+def gen_loss():
+    """p_loss (GaussianDiffusion.py:419-434) of the reference with the model output, the noise and t injected: the loss dict,
+    the scalar and -- through the reference's own autograd graph -- d(scalar)/d(estimate_noise), for every loss type, with
+    uniform draws (`loss_weight="none"`) and the weighted numpy draw ("prop-t")."""
+    g = torch.Generator().manual_seed(23)
+    B, H = 6, 16
+    x0 = torch.rand(B, 1, H, H, generator=g) * 2 - 1
+    x0[:, :, 0, :4] = -1.0
+    x0[:, :, 1, :4] = 1.0
+    eps0 = torch.randn(B, 1, H, H, generator=g)
+    eps0[:, :, 2, :3] = 30.0                       # drives pred_x_0 into the clamp (zero gradient through the VLB term there)
+    noise = torch.randn(B, 1, H, H, generator=g)
+    noise[:, :, 3, :2] = eps0[:, :, 3, :2]         # exact zeros of eps - noise: sign(0) = 0 in the l1 gradient
+    out = {"x0": x0.numpy(), "eps": eps0.numpy(), "noise": noise.numpy()}
+    real_randint = torch.randint
+    for lt in ("l1", "l2", "hybrid"):
+        for lw in ("none", "prop-t"):
+            d = ref_gd.GaussianDiffusionModel([H, H], ref_gd.get_beta_schedule(1000, "linear"), loss_type=lt, loss_weight=lw,
+                                              noise="gauss")
+            d.noise_fn = lambda a, b: noise
+            eps = eps0.clone().requires_grad_(True)
+            t_inj = torch.tensor([0, 1, 2, 500, 998, 0])
+            np.random.seed(5)
+            torch.randint = lambda *a, **k: t_inj.clone()
+            try:
+                total, (ld, x_t, e_out) = d.p_loss(lambda a, b: eps, x0, {"train_start": True, "sample_distance": 800})
+            finally:
+                torch.randint = real_randint
+            total.backward()
+            tag = f"{lt}_{lw}"
+            if lw == "none":
+                t_used, w_used = t_inj, torch.ones(B)
+            else:
+                np.random.seed(5)
+                t_used, w_used = d.sample_t_with_weights(B, "cpu")
+            out[f"{tag}_t"] = t_used.numpy()
+            out[f"{tag}_weights"] = w_used.numpy()
+            out[f"{tag}_x_t"] = x_t.detach().numpy()
+            out[f"{tag}_loss"] = ld["loss"].detach().numpy()
+            if "vlb" in ld:
+                out[f"{tag}_vlb"] = ld["vlb"].detach().numpy()
+            out[f"{tag}_total"] = np.float32(total.item())
+            out[f"{tag}_d_eps"] = eps.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "loss_kat.npz"), **out)
+    print("loss_kat.npz:", len(out), "arrays")
+
+
 def gen_simplex2():
     """2-D OpenSimplex (simplex.py:211-318, 56-73): point values as bit patterns, a coordinate grid, octave fields."""
     out = {}
@@ -507,7 +556,7 @@ def gen_simplex2():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["simplex", "diffusion", "unet", "metrics", "vlb", "simplex2", "unet_c5", "training",
+    which = sys.argv[1:] or ["simplex", "diffusion", "unet", "metrics", "vlb", "loss", "simplex2", "unet_c5", "training",
                              "detection", "loader"]
     torch.set_num_threads(8)
     if "simplex" in which:
@@ -522,6 +571,8 @@ if __name__ == "__main__":
         gen_metrics()
     if "vlb" in which:
         gen_vlb()
+    if "loss" in which:
+        gen_loss()
     if "simplex2" in which:
         gen_simplex2()
     if "unet_c5" in which:
