@@ -326,7 +326,7 @@ def lib():
     L.anoddpm_prof_enable.argtypes = [c_int32]
     L.anoddpm_prof_collect.argtypes = [POINTER(c_double), POINTER(c_int64)]
     L.anoddpm_adamw_ema.argtypes = [POINTER(AdamwArgs), c_void_p]
-    L.anoddpm_sumsq.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
+    L.anoddpm_sumsq.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p]
     L.anoddpm_anomaly_map.argtypes = [POINTER(AnomalyArgs), c_void_p]
     L.anoddpm_vlb_terms.argtypes = [POINTER(VlbArgs), c_void_p]
     L.anoddpm_loss_forward.argtypes = [POINTER(LossArgs), c_void_p]

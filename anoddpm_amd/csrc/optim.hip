@@ -24,16 +24,43 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(anoddpm_adamw_args a, fl
     }
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float *g, int64_t n, float *out)
+constexpr int SUMSQ_BLOCKS = 2048;
+
+// stage 1: one fp64 partial per block; stage 2 (one block): fixed-order fold -> {sum of squares, norm, clip factor}.
+// No atomics: data-parallel replicas that hold bit-identical reduced gradients must compute bit-identical clip factors,
+// or their parameters drift apart.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float *g, int64_t n, double *partial)
 {
-    __shared__ float part[4];
-    float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += g[i] * g[i];
+    __shared__ double part[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = g[i];
+        s += (double)v * (double)v;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((part[0] + part[1]) + part[2]) + part[3];
+}
+
+__global__ __launch_bounds__(256) void sumsq_fold_kernel(const double *partial, int nblocks, float max_norm, float *out)
+{
+    __shared__ double acc[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+    acc[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 256; ++i) t += acc[i];
+        const float ss = (float)t;
+        const float norm = sqrtf(ss);
+        out[0] = ss;
+        out[1] = norm;
+        // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
+        out[2] = max_norm > 0.f ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+    }
 }
 
 }  // namespace
@@ -50,12 +77,12 @@ extern "C" int anoddpm_adamw_ema(const anoddpm_adamw_args *a, void *stream)
     return anoddpm::check_launch("adamw_ema");
 }
 
-extern "C" int anoddpm_sumsq(const float *g, int64_t n, float *out, void *stream)
+extern "C" int anoddpm_sumsq(const float *g, int64_t n, float *out, double *workspace, float max_norm, void *stream)
 {
-    ANODDPM_REQUIRE(g && out && n >= 0, "sumsq: bad arguments");
-    if (n == 0) return ANODDPM_OK;
+    ANODDPM_REQUIRE(g && out && workspace && n >= 0, "sumsq: bad arguments");
     const int64_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0,
-                       anoddpm::as_stream(stream), g, n, out);
+    const int nb = (int)(blocks > SUMSQ_BLOCKS ? SUMSQ_BLOCKS : (blocks < 1 ? 1 : blocks));
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, anoddpm::as_stream(stream), g, n, workspace);
+    hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(256), 0, anoddpm::as_stream(stream), workspace, nb, max_norm, out);
     return anoddpm::check_launch("sumsq");
 }

@@ -231,8 +231,8 @@ class FusedAdamWEMA:
         self.m = torch.zeros_like(flat.flat_param)
         self.v = torch.zeros_like(flat.flat_param)
         self.step_count = 0
-        self.sumsq = torch.zeros(1, device=flat.flat_param.device)
-        self.scale = torch.ones(1, device=flat.flat_param.device)
+        self.norm_out = torch.zeros(3, device=flat.flat_param.device)       # {sum of squares, norm, clip factor}
+        self.norm_ws = torch.zeros(2048, device=flat.flat_param.device, dtype=torch.float64)
         self.last_norm = None
 
     def step(self):
@@ -240,12 +240,11 @@ class FusedAdamWEMA:
         stream = current_stream()
         scale_ptr = None
         if self.max_norm is not None:
-            self.sumsq.zero_()
-            check(lib().anoddpm_sumsq(ptr(f.flat_grad), f.numel, ptr(self.sumsq), stream), "sumsq")
-            norm = self.sumsq.sqrt()
-            self.last_norm = norm
-            torch.clamp(self.max_norm / (norm + 1e-6), max=1.0, out=self.scale)     # clip_grad_norm_ formula
-            scale_ptr = self.scale.data_ptr()
+            # norm + clip_grad_norm_'s factor on the device (deterministic two-stage reduction: identical on every replica)
+            check(lib().anoddpm_sumsq(ptr(f.flat_grad), f.numel, ptr(self.norm_out), ptr(self.norm_ws), float(self.max_norm), stream),
+                  "sumsq")
+            self.last_norm = self.norm_out[1:2]
+            scale_ptr = self.norm_out.data_ptr() + 8
         self.step_count += 1
         a = AdamwArgs()
         a.p, a.m, a.v, a.g = f.flat_param.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), f.flat_grad.data_ptr()

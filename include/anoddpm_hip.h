@@ -399,9 +399,11 @@ typedef struct {
 
 int anoddpm_adamw_ema(const anoddpm_adamw_args *a, void *stream);
 
-/* Sum of squares of a flat fp32 buffer -> *out (fp32, [dev]); out must be zeroed by the caller.
- * (clip_grad_norm_, diffusion_training.py:104) */
-int anoddpm_sumsq(const float *g, int64_t n, float *out, void *stream);
+/* Global gradient norm and clip factor of a flat fp32 buffer (clip_grad_norm_(params, max_norm), diffusion_training.py:104):
+ *   out[0] = sum of squares, out[1] = its square root, out[2] = min(max_norm / (out[1] + 1e-6), 1)   (1 when max_norm <= 0)
+ * out: [dev] fp32[3]; workspace: [dev] >= 2048 doubles.  Two-stage fp64 reduction in a fixed order, no atomics: replicas that
+ * hold identical gradients compute identical clip factors. */
+int anoddpm_sumsq(const float *g, int64_t n, float *out, double *workspace, float max_norm, void *stream);
 
 /* ------------------------------------------------------------------ anomaly map + segmentation counts
  * One pass over an image and its `navg` reconstructions (the (t_distance, avg) chains of detection_A/B):

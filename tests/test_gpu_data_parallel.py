@@ -101,7 +101,10 @@ def test_two_ranks_native_cut_backward_match_single_process_large_batch(tmp_path
         for o in (outs[0][step], outs[1][step]):
             assert (o["grad"] - grad).abs().max().item() < 2e-4 * gmax, (step, (o["grad"] - grad).abs().max().item(), gmax)
             assert abs(o["norm"] - norm) < 2e-4 * norm
-            assert (o["param"] - param).abs().max().item() < 1e-5          # one AdamW step moves a parameter by <= lr = 1e-3
+            # the first AdamW steps move every parameter by ~lr * sign(g) = 1e-3: elements whose gradient is rounding noise may
+            # differ by a fraction of that, everything else agrees closely
+            dp = (o["param"] - param).abs()
+            assert dp.max().item() < 5e-4 and dp.mean().item() < 2e-6, (dp.max().item(), dp.mean().item())
             # every bucket was launched from inside the cut backward, in bucket order, the first well before the end
             done = [d for _, d in o["log"]]
             assert [b for b, _ in o["log"]] == list(range(o["nbuckets"])) and all(d is not None for d in done) and done == sorted(done)
