@@ -248,6 +248,72 @@ def timed(c, args, step_fn):
     return elapsed
 
 
+def committed_traffic(config_name, batch, kernel_prefixes):
+    """HBM-side bytes per launch of a kernel class from the committed PMC passes (profiles/r*_traffic_<config>.json, written by
+    tools/traffic_from_pmc.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench command, corrected with
+    the calibration of tools/hbm_calib.hip).  PMC counters cannot be read from inside the process, so the bench line carries the
+    committed measurement of the same workload -- or null when none matches (other config / batch)."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_traffic_{config_name}.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("per_gpu_batch") == batch:
+            best = (path, d)
+    if best is None:
+        return None
+    path, d = best
+    n = f = w = 0.0
+    for k, v in d["kernels"].items():
+        if any(k.startswith(p) for p in kernel_prefixes):
+            n += v["launches"]
+            f += v["fetch_bytes_per_launch"] * v["launches"]
+            w += v["write_bytes_per_launch"] * v["launches"]
+    if n == 0:
+        return None
+    return {"bytes_per_launch": (f + w) / n, "fetch_bytes_per_launch": f / n, "write_bytes_per_launch": w / n,
+            "source": os.path.relpath(path, ROOT), "fetch_factor": d["calibration"]["fetch_factor"],
+            "write_factor": d["calibration"]["write_factor"], "tree": d.get("tree")}
+
+
+PEAK_HBM_GBPS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (about 6.3 TB/s achievable)
+
+
+def hbm_kernel_rows(plan, B, ms, cnt, steps, extra=()):
+    """The memory-bound kernels of the step against the HBM roofline: algorithmic bytes (what the op must move: its inputs once,
+    its outputs once) / HIP-event time of its launches.  This is the one place the north star's '>= 70 % of the memory-bandwidth
+    roofline' is meaningful."""
+    from anoddpm_amd import _lib
+    S = plan.S
+    by = {"stem": 0.0, "head": 0.0, "resample": 0.0, "chan_stats": 0.0}
+    for code, st in plan.ops:
+        if code == _lib.OP_STEM:
+            by["stem"] += 4.0 * st.B * st.H * st.W * (st.Cin + st.Cout)
+        elif code == _lib.OP_HEAD:
+            by["head"] += 4.0 * st.B * st.H * st.W * (st.C + st.Cout)
+        elif code == _lib.OP_RESAMPLE:
+            pin = st.B * st.H * st.W * st.C
+            pout = pin * 4 if st.mode == 1 else pin // 4
+            by["resample"] += 4.0 * (pin + pout + (pout if st.out_act else 0))
+        elif code == _lib.OP_CHAN_STATS:
+            by["chan_stats"] += 4.0 * st.B * st.P * st.C
+    slots = {"stem": (_lib.OP_STEM, "conv_stem_strip (3x3, Cin=1 -> base channels, NCHW in / NHWC out)"),
+             "head": (_lib.OP_HEAD, "conv_head_taps (GroupNorm-apply + SiLU + 3x3 -> 1 channel)"),
+             "resample": (_lib.OP_RESAMPLE, "resample2x (avg-pool / nearest x2 of the skip path, + pooled activated operand)"),
+             "chan_stats": (_lib.OP_CHAN_STATS, "chan_stats (GroupNorm partial sums of the stem output)")}
+    rows = []
+    for key, (slot, name) in slots.items():
+        t = ms[slot] / steps
+        if t > 0 and by[key] > 0:
+            gbps = by[key] / (t / 1000.0) / 1e9
+            rows.append({"kernel": name, "launches_per_step": cnt[slot] / steps, "ms_per_step": t, "algorithmic_MB_per_step": by[key] / 1e6,
+                         "GBps": gbps, "frac_of_8TBps": gbps / PEAK_HBM_GBPS})
+    rows.extend(extra)
+    return rows
+
+
 def run_reverse(c, args, cfg):
     import GaussianDiffusion as GD
     from UNet import UNetModel
@@ -323,8 +389,8 @@ def run_reverse(c, args, cfg):
                     "achieved_is": "FLOPs the matrix pipe executes for the kernel's launches (Winograd F(4x4,3x3): 1/4, F(2x2,3x3): 4/9 of the "
                                    "direct-convolution count) / their HIP-event time",
                     "algorithmic_tflops": tf(d["alg"], d["ms"]),
-                    # HBM bytes come from PMC counters, which cannot be read from inside this process: not reported here;
-                    # the per-kernel counter passes of the same command are committed under profiles/ (README there)
+                    # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this
+                    # is the committed measurement of the same command (profiles/, corrected by the calibrated FETCH_SIZE factor)
                     "traffic": None,
                     "launches_per_step": nl,
                     "avg_launch_ms": d["ms"] / max(d["n"], 1),
@@ -343,6 +409,34 @@ def run_reverse(c, args, cfg):
                                            ("linear", 5), ("posemb", 6), ("stem", 7), ("layout", 8), ("chan_stats", 9),
                                            ("gn_finalize", 10), ("head", 11), ("attention", 26))},
                     "instrumented_ms_per_step": prof_ms_per_step}
+        prefix = {14: ["wino43_kernel"], 12: ["wino_kernel"], _lib.OP_IGEMM: ["igemm_kernel", "pointwise_stream_kernel"],
+                  _lib.OP_ATTENTION: ["attention_kernel"]}[classes[dom][0]]
+        tr = committed_traffic(args.config, B, prefix)
+        if tr is not None:
+            # algorithmic bytes of the same launches: operand read once + output written once + the layer's packed weights once
+            ent = classes[dom][1]
+            wmul = {14: 36.0, 12: 16.0}.get(classes[dom][0], None)
+            alg = sum(4.0 * B * e["H"] * e["W"] * (e["K"] * (0.25 if e.get("a_mode") == 1 else 1.0) + e["N"])
+                      + 4.0 * e["K"] * e["N"] * (wmul if wmul else e["ks"] * e["ks"]) for e in ent) / max(len(ent), 1)
+            roofline["traffic"] = tr["bytes_per_launch"]
+            roofline["traffic_detail"] = dict(tr, algorithmic_bytes_per_launch=alg, ratio_to_algorithmic=tr["bytes_per_launch"] / alg,
+                                              GBps_at_avg_launch=tr["bytes_per_launch"] / (roofline["avg_launch_ms"] / 1000.0) / 1e9)
+        # the memory-bound kernels against the HBM roofline (HIP events of the same instrumented pass; p_update timed here)
+        ev = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            diff._reverse_update(chain.x, chain.t, chain.x, chain.noise, want_pred=False, out=torch.empty_like(chain.x))
+            e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+        pu_ms = min(a.elapsed_time(b) for a, b in ev)
+        pu_bytes = 16.0 * chain.x.numel()
+        extra = [{"kernel": "p_update (fused reverse update: read x_t, eps, noise; write x_{t-1})", "launches_per_step": 1.0, "ms_per_step": pu_ms,
+                  "algorithmic_MB_per_step": pu_bytes / 1e6, "GBps": pu_bytes / (pu_ms / 1000.0) / 1e9,
+                  "frac_of_8TBps": pu_bytes / (pu_ms / 1000.0) / 1e9 / PEAK_HBM_GBPS,
+                  "note": "1 MB per launch: launch-latency bound, timed with a HIP-event pair around a lone launch"}]
+        roofline["hbm_kernels"] = hbm_kernel_rows(plan, B, ms, cnt, args.steps, extra)
     metric = ("reverse-diffusion images/sec @256x256 T=1000 simplex" if cfg["img"] == 256 else
               f"reverse-diffusion images/sec @{cfg['img']}x{cfg['img']} T=1000 simplex")
     out = {"metric": metric, "value": value, "unit": "images/s", "ms_per_step": ms_per_step, "scaling": "weak", "dtype": "f32",

@@ -33,7 +33,12 @@ def test_bench_line_small_config():
     r = d["roofline"]
     assert r["bound"] in ("mfma", "hbm") and r["unit"] == "TFLOP/s" and r["peak"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1.0
-    assert r["algorithmic_tflops"] >= r["achieved"] - 1e-9 and r["traffic"] is None
+    assert r["algorithmic_tflops"] >= r["achieved"] - 1e-9
+    assert r["traffic"] is None                                   # no committed PMC pass for this (test-sized) configuration
+    # the memory-bound kernels against the HBM roofline: stem, head, resample, stem statistics, the fused reverse update
+    names = " ".join(k["kernel"] for k in r["hbm_kernels"])
+    assert all(n in names for n in ("conv_stem", "conv_head", "resample2x", "p_update"))
+    assert all(0 < k["frac_of_8TBps"] < 1 and abs(k["frac_of_8TBps"] - k["GBps"] / 8000.0) < 1e-9 for k in r["hbm_kernels"])
 
 
 def test_bench_cpu_baseline_object():

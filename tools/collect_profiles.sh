@@ -33,4 +33,6 @@ for d in c2_stats c2_fetch c2_write c2_sq c3_stats c4_stats c4_sq; do
   for f in $(find $OUT/$d -name "*kernel_stats.csv" 2>/dev/null); do cp $f $OUT/${d}_kernel_stats.csv; done
   rm -rf $OUT/$d
 done
+# HBM-side bytes per launch for bench.py's roofline.traffic (calibration: tools/calib_hbm.sh -> profiles/r3_hbm_calibration.json)
+python tools/traffic_from_pmc.py traffic profiles/r3_hbm_calibration.json $OUT/c2_fetch_by_kernel.csv $OUT/c2_write_by_kernel.csv 4 "${2:-}" > $OUT/traffic_c2.json
 ls -la $OUT
