@@ -302,14 +302,14 @@ class UNetModel(nn.Module):
         return plan
 
     def _forward_autograd(self, x, time):
-        """Forward with autograd recording (training, diffusion_training.py:99-102).  Default: the native training plan
-        (train_plan.py: forward + backward as flat C-ABI op lists, no ATen / MIOpen compute).  ANODDPM_TRAIN_PLAN=0 selects the
-        per-operator autograd expression below (fused 3x3 blocks native, the rest PyTorch-ROCm); ANODDPM_TORCH_BACKWARD=1
-        the all-torch expression (also what runs with dropout > 0 or frozen parameters)."""
+        """Forward with autograd recording (training, diffusion_training.py:99-102): the native training plan (train_plan.py:
+        forward + backward as flat C-ABI op lists, no ATen / MIOpen compute).  Shapes the plan does not cover yet (dropout > 0,
+        the Downsample / Upsample topology, frozen parameters) -- and ANODDPM_TORCH_BACKWARD=1, the reference expression the
+        parity tests compare against -- run the same forward as differentiable PyTorch-ROCm ops."""
         _lib.require_cuda(x, "UNetModel.forward (training)")
         if (x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[1] == self.in_channels
                 and not (self.dropout > 0 and self.training)
-                and os.environ.get("ANODDPM_TORCH_BACKWARD", "0") != "1" and os.environ.get("ANODDPM_TRAIN_PLAN", "1") != "0"):
+                and os.environ.get("ANODDPM_TORCH_BACKWARD", "0") != "1"):
             from . import train_plan
             params = list(self.parameters())
             if train_plan.eligible(self, x.shape[0], x.shape[2]) and all(p.requires_grad for p in params):
@@ -334,31 +334,8 @@ class UNetModel(nn.Module):
         temb = F.linear(temb, P("time_embedding.1.weight"), P("time_embedding.1.bias"))
         temb = F.linear(F.silu(temb), P("time_embedding.3.weight"), P("time_embedding.3.bias"))
 
-        # Hand-written forward + backward for the 3x3 blocks (95 % of the FLOPs): train_ops.FusedGNSiLUConv3x3.
-        # ANODDPM_TORCH_BACKWARD=1 keeps the all-torch (MIOpen) expression, which is also what runs with dropout > 0.
-        native = (not (self.dropout > 0 and self.training)) and os.environ.get("ANODDPM_TORCH_BACKWARD", "0") != "1"
-        if native:
-            from .train_ops import fused_gn_silu_conv3x3
-
         def res(p, h, resample):
             xs = h
-            if native:
-                # the two GN -> SiLU -> [resample] -> conv3x3 stages run on hand-written forward AND backward kernels
-                # (train_ops.FusedGNSiLUConv3x3); the embedding add and the residual ride in the conv epilogues
-                e = F.linear(F.silu(temb), P(p + ".embed_layers.1.weight"), P(p + ".embed_layers.1.bias"))
-                am = {"down": 2, "up": 1}.get(resample, 0)
-                h = fused_gn_silu_conv3x3(h, P(p + ".in_layers.0.weight"), P(p + ".in_layers.0.bias"),
-                                          P(p + ".in_layers.2.weight"), P(p + ".in_layers.2.bias"), temb=e, a_mode=am,
-                                          epoch=self._weights_epoch)
-                if resample == "down":
-                    xs = F.avg_pool2d(xs, 2, 2)
-                elif resample == "up":
-                    xs = F.interpolate(xs, scale_factor=2, mode="nearest")
-                if (p + ".skip_connection.weight") in sd:
-                    xs = F.conv2d(xs, P(p + ".skip_connection.weight"), P(p + ".skip_connection.bias"))
-                return fused_gn_silu_conv3x3(h, P(p + ".out_layers.0.weight"), P(p + ".out_layers.0.bias"),
-                                             P(p + ".out_layers.3.weight"), P(p + ".out_layers.3.bias"), res=xs,
-                                             epoch=self._weights_epoch)
             h = F.silu(gn(p + ".in_layers.0", h))
             if resample == "down":
                 h, xs = F.avg_pool2d(h, 2, 2), F.avg_pool2d(xs, 2, 2)
@@ -407,8 +384,6 @@ class UNetModel(nn.Module):
 
         down, middle, up = self._blocks
         h = x.float()
-        if native:
-            h = h.contiguous(memory_format=torch.channels_last)      # NHWC in memory: what the fused blocks consume
         skips = []
         for blk in down:
             h = run(blk, h)
@@ -477,7 +452,7 @@ def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None
     3: Winograd F(4x4,3x3) -- only when the
     caller can supply its weights, `f43`, and only on maps >= 64x64 with enough workgroups, where its 1.78x fewer MFMAs outweigh
     the looser fp32 rounding: ~8e-6 per layer instead of 4e-7) and split-K of one
-    anoddpm_igemm launch; shared by the inference plan and the training operators (train_ops).  Policy: fill the 256
+    anoddpm_igemm launch; shared by the inference plan and the training plan.  Policy: fill the 256
     CUs -- >= 512 workgroups for the direct kernels when K allows it, one full round of >= 4-chunk workgroups for
     Winograd on small maps."""
     c0 = K if c0 is None else c0
