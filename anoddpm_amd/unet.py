@@ -26,8 +26,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
-from ._lib import (AttentionArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, IgemmArgs, LayoutArgs, LinearArgs, Op, PosembArgs,
-                   ResampleArgs, SoftmaxArgs, StemArgs, check, lib)
+from ._lib import (AttentionArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, IgemmArgs, LayoutArgs, LinearArgs, Op, PackArgs, PackBatchArgs,
+                   PosembArgs, ResampleArgs, SoftmaxArgs, StemArgs, check, lib)
 
 __all__ = ["UNetModel", "update_ema_params", "zero_module", "GroupNorm32"]
 
@@ -402,40 +402,6 @@ def _posemb_freqs(half):
 
 
 # ----------------------------------------------------------------------------- plan
-def _pack_conv(w):
-    """OIHW / OI1 -> [taps][I/4][O][4] fp32 (B operand layout of the implicit GEMM)."""
-    if w.dim() == 3:
-        w = w.unsqueeze(-1)
-    o, i, kh, kw = w.shape
-    return (w.detach().float().permute(2, 3, 1, 0).reshape(kh * kw, i // 4, 4, o)
-            .permute(0, 1, 3, 2).contiguous())
-
-
-_WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
-
-
-def _pack_wino(w):
-    """OIHW 3x3 -> Winograd F(2x2,3x3) weights U = G g G^T, laid out [16][I/4][O][4] (xi = 4*u + v)."""
-    o, i, kh, kw = w.shape
-    assert kh == 3 and kw == 3
-    G = _WINO_G.to(device=w.device, dtype=torch.float64)
-    U = torch.einsum("ua,oiab,vb->uvio", G, w.detach().double(), G).float()          # [4][4][I][O]
-    return U.reshape(16, i // 4, 4, o).permute(0, 1, 3, 2).contiguous()
-
-
-_WINO43_G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
-                          [0, 0, 1]], dtype=torch.float64)
-
-
-def _pack_wino43(w):
-    """OIHW 3x3 -> Winograd F(4x4,3x3) weights U = G g G^T (G 6x3, fp64, rounded once), laid out [36][I/4][O][4] (xi = 6*u + v)."""
-    o, i, kh, kw = w.shape
-    assert kh == 3 and kw == 3
-    G = _WINO43_G.to(device=w.device)
-    U = torch.einsum("ua,oiab,vb->uvio", G, w.detach().double(), G).float()          # [6][6][I][O]
-    return U.reshape(36, i // 4, 4, o).permute(0, 1, 3, 2).contiguous()
-
-
 def _use_winograd():
     import os
     return os.environ.get("ANODDPM_NO_WINOGRAD", "0") != "1"
@@ -512,7 +478,8 @@ class _Plan:
         self.B, self.S, self.device = B, S, device
         self.keep = []          # tensors / ctypes structs that must outlive the op list
         self.ops = []           # (code, struct)
-        self.packers = []       # callables that (re)pack weights into their fixed buffers
+        self._pack_jobs = []    # (parameter name, PackArgs): one device-side packing job per packed buffer
+        self._packed = {}
         self.token = None
         self.flops = {"conv3": 0.0, "conv1": 0.0, "attn": 0.0, "qkvproj": 0.0}
         self.igemm_flops = 0.0
@@ -535,17 +502,34 @@ class _Plan:
         self.keep.append(t)
         return t
 
-    def packed(self, key, fn):
-        """Fixed device buffer holding fn(param) -- refreshed in place when parameters change."""
-        params = dict(self.model.named_parameters())
-        src = params[key]
-        res = fn(src.to(self.device))
-        # the packed buffer must OWN its storage: for fp32 bias / gamma / beta `fn` is the identity and the result
-        # would alias the parameter -- refresh_weights' dst.copy_() would then bump the parameter's version
-        # counter and trigger a full re-pack on every forward
-        dst = torch.empty(res.shape, dtype=res.dtype, device=self.device).copy_(res)
+    _PACK_KINDS = {"conv": None, "wino": 1, "wino43": 5, "copy": 4, "small": 3}
+
+    def packed(self, key, kind, out=None):
+        """Plan-owned device buffer holding parameter `key` in the layout `kind` names ("conv": [taps][I/4][O][4] direct 3x3 or
+        pointwise, "wino" / "wino43": Winograd-domain 3x3, "small": [9][I][O] for the stem / head kernels, "copy": as is).  Filled by
+        ONE anoddpm_pack_batch launch over all of the plan's weights (refresh_weights) -- no ATen / rocBLAS kernel."""
+        ck = (key, kind, None if out is None else out.data_ptr())
+        hit = self._packed.get(ck)
+        if hit is not None:
+            return hit
+        p = dict(self.model.named_parameters())[key]
+        shape = tuple(p.shape)
+        k = self._PACK_KINDS[kind]
+        if kind == "conv":
+            k = 0 if (len(shape) == 4 and shape[2] == 3) else 2
+        if k == 4:
+            N, K, n_out = p.numel(), 1, p.numel()
+        else:
+            N, K = shape[0], shape[1]
+            n_out = {0: 9, 1: 16, 2: 1, 3: 9, 5: 36}[k] * N * K
+        if k in (0, 1, 2, 5) and K % 4:
+            raise NotImplementedError(f"{key}: input channel count {K} must be a multiple of 4")
+        dst = out if out is not None else torch.empty(n_out, dtype=torch.float32, device=self.device)
         self.keep.append(dst)
-        self.packers.append((key, fn, dst))
+        st = PackArgs()
+        st.w, st.out, st.N, st.K, st.kind, st.bwd, st.k0, st.kc = None, dst.data_ptr(), N, K, k, 0, 0, 0
+        self._pack_jobs.append((key, st))
+        self._packed[ck] = dst
         return dst
 
     def add(self, code, st):
@@ -554,20 +538,33 @@ class _Plan:
         return st
 
     def refresh_weights(self):
+        """(Re)pack every weight when a parameter changed (version counter / storage / mark_weights_changed epoch): the job table
+        gets the parameters' current addresses and one batched launch fills all packed buffers."""
         params = list(self.model.parameters())
         token = (self.model._weights_epoch,) + tuple((p.data_ptr(), p._version) for p in params)
         if token == self.token:
             return
         named = dict(self.model.named_parameters())
+        jobs = (PackArgs * len(self._pack_jobs))()
+        block0 = [0]
+        for i, (key, st) in enumerate(self._pack_jobs):
+            src = named[key]
+            if src.device != self.device:
+                raise _lib.AnoddpmError(f"parameter {key} is on {src.device}, plan is on {self.device}")
+            if src.dtype != torch.float32 or not src.is_contiguous():
+                raise _lib.AnoddpmError(f"parameter {key} must be contiguous fp32")
+            st.w = src.data_ptr()
+            ctypes.memmove(ctypes.addressof(jobs[i]), ctypes.addressof(st), ctypes.sizeof(PackArgs))
+            block0.append(block0[-1] + int(lib().anoddpm_pack_job_blocks(ctypes.byref(st))))
         with torch.no_grad():
-            for key, fn, dst in self.packers:
-                src = named[key]
-                if src.device != self.device:
-                    raise _lib.AnoddpmError(f"parameter {key} is on {src.device}, plan is on {self.device}")
-                dst.copy_(fn(src))
-            for fn in self.post_pack:
-                fn()
+            raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self.device)
+            b0 = torch.tensor(block0, dtype=torch.int32).to(self.device)
+        pb = PackBatchArgs()
+        pb.jobs, pb.block0, pb.njobs, pb.nblocks = raw.data_ptr(), b0.data_ptr(), len(self._pack_jobs), block0[-1]
+        check(lib().anoddpm_pack_batch(ctypes.byref(pb), _lib.current_stream()), "weight packing")
+        self._pack_table = (raw, b0, pb)             # alive until the next refresh (the launch is asynchronous)
         self.token = token
+        self.pack_count = getattr(self, "pack_count", 0) + 1
 
     # -- op emitters ----------------------------------------------------------------------
     def chan_stats(self, buf, C, P):
@@ -600,8 +597,8 @@ class _Plan:
             st.stats1, st.rows1 = s1.data_ptr(), r1
         else:
             st.stats1, st.rows1 = None, 0
-        st.gamma = self.packed(gamma_key, lambda w: w.detach().float()).data_ptr()
-        st.beta = self.packed(beta_key, lambda w: w.detach().float()).data_ptr()
+        st.gamma = self.packed(gamma_key, "copy").data_ptr()
+        st.beta = self.packed(beta_key, "copy").data_ptr()
         scale, shift = self.buf(B, C), self.buf(B, C)
         st.scale, st.shift = scale.data_ptr(), shift.data_ptr()
         st.c0, st.c1, st.P, st.B, st.groups, st.eps = c0, c1, P, B, 32, 1e-5
@@ -726,8 +723,6 @@ class _Plan:
         B, S, dev = self.B, self.S, self.device
         base, ted = m.model_channels, m._ted
         down, middle, up = m._blocks
-        self.post_pack = []
-
         # --- timestep path: features -> MLP -> all per-block projections in one launch (UNet.py:271-276,185-188)
         half = base // 2
         freqs = _posemb_freqs(half).to(dev)
@@ -741,8 +736,8 @@ class _Plan:
         def linear(inp, wkey, bkey, K, N, act_in, act_out, w=None, b=None):
             st = LinearArgs()
             st.inp = inp.data_ptr()
-            wt = w if w is not None else self.packed(wkey, lambda t: t.detach().float())
-            bt = b if b is not None else self.packed(bkey, lambda t: t.detach().float())
+            wt = w if w is not None else self.packed(wkey, "copy")
+            bt = b if b is not None else self.packed(bkey, "copy")
             st.w, st.bias = wt.data_ptr(), bt.data_ptr()
             o = self.buf(B, N)
             st.out = o.data_ptr()
@@ -760,15 +755,10 @@ class _Plan:
             tot += b[3]
         w_all = self.buf(tot, ted)
         b_all = self.buf(tot)
-        named = dict(m.named_parameters())
-
-        def pack_emb():
-            for b in res_blocks:
-                o = offs[b[0]]
-                w_all[o:o + b[3]].copy_(named[b[0] + ".embed_layers.1.weight"].detach().to(dev))
-                b_all[o:o + b[3]].copy_(named[b[0] + ".embed_layers.1.bias"].detach().to(dev))
-        pack_emb()
-        self.post_pack.append(pack_emb)
+        for blk_ in res_blocks:                                  # every block's projection copied into the concatenated matrix
+            o = offs[blk_[0]]
+            self.packed(blk_[0] + ".embed_layers.1.weight", "copy", out=w_all[o:o + blk_[3]])
+            self.packed(blk_[0] + ".embed_layers.1.bias", "copy", out=b_all[o:o + blk_[3]])
         emb_all = linear(temb, None, None, ted, tot, 1, 0, w=w_all, b=b_all)
         self.emb_tot = tot
 
@@ -793,18 +783,18 @@ class _Plan:
             self.igemm(srcs=([(pooled, cin)] if pooled is not None else srcs), H=Hout, W=Hout, ks=3, N=cout,
                        gn=(None if pooled is not None else g1), act=(0 if pooled is not None else 1),
                        a_mode=(0 if pooled is not None else {None: 0, "up": 1, "down": 2}[resample]),
-                       bmat=lambda p=prefix: self.packed(p + ".in_layers.2.weight", _pack_conv),
-                       wino=lambda p=prefix: self.packed(p + ".in_layers.2.weight", _pack_wino),
-                       wino43=lambda p=prefix: self.packed(p + ".in_layers.2.weight", _pack_wino43),
-                       bias=self.packed(prefix + ".in_layers.2.bias", lambda t: t.detach().float()),
+                       bmat=lambda p=prefix: self.packed(p + ".in_layers.2.weight", "conv"),
+                       wino=lambda p=prefix: self.packed(p + ".in_layers.2.weight", "wino"),
+                       wino43=lambda p=prefix: self.packed(p + ".in_layers.2.weight", "wino43"),
+                       bias=self.packed(prefix + ".in_layers.2.bias", "copy"),
                        temb=emb_all.data_ptr() + 4 * offs[prefix], temb_ld=tot, out=h1, want_stats=True)
             g2 = self.gn([(h1, cout)], Pout, prefix + ".out_layers.0.weight", prefix + ".out_layers.0.bias")
             if cin != cout:
                 sk = self.buf(B, Pout, cout)
                 assert resample is None
                 self.igemm(srcs=srcs, H=Hout, W=Hout, ks=1, N=cout, kind="conv1",
-                           bmat=self.packed(prefix + ".skip_connection.weight", _pack_conv),
-                           bias=self.packed(prefix + ".skip_connection.bias", lambda t: t.detach().float()), out=sk)
+                           bmat=self.packed(prefix + ".skip_connection.weight", "conv"),
+                           bias=self.packed(prefix + ".skip_connection.bias", "copy"), out=sk)
             elif resample is not None and pooled is not None:
                 sk = sk_pool
             elif resample is not None:
@@ -820,10 +810,10 @@ class _Plan:
                 sk = srcs[0][0]
             h2 = self.buf(B, Pout, cout)
             self.igemm(srcs=[(h1, cout)], H=Hout, W=Hout, ks=3, N=cout, gn=g2, act=1,
-                       bmat=lambda p=prefix: self.packed(p + ".out_layers.3.weight", _pack_conv),
-                       wino=lambda p=prefix: self.packed(p + ".out_layers.3.weight", _pack_wino),
-                       wino43=lambda p=prefix: self.packed(p + ".out_layers.3.weight", _pack_wino43),
-                       bias=self.packed(prefix + ".out_layers.3.bias", lambda t: t.detach().float()),
+                       bmat=lambda p=prefix: self.packed(p + ".out_layers.3.weight", "conv"),
+                       wino=lambda p=prefix: self.packed(p + ".out_layers.3.weight", "wino"),
+                       wino43=lambda p=prefix: self.packed(p + ".out_layers.3.weight", "wino43"),
+                       bias=self.packed(prefix + ".out_layers.3.bias", "copy"),
                        res=sk, out=h2, want_stats=True)
             return h2, Hout
 
@@ -836,8 +826,8 @@ class _Plan:
             g = self.gn([(x, C)], L, prefix + ".norm.weight", prefix + ".norm.bias")
             qkv = self.buf(B, L, 3 * C)
             self.igemm(srcs=[(x, C)], H=Hc, W=Hc, ks=1, N=3 * C, gn=g, act=0, kind="qkvproj",
-                       bmat=self.packed(prefix + ".to_qkv.weight", _pack_conv),
-                       bias=self.packed(prefix + ".to_qkv.bias", lambda t: t.detach().float()), out=qkv)
+                       bmat=self.packed(prefix + ".to_qkv.weight", "conv"),
+                       bias=self.packed(prefix + ".to_qkv.bias", "copy"), out=qkv)
             att = self.buf(B, L, C)
             if not self.attention(qkv, att, L, heads, ch):
                 S_ = self.buf(B * heads, L, L)
@@ -856,8 +846,8 @@ class _Plan:
                            out=att, out_ld=C, o_strides=(L * C, ch))
             y = self.buf(B, L, C)
             self.igemm(srcs=[(att, C)], H=Hc, W=Hc, ks=1, N=C, kind="qkvproj",
-                       bmat=self.packed(prefix + ".proj_out.weight", _pack_conv),
-                       bias=self.packed(prefix + ".proj_out.bias", lambda t: t.detach().float()),
+                       bmat=self.packed(prefix + ".proj_out.weight", "conv"),
+                       bias=self.packed(prefix + ".proj_out.bias", "copy"),
                        res=x, out=y, want_stats=True)
             return y
 
@@ -879,10 +869,10 @@ class _Plan:
                     return out, Ho
                 full = self.buf(B, Hc * Hc, C)
                 self.igemm(srcs=[(x, C)], H=Hc, W=Hc, ks=3, N=C, act=0,
-                           bmat=lambda p=prefix: self.packed(p + ".downsample.weight", _pack_conv),
-                           wino=lambda p=prefix: self.packed(p + ".downsample.weight", _pack_wino),
-                           wino43=lambda p=prefix: self.packed(p + ".downsample.weight", _pack_wino43),
-                           bias=self.packed(prefix + ".downsample.bias", lambda t: t.detach().float()), out=full)
+                           bmat=lambda p=prefix: self.packed(p + ".downsample.weight", "conv"),
+                           wino=lambda p=prefix: self.packed(p + ".downsample.weight", "wino"),
+                           wino43=lambda p=prefix: self.packed(p + ".downsample.weight", "wino43"),
+                           bias=self.packed(prefix + ".downsample.bias", "copy"), out=full)
                 rs(full, Hc, 3, out)
                 return out, Ho
             Ho = Hc * 2
@@ -891,10 +881,10 @@ class _Plan:
                 rs(x, Hc, 1, out)                                       # F.interpolate(scale_factor=2, mode="nearest")
                 return out, Ho
             self.igemm(srcs=[(x, C)], H=Ho, W=Ho, ks=3, N=C, act=0, a_mode=1,      # nearest x2 fused into the operand load
-                       bmat=lambda p=prefix: self.packed(p + ".conv.weight", _pack_conv),
-                       wino=lambda p=prefix: self.packed(p + ".conv.weight", _pack_wino),
-                       wino43=lambda p=prefix: self.packed(p + ".conv.weight", _pack_wino43),
-                       bias=self.packed(prefix + ".conv.bias", lambda t: t.detach().float()), out=out, want_stats=True)
+                       bmat=lambda p=prefix: self.packed(p + ".conv.weight", "conv"),
+                       wino=lambda p=prefix: self.packed(p + ".conv.weight", "wino"),
+                       wino43=lambda p=prefix: self.packed(p + ".conv.weight", "wino43"),
+                       bias=self.packed(prefix + ".conv.bias", "copy"), out=out, want_stats=True)
             return out, Ho
 
         def run(blks, srcs, Hc):
@@ -903,8 +893,8 @@ class _Plan:
                     h0 = self.buf(B, S * S, cout)
                     self.stem = StemArgs()
                     self.stem.x = None
-                    self.stem.w = self.packed(prefix + ".weight", lambda w: w.detach().float().permute(2, 3, 1, 0).reshape(-1, w.shape[0])).data_ptr()
-                    self.stem.bias = self.packed(prefix + ".bias", lambda t: t.detach().float()).data_ptr()
+                    self.stem.w = self.packed(prefix + ".weight", "small").data_ptr()
+                    self.stem.bias = self.packed(prefix + ".bias", "copy").data_ptr()
                     self.stem.out = h0.data_ptr()
                     self.stem.B, self.stem.H, self.stem.W, self.stem.Cin, self.stem.Cout = B, S, S, cin, cout
                     self.add(_lib.OP_STEM, self.stem)
@@ -941,8 +931,8 @@ class _Plan:
             self.y = self.buf(B, nout, S, S)
             st = HeadArgs()
             st.x = hfin.data_ptr()
-            st.w = self.packed("out.2.weight", lambda w: w.detach().float().permute(2, 3, 1, 0).reshape(-1, w.shape[0])).data_ptr()
-            st.bias = self.packed("out.2.bias", lambda t: t.detach().float()).data_ptr()
+            st.w = self.packed("out.2.weight", "small").data_ptr()
+            st.bias = self.packed("out.2.bias", "copy").data_ptr()
             st.gn_scale, st.gn_shift, st.out = g[0].data_ptr(), g[1].data_ptr(), self.y.data_ptr()
             st.B, st.H, st.W, st.C, st.Cout = B, S, S, cfin, nout
             self.add(_lib.OP_HEAD, st)
@@ -950,8 +940,8 @@ class _Plan:
         else:
             y_nhwc = self.buf(B, S * S, nout)
             self.igemm(srcs=[(hfin, cfin)], H=S, W=S, ks=3, N=nout, gn=g, act=1,
-                       bmat=self.packed("out.2.weight", _pack_conv),
-                       bias=self.packed("out.2.bias", lambda t: t.detach().float()), out=y_nhwc)
+                       bmat=self.packed("out.2.weight", "conv"),
+                       bias=self.packed("out.2.bias", "copy"), out=y_nhwc)
             if nout == 1:
                 self.y = y_nhwc.view(B, 1, S, S)
             else:

@@ -7,7 +7,42 @@ import torch
 from anoddpm_amd import _lib
 from anoddpm_amd._lib import (HeadArgs, ChanStatsArgs, GnFinalizeArgs, GnArgs, IgemmArgs, LinearArgs, PosembArgs, ResampleArgs, SoftmaxArgs, StemArgs,
                               check, current_stream, lib)
-from anoddpm_amd.unet import _pack_conv, _pack_wino
+
+
+# ---- host-side reference packers (fp64 transforms, torch ops): what the device packer anoddpm_pack_weights must reproduce
+def _pack_conv(w):
+    """OIHW / OI1 -> [taps][I/4][O][4] fp32 (B operand layout of the implicit GEMM)."""
+    if w.dim() == 3:
+        w = w.unsqueeze(-1)
+    o, i, kh, kw = w.shape
+    return (w.detach().float().permute(2, 3, 1, 0).reshape(kh * kw, i // 4, 4, o)
+            .permute(0, 1, 3, 2).contiguous())
+
+
+_WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+
+
+def _pack_wino(w):
+    """OIHW 3x3 -> Winograd F(2x2,3x3) weights U = G g G^T, laid out [16][I/4][O][4] (xi = 4*u + v)."""
+    o, i, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    G = _WINO_G.to(device=w.device, dtype=torch.float64)
+    U = torch.einsum("ua,oiab,vb->uvio", G, w.detach().double(), G).float()          # [4][4][I][O]
+    return U.reshape(16, i // 4, 4, o).permute(0, 1, 3, 2).contiguous()
+
+
+_WINO43_G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                          [0, 0, 1]], dtype=torch.float64)
+
+
+def _pack_wino43(w):
+    """OIHW 3x3 -> Winograd F(4x4,3x3) weights U = G g G^T (G 6x3, fp64, rounded once), laid out [36][I/4][O][4] (xi = 6*u + v)."""
+    o, i, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    G = _WINO43_G.to(device=w.device)
+    U = torch.einsum("ua,oiab,vb->uvio", G, w.detach().double(), G).float()          # [6][6][I][O]
+    return U.reshape(36, i // 4, 4, o).permute(0, 1, 3, 2).contiguous()
+
 
 
 def nhwc(x):
@@ -83,7 +118,6 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
     P = Hout * Hout
     Pin = srcs[0].shape[1] * srcs[0].shape[2]
     st = IgemmArgs()
-    from anoddpm_amd.unet import _pack_wino43
     wp = _pack_wino43(w) if cfg == 3 else (_pack_wino(w) if cfg == 2 else _pack_conv(w))
     out = torch.full((B, Hout, Hout, N), float("nan"), device=dev)
     st.a0, st.a1 = srcs[0].data_ptr(), srcs[1].data_ptr() if c1 else None

@@ -607,7 +607,7 @@ def test_gn_silu_backward(case):
 @pytest.mark.parametrize("N,K", [(64, 32), (128, 256), (96, 36)])
 def test_device_weight_packing_matches_host_packers(N, K):
     """anoddpm_pack_conv3x3 (training re-packs on the device) against the host packers used by the inference plan."""
-    from anoddpm_amd.unet import _pack_conv, _pack_wino
+    from hipops import _pack_conv, _pack_wino
     from anoddpm_amd._lib import check, current_stream, lib
     w = rnd(N, K, 3, 3, seed=111).to(dev())
     for bwd in (0, 1):

@@ -56,7 +56,7 @@ def test_wgrad_pointwise(B, P, c0, c1, N, gn, act, span):
 
 def test_pack_pointwise_and_small_conv():
     _lib, lib = L()
-    from anoddpm_amd.unet import _pack_conv
+    from hipops import _pack_conv
     torch.manual_seed(1)
     N, K = 24, 40
     w = torch.randn(N, K, device=DEV)

@@ -177,6 +177,13 @@ def test_packed_weights_are_not_repacked_every_forward():
         versions = [p._version for p in m.parameters()]
         m(x, t)
         m(x, t)
-    assert plan.token == tok and versions == [p._version for p in m.parameters()]
+    assert plan.token == tok and versions == [p._version for p in m.parameters()] and plan.pack_count == 1
     ptrs = {p.data_ptr() for p in m.parameters()}
-    assert all(dst.data_ptr() not in ptrs for _, _, dst in plan.packers)
+    assert all(st.out not in ptrs for _, st in plan._pack_jobs)
+    # a parameter update (optimizer step, load_state_dict) is picked up: exactly one more batched packing launch
+    with torch.no_grad():
+        y0 = m(x, t).clone()
+        for p in m.parameters():
+            p.mul_(1.01)
+        y1 = m(x, t)
+    assert plan.pack_count == 2 and not torch.equal(y0, y1)
