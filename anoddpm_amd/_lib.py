@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 (OP_WGRAD3, OP_WGRAD1, OP_GN_BWD, OP_PACK, OP_SOFTMAX_BWD, OP_TRANSPOSE, OP_LINEAR_BWD, OP_STEM_BWD, OP_HEAD_BWD,
@@ -44,7 +44,10 @@ class IgemmArgs(Structure):
                 ("H", c_int32), ("W", c_int32), ("ks", c_int32), ("a_mode", c_int32), ("act", c_int32),
                 ("b_mode", c_int32), ("ldb", c_int32), ("N", c_int32), ("temb_ld", c_int32),
                 ("out_ld", c_int32), ("res_ld", c_int32), ("B", c_int32), ("heads", c_int32),
-                ("ksplit", c_int32), ("cfg", c_int32), ("alpha", c_float), ("gn_ld", c_int32), ("stats", c_void_p), ("stats_rows", c_int32)]
+                ("ksplit", c_int32), ("cfg", c_int32), ("alpha", c_float), ("gn_ld", c_int32), ("stats", c_void_p), ("stats_rows", c_int32),
+                ("tail_csum", c_void_p), ("tail_other", c_void_p), ("tail_gamma", c_void_p), ("tail_beta", c_void_p),
+                ("tail_scale", c_void_p), ("tail_shift", c_void_p), ("tail_mean", c_void_p), ("tail_rstd", c_void_p),
+                ("tail_c1", c_int32), ("tail_groups", c_int32), ("tail_eps", c_float)]
 
 
 class GnArgs(Structure):
@@ -65,7 +68,7 @@ class GnFinalizeArgs(Structure):
                 ("scale", c_void_p), ("shift", c_void_p),
                 ("rows0", c_int32), ("rows1", c_int32), ("c0", c_int32), ("c1", c_int32),
                 ("P", c_int32), ("B", c_int32), ("groups", c_int32), ("eps", c_float),
-                ("mean_out", c_void_p), ("rstd_out", c_void_p)]
+                ("mean_out", c_void_p), ("rstd_out", c_void_p), ("fmt0", c_int32), ("fmt1", c_int32)]
 
 
 class HeadArgs(Structure):

@@ -71,7 +71,7 @@ extern "C" int anoddpm_debug_set(int32_t key, int32_t value)
     return ANODDPM_OK;
 }
 
-extern "C" int anoddpm_abi_version(void) { return 16; }
+extern "C" int anoddpm_abi_version(void) { return 17; }
 
 extern "C" const char *anoddpm_last_error(void) { return g_err; }
 

@@ -494,13 +494,125 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const anoddpm_
     }
 }
 
+// Split-K tail partitioned by (GroupNorm group, image): grid (tail_groups, Z).  A block folds the K slabs of ITS channels over
+// all pixels of its image -- so the per-channel sums it ends up with are complete and GroupNorm needs no second launch: it writes
+// them (fp64) to tail_csum and, with a consumer GroupNorm attached (tail_gamma), the group's scale / shift.  The group may reach
+// into the second source of a virtual concat: those channels' sums come from that tensor's tail_csum.  Every reduction runs in a
+// fixed order (deterministic).  Thread = (pixel row tr, channel quad tq) of the block's <= 64 own channels.
+constexpr int GT_NT = 512;             // threads of the group-partitioned tail
+constexpr int GT_PARTS = 8;            // row-sum partials per channel (second reduction stage)
+
+__global__ __launch_bounds__(GT_NT) void splitk_reduce_gn_kernel(const anoddpm_igemm_args a)
+{
+    __shared__ double lds_s[GT_NT * 4];
+    __shared__ double lds_q[GT_NT * 4];
+    __shared__ double part_s[GT_PARTS * 64];
+    __shared__ double part_q[GT_PARTS * 64];
+    __shared__ double grp[2];
+    const int P = a.H * a.W, N = a.N;
+    const int Z = a.B;                                          // heads == 1
+    const int z = blockIdx.y, g = blockIdx.x;
+    const int C = N + a.tail_c1;
+    const int cpg = C / a.tail_groups;
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;                // the group's channels in the concatenation
+    const int lo = c_lo < N ? c_lo : N, hi = c_hi < N ? c_hi : N;   // ... that belong to this output
+    const int nq = (hi - lo) >> 2;
+    const int tid = threadIdx.x;
+    double cs[4] = {0.0, 0.0, 0.0, 0.0}, cq[4] = {0.0, 0.0, 0.0, 0.0};
+    int rows = 0;
+    if (nq > 0) {
+        rows = GT_NT / nq;
+        const int tq = tid % nq, tr = tid / nq;
+        if (tr < rows) {
+            const int n0 = lo + tq * 4;
+            f32x4 add = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) add += ld4(a.bias + n0);
+            if (a.temb) add += ld4(a.temb + (int64_t)z * a.temb_ld + n0);
+            const int64_t slab = (int64_t)Z * P * N;
+            for (int pix = tr; pix < P; pix += rows) {
+                const float *src = a.ws + ((int64_t)z * P + pix) * N + n0;
+                f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+                if (a.res) rv = ld4(a.res + (int64_t)z * a.r_bs + (int64_t)pix * a.res_ld + n0);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+                for (int ks = 0; ks < a.ksplit; ++ks) v += ld4(src + ks * slab);      // slab order: as the plain tail
+                v = v * a.alpha + add;
+                if (a.res) v += rv;
+                *reinterpret_cast<f32x4 *>(a.out + (int64_t)z * a.o_bs + (int64_t)pix * a.out_ld + n0) = v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { cs[e] += (double)v[e]; cq[e] += (double)v[e] * (double)v[e]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { lds_s[tid * 4 + e] = cs[e]; lds_q[tid * 4 + e] = cq[e]; }
+    __syncthreads();
+    // per-channel totals over the pixel rows in two fixed-order stages: GT_PARTS partial sums per channel, then their sum
+    const int nown = hi - lo;                                   // <= 64
+    {
+        const int c = tid % 64, part = tid / 64;                // GT_NT / 64 == GT_PARTS
+        if (c < nown) {
+            const int cq4 = c >> 2, ce = c & 3;
+            const int r0 = (rows * part) / GT_PARTS, r1 = (rows * (part + 1)) / GT_PARTS;
+            double s = 0.0, q = 0.0;
+            for (int r = r0; r < r1; ++r) { s += lds_s[(r * nq + cq4) * 4 + ce]; q += lds_q[(r * nq + cq4) * 4 + ce]; }
+            part_s[part * 64 + c] = s;
+            part_q[part * 64 + c] = q;
+        }
+    }
+    __syncthreads();
+    double s = 0.0, q = 0.0;
+    if (tid < nown) {
+#pragma unroll
+        for (int p = 0; p < GT_PARTS; ++p) { s += part_s[p * 64 + tid]; q += part_q[p * 64 + tid]; }
+        double *dst = a.tail_csum + ((int64_t)z * N + lo + tid) * 2;
+        dst[0] = s;
+        dst[1] = q;
+    }
+    if (!a.tail_gamma) return;
+    // group statistics: own channels + the channels of the second source, channel order
+    __syncthreads();
+    if (tid < nown) { lds_s[tid] = s; lds_q[tid] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        double S = 0.0, Q = 0.0;
+        for (int c = 0; c < nown; ++c) { S += lds_s[c]; Q += lds_q[c]; }
+        const int o_lo = (c_lo > N ? c_lo : N) - N, o_hi = (c_hi > N ? c_hi : N) - N;
+        for (int c = o_lo; c < o_hi; ++c) {
+            const double *src = a.tail_other + ((int64_t)z * a.tail_c1 + c) * 2;
+            S += src[0];
+            Q += src[1];
+        }
+        const double n = (double)P * cpg;
+        const double mean = S / n;
+        double var = Q / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)a.tail_eps);
+        grp[0] = mean;
+        grp[1] = rstd;
+        if (a.tail_mean) {
+            a.tail_mean[(int64_t)z * a.tail_groups + g] = (float)mean;
+            a.tail_rstd[(int64_t)z * a.tail_groups + g] = (float)rstd;
+        }
+    }
+    __syncthreads();
+    if (tid < cpg) {
+        const int c = c_lo + tid;
+        const double sc = grp[1] * (double)a.tail_gamma[c];
+        a.tail_scale[(int64_t)z * C + c] = (float)sc;
+        a.tail_shift[(int64_t)z * C + c] = (float)((double)a.tail_beta[c] - grp[0] * sc);
+    }
+}
+
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Second launch of a split-K contraction (direct or Winograd): fold the slabs, add bias / temb / residual, and
 // (optionally) emit the GroupNorm statistics rows.
 void launch_splitk_tail(const anoddpm_igemm_args *a, int64_t Z, int64_t P, hipStream_t s)
 {
-    if (a->stats) {
+    if (a->tail_csum) {
+        hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((unsigned)a->tail_groups, (unsigned)Z), dim3(GT_NT), 0, s, *a);
+    } else if (a->stats) {
         hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3((unsigned)a->stats_rows, (unsigned)Z), dim3(256), 0, s, *a, a->stats_rows);
     } else {
         const int64_t total = Z * P * (a->N / 4);
@@ -526,6 +638,16 @@ extern "C" int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream)
     ANODDPM_REQUIRE(a->b_mode != 2 || a->N % 4 == 0, "igemm: b_mode 2 needs N %% 4 == 0");
     ANODDPM_REQUIRE(!a->stats || a->heads == 1, "igemm: fused statistics need heads == 1");
     ANODDPM_REQUIRE(!a->stats || a->ksplit == 1 || a->stats_rows >= 1, "igemm: split-K statistics need stats_rows");
+    if (a->tail_csum) {
+        ANODDPM_REQUIRE(a->ksplit > 1 && a->heads == 1 && !a->stats && a->N % 4 == 0, "igemm: the GroupNorm tail needs split-K, heads == 1 and no statistics rows");
+        ANODDPM_REQUIRE(a->tail_groups >= 1 && a->tail_groups <= 65535 && a->tail_c1 >= 0 && (a->N + a->tail_c1) % a->tail_groups == 0 &&
+                        ((a->N + a->tail_c1) / a->tail_groups) % 4 == 0 && (a->N + a->tail_c1) / a->tail_groups <= 64,
+                        "igemm: GroupNorm tail: (N + tail_c1) / tail_groups must be a multiple of 4 and <= 64");
+        ANODDPM_REQUIRE(a->tail_c1 == 0 || !a->tail_gamma || a->tail_other, "igemm: GroupNorm tail over a concatenation needs tail_other");
+        ANODDPM_REQUIRE(!a->tail_gamma || (a->tail_beta && a->tail_scale && a->tail_shift), "igemm: GroupNorm tail: null affine / output");
+        ANODDPM_REQUIRE((a->tail_mean == nullptr) == (a->tail_rstd == nullptr), "igemm: tail_mean and tail_rstd go together");
+        ANODDPM_REQUIRE(a->tail_gamma || a->tail_c1 == 0, "igemm: tail_c1 without a consumer GroupNorm");
+    }
     ANODDPM_REQUIRE(a->b_mode == 0 || a->ldb % 4 == 0, "igemm: ldb must be a multiple of 4");
     ANODDPM_REQUIRE(a->a0_ld % 4 == 0 && (a->c1 == 0 || a->a1_ld % 4 == 0), "igemm: pixel strides must be multiples of 4 floats");
     ANODDPM_REQUIRE(al16(a->a0) && al16(a->bmat) && (!a->a1 || al16(a->a1)), "igemm: operands must be 16-byte aligned");

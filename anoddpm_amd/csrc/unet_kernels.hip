@@ -177,7 +177,31 @@ __global__ __launch_bounds__(256) void gn_finalize2_kernel(anoddpm_gn_finalize_a
     double s = 0.0, q = 0.0;
     const int cbeg = g * cpg;
     const bool one_source = (cbeg + cpg <= a.c0) || (cbeg >= a.c0);       // block-uniform
-    if (one_source && (cpg & 1) == 0 && (a.c0 & 1) == 0 && (a.c1 & 1) == 0) {
+    if (a.fmt0 != 0 || (a.c1 && a.fmt1 != 0)) {
+        // at least one source is a single row of fp64 sums (anoddpm_igemm_args.tail_csum): per channel, rows strided over threads
+        for (int cc = 0; cc < cpg; ++cc) {
+            const int c = cbeg + cc;
+            const bool first = c < a.c0;
+            const int fmt = first ? a.fmt0 : a.fmt1;
+            const int cl = first ? c : c - a.c0, cw = first ? a.c0 : a.c1;
+            if (fmt != 0) {
+                if (tid == 0) {
+                    const double *st = reinterpret_cast<const double *>(first ? a.stats0 : a.stats1) + ((int64_t)b * cw + cl) * 2;
+                    s += st[0];
+                    q += st[1];
+                }
+            } else {
+                const float *st = first ? a.stats0 : a.stats1;
+                const int rows = first ? a.rows0 : a.rows1;
+                st += (int64_t)b * rows * cw * 2;
+                for (int r = tid; r < rows; r += 256) {
+                    const float2 v = *reinterpret_cast<const float2 *>(st + ((int64_t)r * cw + cl) * 2);
+                    s += (double)v.x;
+                    q += (double)v.y;
+                }
+            }
+        }
+    } else if (one_source && (cpg & 1) == 0 && (a.c0 & 1) == 0 && (a.c1 & 1) == 0) {
         // 2*cpg floats = cpg/2 float4 per row, 16-byte aligned
         const float *st;
         int rows, cl, cw;
@@ -649,7 +673,7 @@ extern "C" int anoddpm_gn_finalize(const anoddpm_gn_finalize_args *a, void *stre
     ANODDPM_REQUIRE(a->c0 > 0 && a->c1 >= 0 && (a->c1 == 0 || a->stats1), "gn_finalize: bad channel counts");
     const int C = a->c0 + a->c1;
     ANODDPM_REQUIRE(a->groups > 0 && a->groups <= 65535 && C % a->groups == 0 && C / a->groups <= 256, "gn_finalize: bad group size");
-    ANODDPM_REQUIRE(a->B > 0 && a->B <= 65535 && a->P > 0 && a->rows0 > 0 && (a->c1 == 0 || a->rows1 > 0), "gn_finalize: bad sizes");
+    ANODDPM_REQUIRE(a->B > 0 && a->B <= 65535 && a->P > 0 && (a->fmt0 != 0 || a->rows0 > 0) && (a->c1 == 0 || a->fmt1 != 0 || a->rows1 > 0), "gn_finalize: bad sizes");
     ANODDPM_REQUIRE((a->mean_out == nullptr) == (a->rstd_out == nullptr), "gn_finalize: mean_out and rstd_out go together");
     hipLaunchKernelGGL(gn_finalize2_kernel, dim3(a->groups, a->B), dim3(256), 0, anoddpm::as_stream(stream), *a);
     return anoddpm::check_launch("gn_finalize");

@@ -183,14 +183,15 @@ class TrainPlan(_Plan):
         for buf, c in [(s[0], s[1]) for s in srcs]:
             if buf.data_ptr() not in self.stats_of:
                 self.chan_stats(buf, c, P)
+        job = self.gn_tail_job(srcs, self.W(prefix + ".weight"), self.W(prefix + ".bias"), want_mean=True)
+        if job is not None:
+            return job
         st = GnFinalizeArgs()
-        s0, r0 = self.stats_of[srcs[0][0].data_ptr()]
-        st.stats0, st.rows0 = s0.data_ptr(), r0
+        self.stats_source(st, 0, srcs[0][0], c0)
         if c1:
-            s1, r1 = self.stats_of[srcs[1][0].data_ptr()]
-            st.stats1, st.rows1 = s1.data_ptr(), r1
+            self.stats_source(st, 1, srcs[1][0], c1)
         else:
-            st.stats1, st.rows1 = None, 0
+            st.stats1, st.rows1, st.fmt1 = None, 0, 0
         st.gamma, st.beta = self.W(prefix + ".weight"), self.W(prefix + ".bias")
         scale, shift, mean, rstd = self.buf(B, C), self.buf(B, C), self.buf(B, 32), self.buf(B, 32)
         st.scale, st.shift, st.mean_out, st.rstd_out = scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr()

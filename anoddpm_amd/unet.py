@@ -577,7 +577,46 @@ class _Plan:
         st.a, st.stats, st.a_bs = buf.data_ptr(), stats.data_ptr(), P * C
         st.C, st.a_ld, st.P, st.B, st.nslab = C, C, P, B, nslab
         self.add(_lib.OP_CHAN_STATS, st)
-        self.stats_of[buf.data_ptr()] = (stats, nslab)
+        self.stats_of[buf.data_ptr()] = ("rows", stats, nslab)
+
+    fuse_gn_tail = True          # split-K tails fold the consumer's GroupNorm in (anoddpm_igemm_args.tail_*); see gn()
+
+    def stats_source(self, st, which, src, c):
+        """Point the `which`-th statistics source of a GnFinalizeArgs at the partial sums of tensor `src`."""
+        kind, buf, extra = self.stats_of[src.data_ptr()]
+        setattr(st, f"stats{which}", buf.data_ptr())
+        setattr(st, f"rows{which}", extra if kind == "rows" else 1)
+        setattr(st, f"fmt{which}", 0 if kind == "rows" else 1)
+
+    def gn_tail_job(self, srcs, gamma, beta, want_mean=False):
+        """GroupNorm over `srcs` finished inside the split-K tail that produces srcs[0] (no launch of its own): possible when that
+        tensor comes from a split-K contraction with the group-partitioned tail (its folded sums are complete there), no other
+        GroupNorm has claimed the tail yet, and the second source -- the skip tensor of a virtual concat -- has folded sums too.
+        Returns (scale, shift[, mean, rstd]) or None."""
+        B = self.B
+        c0 = srcs[0][1]
+        c1 = srcs[1][1] if len(srcs) > 1 else 0
+        C = c0 + c1
+        ent = self.stats_of.get(srcs[0][0].data_ptr())
+        if ent is None or ent[0] != "csum" or ent[2].tail_gamma or C % 32 or (C // 32) % 4 or C // 32 > 64:
+            return None
+        other = None
+        if c1:
+            e1 = self.stats_of.get(srcs[1][0].data_ptr())
+            if e1 is None or e1[0] != "csum":
+                return None
+            other = e1[1]
+        st = ent[2]
+        scale, shift = self.buf(B, C), self.buf(B, C)
+        st.tail_gamma, st.tail_beta = gamma, beta
+        st.tail_scale, st.tail_shift = scale.data_ptr(), shift.data_ptr()
+        st.tail_other, st.tail_c1 = (other.data_ptr() if other is not None else None), c1
+        st.tail_groups, st.tail_eps = 32, 1e-5
+        if want_mean:
+            mean, rstd = self.buf(B, 32), self.buf(B, 32)
+            st.tail_mean, st.tail_rstd = mean.data_ptr(), rstd.data_ptr()
+            return scale, shift, mean, rstd
+        return scale, shift
 
     def gn(self, srcs, P, gamma_key, beta_key):
         """GroupNorm(32) affine of one or two concatenated sources from their per-channel partial sums
@@ -589,16 +628,17 @@ class _Plan:
         for buf, c in [(s[0], s[1]) for s in srcs]:
             if buf.data_ptr() not in self.stats_of:
                 self.chan_stats(buf, c, P)
+        gamma, beta = self.packed(gamma_key, "copy").data_ptr(), self.packed(beta_key, "copy").data_ptr()
+        job = self.gn_tail_job(srcs, gamma, beta)
+        if job is not None:
+            return job
         st = GnFinalizeArgs()
-        s0, r0 = self.stats_of[srcs[0][0].data_ptr()]
-        st.stats0, st.rows0 = s0.data_ptr(), r0
+        self.stats_source(st, 0, srcs[0][0], c0)
         if c1:
-            s1, r1 = self.stats_of[srcs[1][0].data_ptr()]
-            st.stats1, st.rows1 = s1.data_ptr(), r1
+            self.stats_source(st, 1, srcs[1][0], c1)
         else:
-            st.stats1, st.rows1 = None, 0
-        st.gamma = self.packed(gamma_key, "copy").data_ptr()
-        st.beta = self.packed(beta_key, "copy").data_ptr()
+            st.stats1, st.rows1, st.fmt1 = None, 0, 0
+        st.gamma, st.beta = gamma, beta
         scale, shift = self.buf(B, C), self.buf(B, C)
         st.scale, st.shift = scale.data_ptr(), shift.data_ptr()
         st.c0, st.c1, st.P, st.B, st.groups, st.eps = c0, c1, P, B, 32, 1e-5
@@ -698,19 +738,27 @@ class _Plan:
             rows = tiles * {2: 4, 3: 1}.get(cfg, 2)            # partial rows per pixel tile (F(4x4,3x3): one per workgroup)
             stats = self.buf(B, rows, N, 2)
             st.stats = stats.data_ptr()
-            self.stats_of[out.data_ptr()] = (stats, rows)
+            self.stats_of[out.data_ptr()] = ("rows", stats, rows)
         st.stats_rows = 0
-        if want_stats and ksplit > 1 and heads == 1:
+        st.tail_csum = None
+        if (want_stats and ksplit > 1 and heads == 1 and N % 128 == 0 and self.fuse_gn_tail
+                and P <= int(os.environ.get("ANODDPM_GN_TAIL_MAX_P", 256)) and os.environ.get("ANODDPM_NO_GN_TAIL", "0") != "1"):
+            # group-partitioned tail: folded per-channel sums now, the consumer's GroupNorm attached later by gn()
+            csum = self.buf(B, N, 2, dtype=torch.float64)
+            st.tail_csum, st.tail_groups, st.tail_c1, st.tail_eps = csum.data_ptr(), 32, 0, 1e-5
+            st.tail_gamma = st.tail_beta = st.tail_scale = st.tail_shift = st.tail_other = st.tail_mean = st.tail_rstd = None
+            self.stats_of[out.data_ptr()] = ("csum", csum, st)
+        elif want_stats and ksplit > 1 and heads == 1:
             # the split-K reduction emits the statistics: one row per pixel slab
             rows_per_block = 256 // min(N // 4, 256)          # pixel rows a 256-thread block covers per pass
             nslab = max(1, -(-P // (4 * rows_per_block)))     # <= 4 pixels per thread: the k-slab loads are serial
             stats = self.buf(B, nslab, N, 2)
             st.stats, st.stats_rows = stats.data_ptr(), nslab
-            self.stats_of[out.data_ptr()] = (stats, nslab)
+            self.stats_of[out.data_ptr()] = ("rows", stats, nslab)
         self.add(_lib.OP_IGEMM, st)
         self.igemm_log.append(dict(wino=(cfg in (2, 3)), f43=(cfg == 3), kind=kind, H=H, W=W, K=K, N=N, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads,
                                    cfg=cfg, ksplit=ksplit, dual=bool(c1), gflop=2.0 * K * N * ks * ks * P * Z / 1e9))
-        if want_stats and st.stats is None:
+        if want_stats and st.stats is None and not st.tail_csum:
             self.chan_stats(out, N, P)
         fl = 2.0 * K * N * ks * ks * P * Z
         self.flops[kind] = self.flops.get(kind, 0.0) + fl

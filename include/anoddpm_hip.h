@@ -209,6 +209,19 @@ typedef struct {
                                        without re-reading the tensor.  With ksplit > 1 the split-K reduction
                                        emits them instead, as [B][stats_rows][N][2] */
     int32_t stats_rows;             /* split-K only: number of pixel slabs (= rows) of the statistics */
+    /* Split-K tail with the consumer's GroupNorm folded in (ksplit > 1, heads == 1, N % 128 == 0; `stats` must be NULL).  With
+     * tail_csum set, the tail launch is partitioned by (GroupNorm group, image) instead of pixel slabs: a workgroup folds the K
+     * slabs of its channels over ALL pixels of its image, so it owns complete per-channel sums -- it writes them to tail_csum and,
+     * when tail_gamma is set, finishes GroupNorm(tail_groups, N + tail_c1) of torch.cat([out, other], 1) on the spot (UNet.py:409-411,
+     * 402): scale / shift of its group's channels, the other source's channels taken from ITS folded sums.  One launch replaces the
+     * statistics rows + anoddpm_gn_finalize of the plain tail.  (N + tail_c1) / tail_groups must be a multiple of 4. */
+    double *tail_csum;              /* [B][N][2] {sum, sum of squares} over the image, fp64 */
+    const double *tail_other;       /* [B][tail_c1][2] of the second source, or NULL */
+    const float *tail_gamma, *tail_beta;   /* [N + tail_c1], or NULL: folded sums only */
+    float *tail_scale, *tail_shift; /* [B][N + tail_c1] */
+    float *tail_mean, *tail_rstd;   /* optional [B][tail_groups] (training) */
+    int32_t tail_c1, tail_groups;
+    float tail_eps;
 } anoddpm_igemm_args;
 
 int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream);
@@ -252,6 +265,8 @@ typedef struct {
     int32_t P, B, groups;
     float eps;
     float *mean_out, *rstd_out;     /* optional [B][groups]: saved for anoddpm_gn_silu_backward (training) */
+    int32_t fmt0, fmt1;             /* 0: statsN = fp32 rows as above; 1: statsN = ONE row of fp64 pairs [B][c][2] (the tail_csum of
+                                       anoddpm_igemm_args; rowsN is ignored) */
 } anoddpm_gn_finalize_args;
 
 int anoddpm_gn_finalize(const anoddpm_gn_finalize_args *a, void *stream);

@@ -108,7 +108,7 @@ _LAST_KEEP = None
 
 
 def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=None, res=None, cfg=0, ksplit=1,
-               stats_out=None):
+               stats_out=None, gn_tail=None):
     """srcs: NHWC sources; w: OIHW weights.  Returns NHWC [B,Hout,Hout,N]."""
     dev = srcs[0].device
     B = srcs[0].shape[0]
@@ -138,7 +138,26 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
     st.cfg, st.ksplit = cfg, ksplit
     ws = torch.empty(max(1, ksplit * B * P * N), device=dev) if ksplit > 1 else None
     st.ws = ws.data_ptr() if ws is not None else None
-    if stats_out is not None and ksplit > 1:
+    if gn_tail is not None:
+        # split-K tail with the consumer GroupNorm folded in: gn_tail = dict(gamma, beta[, other_csum], want_mean) -> filled with
+        # csum / scale / shift / mean / rstd
+        assert ksplit > 1
+        c1t = gn_tail["other_csum"].shape[1] if gn_tail.get("other_csum") is not None else 0
+        csum = torch.full((B, N, 2), float("nan"), device=dev, dtype=torch.float64)
+        st.tail_csum, st.tail_c1, st.tail_groups, st.tail_eps = csum.data_ptr(), c1t, 32, 1e-5
+        gn_tail["csum"] = csum
+        if gn_tail.get("gamma") is not None:
+            sc = torch.full((B, N + c1t), float("nan"), device=dev)
+            sh = torch.full((B, N + c1t), float("nan"), device=dev)
+            st.tail_gamma, st.tail_beta = gn_tail["gamma"].data_ptr(), gn_tail["beta"].data_ptr()
+            st.tail_scale, st.tail_shift = sc.data_ptr(), sh.data_ptr()
+            st.tail_other = gn_tail["other_csum"].data_ptr() if c1t else None
+            gn_tail["scale"], gn_tail["shift"] = sc, sh
+            if gn_tail.get("want_mean"):
+                gn_tail["mean"] = torch.full((B, 32), float("nan"), device=dev)
+                gn_tail["rstd"] = torch.full((B, 32), float("nan"), device=dev)
+                st.tail_mean, st.tail_rstd = gn_tail["mean"].data_ptr(), gn_tail["rstd"].data_ptr()
+    elif stats_out is not None and ksplit > 1:
         nslab = 3 if P > 16 else 1
         stats = torch.full((B, nslab, N, 2), float("nan"), device=dev)
         st.stats, st.stats_rows = stats.data_ptr(), nslab
@@ -155,7 +174,7 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
     check(lib().anoddpm_igemm(ctypes.byref(st), current_stream()), "igemm")
     torch.cuda.synchronize()
     global LAST_IGEMM, _LAST_KEEP
-    LAST_IGEMM, _LAST_KEEP = st, (srcs, wp, out, gn, bias, temb, res, ws)        # tools/bench_conv.py re-launches the prepared call
+    LAST_IGEMM, _LAST_KEEP = st, (srcs, wp, out, gn, bias, temb, res, ws, gn_tail)        # tools/bench_conv.py re-launches the prepared call
     return out
 
 

@@ -620,3 +620,61 @@ def test_device_weight_packing_matches_host_packers(N, K):
             ref = host(src).reshape(-1)
             assert out.shape == ref.shape
             assert torch.allclose(out, ref, rtol=1e-6, atol=1e-7), (mode, bwd, (out - ref).abs().max().item())
+
+
+@pytest.mark.parametrize("cfg,ks,H,K,N,c1,ksplit", [(2, 3, 16, 256, 256, 0, 4), (2, 3, 32, 128, 128, 256, 2), (1, 3, 8, 256, 512, 0, 8),
+                                                    (1, 1, 16, 512, 256, 128, 4), (2, 3, 16, 128, 256, 384, 2)])
+def test_splitk_tail_with_fused_groupnorm(cfg, ks, H, K, N, c1, ksplit):
+    """anoddpm_igemm's group-partitioned split-K tail (tail_csum / tail_gamma ...): same output as the slab tail, folded per-channel
+    sums, and the consumer GroupNorm(32, N + c1) over the virtual concat [out, other] (UNet.py:402, 409-411) equal to
+    torch.nn.functional.group_norm's statistics -- incl. a group that straddles the two sources (N = 256, c1 = 128: 12 per group)."""
+    import hipops as H_
+    DEV = "cuda:0"
+    torch.manual_seed(7)
+    B = 3
+    x = torch.randn(B, H, H, K, device=DEV)
+    w = torch.randn(N, K, ks, ks, device=DEV) * (1.0 / (K * ks * ks) ** 0.5)
+    bias = torch.randn(N, device=DEV)
+    temb = torch.randn(B, N, device=DEV)
+    res = torch.randn(B, H, H, N, device=DEV)
+    ref = H_.conv_igemm([x], w, bias, Hout=H, ks=ks, temb=temb, res=res, cfg=cfg, ksplit=ksplit)
+    other = torch.randn(B, H, H, c1, device=DEV) * 1.7 + 0.3 if c1 else None
+    other_csum = None
+    if c1:
+        of = other.double().reshape(B, -1, c1)
+        other_csum = torch.stack([of.sum(1), (of * of).sum(1)], dim=-1).contiguous()
+    C = N + c1
+    gamma, beta = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+    tail = dict(gamma=gamma, beta=beta, other_csum=other_csum, want_mean=True)
+    out = H_.conv_igemm([x], w, bias, Hout=H, ks=ks, temb=temb, res=res, cfg=cfg, ksplit=ksplit, gn_tail=tail)
+    assert (out - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()        # same slab order; the compilers' FMA choices may differ
+    of = out.double().reshape(B, -1, N)
+    np.testing.assert_allclose(tail["csum"][..., 0].cpu().numpy(), of.sum(1).cpu().numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(tail["csum"][..., 1].cpu().numpy(), (of * of).sum(1).cpu().numpy(), rtol=1e-9)
+    cat = torch.cat([out, other], dim=-1) if c1 else out
+    xn = cat.permute(0, 3, 1, 2).double()
+    g = xn.reshape(B, 32, -1)
+    mean, var = g.mean(-1), g.var(-1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    np.testing.assert_allclose(tail["mean"].cpu().numpy(), mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(tail["rstd"].cpu().numpy(), rstd.cpu().numpy(), rtol=1e-5)
+    y = torch.nn.functional.group_norm(xn, 32, gamma.double(), beta.double(), eps=1e-5).permute(0, 2, 3, 1)
+    got = cat.double() * tail["scale"].double()[:, None, None, :] + tail["shift"].double()[:, None, None, :]
+    assert ((got - y).abs().max() / y.abs().max()).item() < 1e-5
+    # folded sums only (no consumer GroupNorm attached)
+    tail2 = dict(gamma=None)
+    out2 = H_.conv_igemm([x], w, bias, Hout=H, ks=ks, temb=temb, res=res, cfg=cfg, ksplit=ksplit, gn_tail=tail2)
+    assert torch.equal(out2, out)
+    np.testing.assert_allclose(tail2["csum"].cpu().numpy(), tail["csum"].cpu().numpy(), rtol=1e-12)      # another partition: another fp64 summation order
+    # anoddpm_gn_finalize on the folded sums (the launch a second consumer GroupNorm of the same tensor takes)
+    from anoddpm_amd._lib import GnFinalizeArgs, check, current_stream, lib
+    import ctypes
+    st = GnFinalizeArgs()
+    sc, sh = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    st.stats0, st.rows0, st.fmt0 = tail["csum"].data_ptr(), 1, 1
+    st.stats1, st.rows1, st.fmt1 = (other_csum.data_ptr(), 1, 1) if c1 else (None, 0, 0)
+    st.gamma, st.beta, st.scale, st.shift = gamma.data_ptr(), beta.data_ptr(), sc.data_ptr(), sh.data_ptr()
+    st.c0, st.c1, st.P, st.B, st.groups, st.eps = N, c1, H * H, B, 32, 1e-5
+    check(lib().anoddpm_gn_finalize(ctypes.byref(st), current_stream()), "gn_finalize")
+    assert (sc - tail["scale"]).abs().max().item() < 1e-6 * tail["scale"].abs().max().item()
+    assert (sh - tail["shift"]).abs().max().item() < 1e-5 * max(tail["shift"].abs().max().item(), 1.0)
