@@ -22,6 +22,7 @@ SOURCES = {
     "igemm.hip": [],
     "winograd.hip": [],
     "winograd43.hip": [],
+    "winograd43r.hip": [],
     "pointwise.hip": [],
     "attention.hip": [],
     "executor.hip": [],

@@ -405,6 +405,10 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
     ANODDPM_REQUIRE(a->B <= 65535, "winograd43: batch too large");
     const bool fast = a->gn_scale && a->act;
     const int dbg = anoddpm::g_debug[2];
+    // 128-channel grid: the channel-sliced kernel (output transform in registers, winograd43r.hip); ANODDPM_DEBUG5=1 keeps this
+    // file's position-sliced kernel
+    // (ANODDPM_DEBUG5=3: also where this file's 64-channel variant would be chosen -- the op tests reach the kernel on small shapes)
+    if (dbg == 0 && ((!half && anoddpm::g_debug[5] != 1) || (a->N % 128 == 0 && anoddpm::g_debug[5] == 3))) return launch_winograd43r(a, s);
     if (fast && dbg == 1) hipLaunchKernelGGL((wino43_kernel<true, 1>), grid, dim3(F4_NT), 0, s, *a);
     else if (fast && dbg == 2) hipLaunchKernelGGL((wino43_kernel<true, 2>), grid, dim3(F4_NT), 0, s, *a);
     else if (fast && dbg == 3) hipLaunchKernelGGL((wino43_kernel<true, 3>), grid, dim3(F4_NT), 0, s, *a);

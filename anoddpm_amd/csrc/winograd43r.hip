@@ -1,0 +1,346 @@
+// Winograd F(4x4,3x3) convolution, channel-sliced variant of winograd43.hip for 128-channel workgroups (cfg = 3 of anoddpm_igemm).
+//
+// Same contract and the same staging / input transform as wino43_kernel (nn.Conv2d 3x3, UNet.py:172,193, with GroupNorm-apply +
+// SiLU, nearest-x2 and the two-source concat fused into the operand load; bias / time-embedding / residual / GroupNorm statistics
+// in the epilogue).  What differs is who owns which accumulator:
+//
+//   wino43_kernel   wave w = transform positions 3w..3w+2 of ALL 128 channels.  The output transform Y = A^T M A needs the 36
+//                   positions of a (tile, channel) together, so the 288 KB of accumulators go through LDS in three rounds
+//                   (108 ds_write + 108 ds_read per thread, six barriers): ~13 % of a workgroup's life at K = 128.
+//   this kernel     wave w = ALL 36 positions of channels 16w..16w+15 (8 waves, 144 accumulator registers each, two waves per
+//                   SIMD).  A lane then holds the complete 6x6 transform-domain block of four tiles of one channel: the output
+//                   transform, bias / embedding / residual add, the 16 stores per tile and the GroupNorm sums all happen in
+//                   registers -- no exchange buffer, no barrier after the K loop, and the statistics row needs no cross-wave fold.
+//                   Price: every wave reads all of V (36 ds_read_b128 per 16-channel chunk instead of 3; LDS has the bandwidth:
+//                   ~2.3 k of the chunk's 9.2 k MFMA cycles), and the input transform's 768 items run on 512 threads.
+//
+// K advances 16 channels per iteration; per iteration a wave issues 144 v_mfma_f32_16x16x4_f32 (16 tiles x 16 channels x 4 k),
+// 36 A-fragment reads (LDS) and 36 B-fragment loads (U[pos][k/4][n][4] from L2, six-deep register ring).
+#include "common.h"
+
+using anoddpm::silu_f;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int R4_NT = 512;                 // threads: 8 waves
+constexpr int R4_KC = 16;                  // channels per K iteration
+constexpr int R4_PW = 18;                  // patch width / height (16 + 2)
+constexpr int R4_PPIX = R4_PW * R4_PW;     // 324 patch pixels
+constexpr int R4_PITCH = 5;                // float4 per patch pixel (4 quads + 1 pad)
+constexpr int R4_PJ = 3;                   // staging slots per thread (3 * 512 = 1536 >= 324 * 4)
+constexpr int R4_SLOTPX = R4_PJ * R4_NT / 4;          // 384 pixel slots per buffer
+constexpr int R4_DT = R4_SLOTPX * R4_PITCH;           // float4 per patch buffer
+constexpr int R4_V = 36 * 16 * 4;                     // float4 per V buffer: [pos][tile][quad]
+constexpr int R4_LDS_FLOATS = (2 * R4_DT + 2 * R4_V) * 4;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const float *base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7ffffffe, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned wave_bytes)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)wave_bytes, 0));
+}
+
+// A^T of F(4x4,3x3) applied to six values: rows (1 1 1 1 1 0), (0 1 -1 2 -2 0), (0 1 1 4 4 0), (0 1 -1 8 -8 1)
+__device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4])
+{
+    const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    o[0] = m[0] + s12 + s34;
+    o[1] = d12 + 2.f * d34;
+    o[2] = s12 + 4.f * s34;
+    o[3] = d12 + 8.f * d34 + m[5];
+}
+
+// DBG (timing ablations only, wrong results; ANODDPM_DEBUG6): 1 no epilogue, 2 no input transform, 3 no patch staging, 4 no B requests
+// R4_RING = B-fragment requests in flight per wave
+template <bool FAST, int DBG = 0, int R4_RING = 6>
+__global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_args a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[R4_LDS_FLOATS];
+    f32x4 *ldsD = reinterpret_cast<f32x4 *>(lds);
+    f32x4 *ldsV = ldsD + 2 * R4_DT;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W;
+    const int K = a.c0 + a.c1, N = a.N, K4 = K >> 2;
+    const int tiles_x = W >> 4;
+    const int y0 = (blockIdx.x / tiles_x) * 16, x0 = (blockIdx.x % tiles_x) * 16;
+    const int n0 = blockIdx.y * 128;
+    const int b = blockIdx.z;
+    const int a_mode = a.a_mode;
+
+    const float *A0 = a.a0 + (int64_t)b * a.a0_bs;
+    const float *A1 = a.a1 ? a.a1 + (int64_t)b * a.a1_bs : nullptr;
+    const float *gsc = a.gn_scale ? a.gn_scale + (int64_t)b * a.gn_ld : nullptr;
+    const float *gsh = a.gn_shift ? a.gn_shift + (int64_t)b * a.gn_ld : nullptr;
+    const bool affine = gsc != nullptr, act = a.act != 0;
+    const int nchunks = K / R4_KC;
+
+    // ---- patch staging (pixel = idx >> 2, quad = idx & 3): geometry fixed for the workgroup
+    int spix[R4_PJ];
+    const int pq = tid & 3;
+#pragma unroll
+    for (int j = 0; j < R4_PJ; ++j) {
+        const int p = (tid + j * R4_NT) >> 2;
+        const int py = p / R4_PW, px = p - py * R4_PW;
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        int sp = -1;
+        if (p < R4_PPIX && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            sp = (a_mode == 0) ? gy * W + gx : (gy >> 1) * (W >> 1) + (gx >> 1);
+        spix[j] = sp;
+    }
+    f32x4 praw[R4_PJ];
+    f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rA0 = rsrc(A0), rA1 = rsrc(A1 ? A1 : A0);
+    const __amdgpu_buffer_rsrc_t rSc = rsrc(gsc ? gsc : A0), rSh = rsrc(gsh ? gsh : A0);
+    auto load_patch = [&](int chunk) {                              // unconditional loads, clamped addresses
+        const int kbase = chunk * R4_KC;
+        const bool first = kbase < a.c0;
+        const __amdgpu_buffer_rsrc_t r = first ? rA0 : rA1;
+        const unsigned ld = (unsigned)(first ? a.a0_ld : a.a1_ld);
+        const unsigned koff = (unsigned)(first ? kbase : kbase - a.c0) * 4u;
+#pragma unroll
+        for (int j = 0; j < R4_PJ; ++j) {
+            const unsigned sp = spix[j] >= 0 ? (unsigned)spix[j] : 0u;
+            praw[j] = bld4(r, (sp * ld + (unsigned)(pq * 4)) * 4u, koff);
+        }
+    };
+    auto store_patch = [&](int buf, int chunk) {                    // GroupNorm-apply + SiLU, zero padding AFTER it
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (FAST || affine) {
+            asc = bld4(rSc, (unsigned)(pq * 16), (unsigned)(chunk * R4_KC) * 4u);
+            ash = bld4(rSh, (unsigned)(pq * 16), (unsigned)(chunk * R4_KC) * 4u);
+        }
+#pragma unroll
+        for (int j = 0; j < R4_PJ; ++j) {
+            const int idx = tid + j * R4_NT;
+            f32x4 v = praw[j];
+            if (FAST) {
+                v = v * asc + ash;
+                v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
+            } else {
+                if (affine) v = v * asc + ash;
+                if (act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+            }
+            ldsD[buf * R4_DT + (idx >> 2) * R4_PITCH + (idx & 3)] = spix[j] >= 0 ? v : zero;
+        }
+    };
+
+    // ---- input transform: 768 items = 16 tiles x 8 channel pairs x 6 transform rows, as twelve "virtual waves" of 64 items
+    // (virtual wave: row u, tile-row pair; lane: channel pair = lane & 7, tile slot = lane >> 3 -- the LDS service groups of
+    // wino43_kernel).  Physical wave w runs (u = w % 6, pair = w / 6); waves 2..5 also run (u = w, pair 1) -- the SAME row
+    // coefficients at a constant address offset -- so every SIMD hosts three passes per chunk (balanced issue time) and the
+    // coefficients stay loop-invariant scalars.
+    const int tu = wave % 6;
+    const int tpair = lane & 7;
+    const int ttile = ((wave / 6) * 2 + (lane >> 5)) * 4 + ((lane >> 3) & 3);
+    const int tbase2 = (((4 * (ttile >> 2)) * R4_PW + 4 * (ttile & 3)) * R4_PITCH) * 2 + tpair;      // float2 index of the tile's patch corner
+    const bool two_pass = wave >= 2 && wave <= 5;                   // wave-uniform
+    constexpr int PASS_D = 8 * R4_PW * R4_PITCH * 2;                // tile row + 2 = patch row + 8 (float2 units)
+    constexpr int PASS_V = 8 * 8;                                   // tile + 8 in V[pos][tile][pair]
+    // B^T row u as (patch row, coefficient) pairs -- every row of B^T touches at most four patch rows:
+    //   u0: 4 d0 - 5 d2 + d4        u1: -4 d1 - 4 d2 + d3 + d4     u2: 4 d1 - 4 d2 - d3 + d4
+    //   u3: -2 d1 - d2 + 2 d3 + d4  u4: 2 d1 - d2 - 2 d3 + d4      u5: 4 d1 - 5 d3 + d5
+    const int tr0 = (tu == 0) ? 0 : 1, tr1 = (tu == 5) ? 3 : 2, tr2 = (tu == 0) ? 4 : ((tu == 5) ? 5 : 3), tr3 = 4;
+    const float tc0 = (tu == 0) ? 4.f : (tu == 1 ? -4.f : (tu == 2 ? 4.f : (tu == 3 ? -2.f : (tu == 4 ? 2.f : 4.f))));
+    const float tc1 = (tu == 0 || tu == 5) ? -5.f : ((tu == 1 || tu == 2) ? -4.f : -1.f);
+    const float tc2 = (tu == 0 || tu == 5) ? 1.f : (tu == 1 ? 1.f : (tu == 2 ? -1.f : (tu == 3 ? 2.f : -2.f)));
+    const float tc3 = (tu == 0 || tu == 5) ? 0.f : 1.f;
+    const int to0 = tr0 * R4_PW * R4_PITCH * 2, to1 = tr1 * R4_PW * R4_PITCH * 2, to2 = tr2 * R4_PW * R4_PITCH * 2, to3 = tr3 * R4_PW * R4_PITCH * 2;
+    auto transform = [&](int pbuf, int vbuf, int dofs, int vofs) {
+        const f32x2 *D = reinterpret_cast<const f32x2 *>(ldsD + pbuf * R4_DT) + tbase2 + dofs;
+        f32x2 t[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            t[j] = tc0 * D[to0 + j * R4_PITCH * 2] + tc1 * D[to1 + j * R4_PITCH * 2] + tc2 * D[to2 + j * R4_PITCH * 2] + tc3 * D[to3 + j * R4_PITCH * 2];
+        const f32x2 p = t[4] - 4.f * t[2], q = t[3] - 4.f * t[1], r = t[4] - t[2], s = t[3] - t[1];
+        f32x2 *V = reinterpret_cast<f32x2 *>(ldsV + vbuf * R4_V) + ((tu * 6) * 16 + ttile) * 8 + tpair + vofs;
+        V[0 * 128] = 4.f * t[0] - 5.f * t[2] + t[4];
+        V[1 * 128] = p + q;
+        V[2 * 128] = p - q;
+        V[3 * 128] = r + 2.f * s;
+        V[4 * 128] = r - 2.f * s;
+        V[5 * 128] = 4.f * t[1] - 5.f * t[3] + t[5];
+    };
+    auto transform_all = [&](int pbuf, int vbuf) {
+        transform(pbuf, vbuf, 0, 0);
+        if (two_pass) transform(pbuf, vbuf, PASS_D, PASS_V);        // wave-uniform branch
+    };
+
+    // ---- accumulators: all 36 positions x this wave's 16 channels x 16 tiles
+    f32x4 acc[36];
+#pragma unroll
+    for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int nw = n0 + wave * 16 + l15;                            // this lane's output channel
+    const __amdgpu_buffer_rsrc_t rU = rsrc(a.bmat);
+    const unsigned xi_bytes = (unsigned)K4 * (unsigned)N * 16u;      // bytes per position of U
+    const unsigned ulane = ((unsigned)kq * (unsigned)N + (unsigned)nw) * 16u;   // + chunk*4*N*16 + pos*xi_bytes
+    const int vread = l15 * 4 + kq;                                  // + pos*64 float4
+
+    f32x4 ring[R4_RING];
+    auto load_b = [&](int chunk, int pos, int slot) {
+        ring[slot] = bld4(rU, ulane, (unsigned)pos * xi_bytes + (unsigned)(chunk * 4) * (unsigned)N * 16u);
+    };
+
+    // prologue: patch(0) -> LDS -> V(0); patch(1) -> LDS; patch(2) requested
+    const int last = nchunks - 1;
+    const int c1 = last >= 1 ? 1 : 0, c2 = last >= 2 ? 2 : last;
+    load_patch(0);
+    f32x4 praw0[R4_PJ];
+#pragma unroll
+    for (int j = 0; j < R4_PJ; ++j) praw0[j] = praw[j];
+    load_patch(c1);
+#pragma unroll
+    for (int g = 0; g < R4_RING; ++g) load_b(0, g, g);
+    {
+        f32x4 keep[R4_PJ];
+#pragma unroll
+        for (int j = 0; j < R4_PJ; ++j) { keep[j] = praw[j]; praw[j] = praw0[j]; }
+        store_patch(0, 0);
+#pragma unroll
+        for (int j = 0; j < R4_PJ; ++j) praw[j] = keep[j];
+    }
+    __syncthreads();
+    transform_all(0, 0);
+    store_patch(1, c1);
+    load_patch(c2);
+    __syncthreads();
+
+    // One iteration per 16-channel chunk (clamped tail indices instead of `if (more)`, as wino43_kernel):
+    //   T  V(c+1) <- patch(c+1)    positions 0..8    S  patch(c+2) -> LDS    positions 9..26    L  request patch(c+3)
+    //   positions 27..35           barrier
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        if (DBG != 2) transform_all((chunk + 1) & 1, (chunk + 1) & 1);
+        const f32x4 *V = ldsV + (chunk & 1) * R4_V + vread;
+        const int nxt = chunk < last ? chunk + 1 : last;
+        const int s2 = chunk + 2 <= last ? chunk + 2 : last, l3 = chunk + 3 <= last ? chunk + 3 : last;
+        f32x4 av[3];                                                // A fragments: two positions ahead of the MFMAs
+        av[0] = V[0];
+        av[1] = V[64];
+#pragma unroll
+        for (int p = 0; p < 36; ++p) {
+            if (p == 9 && DBG != 3) store_patch(chunk & 1, s2);     // patch(chunk+2) replaces patch(chunk): its readers passed the last barrier
+            if (p == 27 && DBG != 3) load_patch(l3);
+            const f32x4 a_cur = av[p % 3];
+            if (p + 2 < 36) av[(p + 2) % 3] = V[(p + 2) * 64];
+            const f32x4 bv = ring[p % R4_RING];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[kk], bv[kk], acc[p], 0, 0, 0);
+            if (DBG != 4) {
+                if (p + R4_RING < 36) load_b(chunk, p + R4_RING, p % R4_RING);
+                else                  load_b(nxt, p + R4_RING - 36, p % R4_RING);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                            // publishes V(chunk+1) and patch(chunk+2); retires V(chunk)
+    }
+
+    if (DBG == 1) {
+        float sum = 0.f;
+#pragma unroll
+        for (int p = 0; p < 36; ++p) sum += (acc[p][0] + acc[p][1]) + (acc[p][2] + acc[p][3]);
+        if (sum == 12345.678f) a.out[0] = sum;
+        return;
+    }
+    // ---- epilogue, in registers: lane = (channel nw, tiles kq*4 .. kq*4+3); tile r of the lane sits in component r of every acc.
+    // (The transposed form -- D = channels x tiles, one 16-byte store per pixel and lane -- measured slower: 292 vs 282 us on the
+    // 256x256 128->128 layer; the stores of a round are HBM-burst-bound, not issue-bound.)
+    const float *TE = a.temb ? a.temb + (int64_t)b * a.temb_ld : nullptr;
+    const __amdgpu_buffer_rsrc_t rO = rsrc(a.out + (int64_t)b * a.o_bs);
+    const __amdgpu_buffer_rsrc_t rR = rsrc(a.res ? a.res + (int64_t)b * a.r_bs : a.out);
+    const bool has_res = a.res != nullptr;
+    const unsigned uW = (unsigned)W, o_ld = (unsigned)a.out_ld, r_ld = (unsigned)a.res_ld;
+    float add = 0.f;
+    if (a.bias) add += a.bias[nw];
+    if (TE) add += TE[nw];
+    // per-lane byte offset of tile (kq, 0)'s first pixel; tile r and pixel (i, j) add the wave-uniform (r*4 + i*W + j) pixels
+    const unsigned pix0 = (unsigned)(y0 + kq * 4) * uW + (unsigned)x0;
+    const unsigned vo = (pix0 * o_ld + (unsigned)nw) * 4u, vr = (pix0 * r_ld + (unsigned)nw) * 4u;
+    auto load_res = [&](int r, float (&rv)[16]) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rv[i] = 0.f;
+        if (has_res) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    rv[i * 4 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rR, (int)vr, (int)((((unsigned)(r * 4) + (unsigned)i * uW + (unsigned)j) * 4u) * r_ld), 0));
+        }
+    };
+    float cs = 0.f, cq = 0.f;
+    float rv[2][16];
+    load_res(0, rv[0]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (r + 1 < 4) load_res(r + 1, rv[(r + 1) & 1]);           // the next tile's residual pixels ride behind this tile's arithmetic
+        // columns first: y[i][v] = sum_u A^T[i][u] m[u][v]
+        float y[4][6];
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+            float mu[6], o[4];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) mu[u] = acc[u * 6 + v][r];
+            at6(mu, o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i][v] = o[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float o4[4];
+            at6(y[i], o4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned so = ((unsigned)(r * 4) + (unsigned)i * uW + (unsigned)j) * 4u;      // wave-uniform pixel offset (x ld below)
+                const float v = a.alpha * o4[j] + add + rv[r & 1][i * 4 + j];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, (int)vo, (int)(so * o_ld), 0);
+                cs += v;
+                cq += v * v;
+            }
+        }
+    }
+    if (a.stats) {
+        // the lane's 64 outputs of channel nw; the four kq lane groups hold the other tiles of the same channel
+        cs += __shfl_xor(cs, 16);
+        cq += __shfl_xor(cq, 16);
+        cs += __shfl_xor(cs, 32);
+        cq += __shfl_xor(cq, 32);
+        if (kq == 0) {
+            float *st = a.stats + (((int64_t)b * gridDim.x + blockIdx.x) * N + nw) * 2;
+            st[0] = cs;
+            st[1] = cq;
+        }
+    }
+}
+
+}  // namespace
+
+namespace anoddpm {
+
+// Called by launch_winograd43 for the 128-channel grid (arguments validated there).
+int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
+{
+    dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / 128), (unsigned)a->B);
+    const bool fast = a->gn_scale && a->act;
+    const int dbg = g_debug[6];
+    if (fast && dbg == 1) hipLaunchKernelGGL((wino43r_kernel<true, 1>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 2) hipLaunchKernelGGL((wino43r_kernel<true, 2>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 3) hipLaunchKernelGGL((wino43r_kernel<true, 3>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 4) hipLaunchKernelGGL((wino43r_kernel<true, 4>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 8) hipLaunchKernelGGL((wino43r_kernel<true, 0, 8>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 9) hipLaunchKernelGGL((wino43r_kernel<true, 0, 4>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast) hipLaunchKernelGGL((wino43r_kernel<true>), grid, dim3(R4_NT), 0, s, *a);
+    else      hipLaunchKernelGGL((wino43r_kernel<false>), grid, dim3(R4_NT), 0, s, *a);
+    return check_launch("winograd43r");
+}
+
+}  // namespace anoddpm

@@ -347,8 +347,18 @@ def test_streaming_pointwise_rejects_fused_operands():
                           Hout=32, ks=1, cfg=4)
 
 
+@pytest.fixture(params=[0, 3], ids=["auto", "channel-sliced"])
+def f43_variant(request):
+    """0: the launcher's choice (the 64-channel position-sliced kernel on these small grids); 3: force the channel-sliced
+    kernel (csrc/winograd43r.hip, what the 128-channel grids of the real layers run) wherever N % 128 == 0."""
+    from anoddpm_amd._lib import lib
+    lib().anoddpm_debug_set(5, request.param)
+    yield request.param
+    lib().anoddpm_debug_set(5, 0)
+
+
 @pytest.mark.parametrize("case", F43_CASES)
-def test_winograd_f43_conv(case):
+def test_winograd_f43_conv(case, f43_variant):
     """cfg = 3: Winograd F(4x4,3x3) (csrc/winograd43.hip) against the direct 3x3 convolution.  fp32 with wider transforms:
     measured ~1e-5 of the tensor magnitude per layer; asserted 1e-4 (north star for whole-model activations: 1e-3)."""
     import hipops
