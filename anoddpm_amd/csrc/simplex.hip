@@ -15,6 +15,7 @@
 // "(d0 - 1 - 3*SQUISH) - 1" (simplex.py:503,506) or "(d0 - 2*SQUISH) - 2" (:737-743); they map
 // to (A,C) = (offset-1, 1) and (0, 2).  Subtracting +0.0 is exact, so one formula serves all.
 #include "common.h"
+#include "simplex_tables.h"
 
 namespace {
 
@@ -29,24 +30,35 @@ __constant__ signed char kGrad3[72] = {
     -11,-4,-4,  -4,-11,-4,  -4,-4,-11,   11,-4,-4,   4,-11,-4,   4,-4,-11,
 };
 
-// LDS tables.  The 24 gradient vectors have components +-4 / +-11: exact in the high dword of a double (low dword 0), so a
-// vertex fetches its whole gradient with ONE 16-byte LDS read instead of three 8-byte ones.
+// LDS tables.  Everything the hash chain touches is stored as BYTE OFFSETS so that an LDS address is one integer add:
+//   PG[m] = {8 * perm[m & 255], 48 * (perm-gradient index of m & 255)}   m < 512: a hash value plus a masked lattice coordinate
+//           never wraps.  One 8-byte entry serves both tables: ds_read_b64 is serviced over 64 banks (the 2- and 4-byte reads over
+//           32), which cuts the bank conflicts of these random lookups -- the kernel is LDS-conflict bound as much as VALU bound.
+//   grad[g] = {gx, gy, gz} as doubles (components +-4 / +-11 of GRADIENTS3, simplex.py:116-127) in 48-byte rows: only rows g and
+//           g + 16 share banks (32-byte rows: g, g + 8, g + 16)
+// plus the two generated tables of simplex_tables.h: which two extra vertices a region decision selects, and each vertex's
+// displacement recipe / hash offsets.
 struct Tables {
-    unsigned char perm[256];
-    unsigned char g24[256];          // gradient index perm % 24 (the reference's pgi3 / 3)
-    int4 gradhi[24];                 // {hi(gx), hi(gy), hi(gz), 0}
+    uint2 PG[512];
+    double grad[24][6];
+    unsigned short lut[384];
+    double vtx[128][10];             // {ax, ay, az, sq, cx, cy, cz, (i8 | j8 << 32), (k8), -}
 };
 
 __device__ __forceinline__ void load_tables(Tables &T, const int16_t *src)
 {
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
-        T.perm[i] = (unsigned char)src[i];
-        T.g24[i] = (unsigned char)(src[256 + i] / 3);
-    }
-    if (threadIdx.x < 24) {
-        const int g = threadIdx.x;
-        T.gradhi[g] = make_int4(__double2hiint((double)kGrad3[3 * g]), __double2hiint((double)kGrad3[3 * g + 1]),
-                                __double2hiint((double)kGrad3[3 * g + 2]), 0);
+    for (int i = threadIdx.x; i < 512; i += blockDim.x)
+        T.PG[i] = make_uint2(8u * (unsigned)(src[i & 255] & 0xFF), 48u * (unsigned)(src[256 + (i & 255)] / 3));
+    for (int i = threadIdx.x; i < 72; i += blockDim.x) T.grad[i / 3][i % 3] = (double)kGrad3[i];
+    for (int i = threadIdx.x; i < 384; i += blockDim.x) T.lut[i] = kExtraLut[i];
+    for (int i = threadIdx.x; i < 128 * 9; i += blockDim.x) {
+        const int e = i / 9, w = i - e * 9;                          // 72-byte source entries -> 80-byte LDS rows
+        unsigned long long v = reinterpret_cast<const unsigned long long *>(&kVertex[e])[w];
+        if (w >= 7) {                                                // {2i, 2j} / {2k, 0} -> the 8-byte entry offsets {8i, 8j} / {8k, 0}
+            const int lo = (int)(v & 0xFFFFFFFFull) * 4, hi = (int)(v >> 32) * 4;
+            v = (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32);
+        }
+        reinterpret_cast<unsigned long long *>(T.vtx[e])[w] = v;
     }
     __syncthreads();
 }
@@ -63,41 +75,29 @@ __device__ __forceinline__ double div_norm3(double v)
     return fma(fma(-NORM3, q, v), r, q);
 }
 
-struct Vtx {
-    int i, j, k;        // lattice offset
-    int lx, ly, lz;     // 0 std, 1 "late -1", 2 "late -2" per component
-};
-
-__device__ __forceinline__ Vtx mk(int i, int j, int k) { return Vtx{i, j, k, 0, 0, 0}; }
-
-__device__ __forceinline__ double component(double d0, int off, double sq, int late)
+__device__ __forceinline__ unsigned lds_u16(const void *base, unsigned byte_off)
 {
-    const double A = (late == 2) ? 0.0 : (double)(off - (late == 1 ? 1 : 0));
-    const double C = (late == 2) ? 2.0 : (late == 1 ? 1.0 : 0.0);
-    return ((d0 - A) - sq) - C;
+    return *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ uint2 lds_pg(const Tables &T, unsigned byte_off)
+{
+    return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(T.PG) + byte_off);
 }
 
-__device__ __forceinline__ double vertex_term(const Tables &T, int xsb, int ysb, int zsb,
-                                              double dx0, double dy0, double dz0, Vtx v, bool on)
+// attn^4 * (g . d) of one vertex whose displacement and gradient byte offset are known (simplex.py:202-208 + the kernel term)
+__device__ __forceinline__ double kernel_term(const Tables &T, double two, double dx, double dy, double dz, unsigned goff)
 {
-    const int n = v.i + v.j + v.k;
-    const double sq = (double)n * SQUISH3;          // n*SQUISH formed as one rounded constant
-    const double dx = component(dx0, v.i, sq, v.lx);
-    const double dy = component(dy0, v.j, sq, v.ly);
-    const double dz = component(dz0, v.k, sq, v.lz);
-    double attn = 2 - dx * dx - dy * dy - dz * dz;
-    // branch-free: the hash chain and the gradient read always run (indices are masked, so always valid); a vertex outside
-    // the kernel radius or an unused slot contributes +0.0 exactly as the reference's skipped term does
-    const int h0 = T.perm[(xsb + v.i) & 0xFF];
-    const int h1 = T.perm[(h0 + ysb + v.j) & 0xFF];
-    const int g = T.g24[(h1 + zsb + v.k) & 0xFF];
-    const int4 gh = T.gradhi[g];
-    const double gx = __hiloint2double(gh.x, 0), gy = __hiloint2double(gh.y, 0), gz = __hiloint2double(gh.z, 0);
-    attn = on ? fmax(attn, 0.0) : 0.0;              // out of radius / unused: +0.0, a signed-zero term leaves the sum unchanged
+    const double *g = reinterpret_cast<const double *>(reinterpret_cast<const char *>(T.grad) + goff);
+    const double gx = g[0], gy = g[1], gz = g[2];
+    double attn = two - dx * dx - dy * dy - dz * dz;                 // `two` = 2.0, or -inf for a corner outside the region's list
+    attn = fmax(attn, 0.0);                                         // out of radius / unlisted: +0.0, the term is a signed zero
     attn *= attn;
     return attn * attn * (gx * dx + gy * dy + gz * dz);
 }
 
+// ABL (timing ablations only, wrong results; ANODDPM_DEBUG7): 1 no extra vertices, 2 no region logic, 3 four corners instead of eight
+// SAFE: the caller guarantees |floor(coordinate)| < 2^31 (the octave kernels check their largest coordinate once per thread)
+template <int ABL = 0, bool SAFE = false>
 __device__ __forceinline__ double noise3(const Tables &T, double x, double y, double z)
 {
     const double stretch = (x + y + z) * STRETCH3;
@@ -106,7 +106,7 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
     // lattice base: only (xsb + i) & 0xFF reaches the hash, and (double)(xsb + ysb + zsb) == fx + fy + fz exactly while the
     // floors stay below 2^50; beyond 2^31 (never in practice) the low bits come from the 64-bit conversion
     int xsb, ysb, zsb;
-    if (fabs(fx) < 2147483000.0 && fabs(fy) < 2147483000.0 && fabs(fz) < 2147483000.0) {
+    if (SAFE || (fabs(fx) < 2147483000.0 && fabs(fy) < 2147483000.0 && fabs(fz) < 2147483000.0)) {
         xsb = (int)fx; ysb = (int)fy; zsb = (int)fz;
     } else {
         xsb = (int)((long long)fx & 0xFF); ysb = (int)((long long)fy & 0xFF); zsb = (int)((long long)fz & 0xFF);
@@ -117,120 +117,128 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
     const double in_sum = xins + yins + zins;
     const double dx0 = x - xb, dy0 = y - yb, dz0 = z - zb;
 
-    Vtx e0 = mk(0, 0, 0), e1 = mk(0, 0, 0);
-    int body;       // bit c set: cube corner c (bit0 = +x, bit1 = +y, bit2 = +z) is on this region's vertex list
-
-    if (in_sum <= 1) {                       // tetrahedron at (0,0,0): simplex.py:354-468
-        int ap = 1, bp = 2;
-        double as = xins, bs = yins;
-        if (as >= bs && zins > bs) { bs = zins; bp = 4; }
-        else if (as < bs && zins > as) { as = zins; ap = 4; }
-        const double wins = 1 - in_sum;
-        if (wins > as || wins > bs) {
-            const int c = (bs > as) ? bp : ap;
-            if (c & 1) { e0.i = 1; e1.i = 1; } else { e0.i = -1; e1.i = 0; }
-            if (c & 2) { e0.j = 1; e1.j = 1; } else if (c & 1) { e0.j = -1; } else { e1.j = -1; }
-            if (c & 4) { e0.k = 1; e1.k = 1; } else { e1.k = -1; }
-        } else {
-            const int c = ap | bp;
-            e0 = mk(c & 1, (c >> 1) & 1, (c >> 2) & 1);
-            e1 = mk((c & 1) ? 1 : -1, (c & 2) ? 1 : -1, (c & 4) ? 1 : -1);
-        }
-        body = 0x17;                         // corners 0, 1, 2, 4
-    } else if (in_sum >= 2) {                // tetrahedron at (1,1,1): simplex.py:469-586
-        int ap = 6, bp = 5;
-        double as = xins, bs = yins;
-        if (as <= bs && zins < bs) { bs = zins; bp = 3; }
-        else if (as > bs && zins < as) { as = zins; ap = 3; }
-        const double wins = 3 - in_sum;
-        if (wins < as || wins < bs) {
-            const int c = (bs < as) ? bp : ap;
-            if (c & 1) { e0.i = 2; e1.i = 1; }
-            if (c & 2) {
-                e0.j = 1; e1.j = 1;
-                if (c & 1) { e1.j = 2; e1.ly = 1; } else { e0.j = 2; e0.ly = 1; }
-            }
-            if (c & 4) { e0.k = 1; e1.k = 2; }
-        } else {
-            const int c = ap & bp;
-            e0 = mk(c & 1, (c >> 1) & 1, (c >> 2) & 1);
-            e1 = mk(2 * (c & 1), 2 * ((c >> 1) & 1), 2 * ((c >> 2) & 1));
-        }
-        body = 0xE8;                         // corners 3, 5, 6, 7
-    } else {                                 // octahedron: simplex.py:587-798
-        double as, bs;
-        int ap, bp;
-        bool af, bf;
+    // ---- region decisions of simplex.py:354-798, branch-free: all three candidates are formed and the one that applies indexes
+    // kExtraLut (the reference's if / elif chains become selects; an `elif` arm is gated by the negation of the arm before it)
+    const bool regA = in_sum <= 1, regB = in_sum >= 2;
+    unsigned idx;
+    if (ABL == 2) {
+        idx = 128 + (3 | 5 << 3 | 1 << 6 | 1 << 7);
+    } else {
+        // Only comparisons and integer selects: a selected score (`a_score = z if ... else x`) is never materialised -- the
+        // comparison it feeds is taken from the comparisons of its candidates, so the branch structure turns into wave-mask
+        // logic on the scalar unit.  (An `elif` arm is gated by the negation of the arm before it.)
+        const bool x_ge_y = xins >= yins, x_lt_y = xins < yins, z_gt_y = zins > yins, z_gt_x = zins > xins;
+        // tetrahedron at (0,0,0): a = x|z, b = y|z (never both z)
+        const bool a1 = x_ge_y && z_gt_y;                            // b := z
+        const bool a2 = !a1 && (x_lt_y && z_gt_x);                   // a := z
+        const double winsA = 1 - in_sum;
+        const bool wAx = winsA > xins, wAy = winsA > yins, wAz = winsA > zins;
+        const bool sA = (a2 ? wAz : wAx) || (a1 ? wAz : wAy);
+        const bool b_gt_a = a1 ? z_gt_x : (a2 ? (yins > zins) : (yins > xins));        // b_score > a_score
+        const unsigned apA = a2 ? 4u : 1u, bpA = a1 ? 4u : 2u;
+        const unsigned cA = sA ? (b_gt_a ? bpA : apA) : (apA | bpA);
+        const unsigned idxA = (sA ? 8u : 0u) | cA;
+        // tetrahedron at (1,1,1)
+        const bool x_le_y = xins <= yins, x_gt_y = xins > yins, z_lt_y = zins < yins, z_lt_x = zins < xins;
+        const bool b1 = x_le_y && z_lt_y;
+        const bool b2 = !b1 && (x_gt_y && z_lt_x);
+        const double winsB = 3 - in_sum;
+        const bool wBx = winsB < xins, wBy = winsB < yins, wBz = winsB < zins;
+        const bool sB = (b2 ? wBz : wBx) || (b1 ? wBz : wBy);
+        const bool b_lt_a = b1 ? z_lt_x : (b2 ? (yins < zins) : (yins < xins));        // b_score < a_score
+        const unsigned apB = b2 ? 3u : 6u, bpB = b1 ? 3u : 5u;
+        const unsigned cB = sB ? (b_lt_a ? bpB : apB) : (apB & bpB);
+        const unsigned idxB = 16u + ((sB ? 8u : 0u) | cB);
+        // octahedron: score = p - 1 or 1 - p, whichever is positive -- the two differences are exact negatives of each other
         const double p1 = xins + yins, p2 = xins + zins, p3 = yins + zins;
-        if (p1 > 1) { as = p1 - 1; ap = 3; af = true; } else { as = 1 - p1; ap = 4; af = false; }
-        if (p2 > 1) { bs = p2 - 1; bp = 5; bf = true; } else { bs = 1 - p2; bp = 2; bf = false; }
-        if (p3 > 1) {
-            const double sc = p3 - 1;
-            if (as <= bs && as < sc) { ap = 6; af = true; }
-            else if (as > bs && bs < sc) { bp = 6; bf = true; }
-        } else {
-            const double sc = 1 - p3;
-            if (as <= bs && as < sc) { ap = 1; af = false; }
-            else if (as > bs && bs < sc) { bp = 1; bf = false; }
-        }
-        if (af == bf) {
-            if (af) {
-                const int c = ap & bp;
-                e0 = mk(1, 1, 1);
-                e1 = (c & 1) ? mk(2, 0, 0) : (c & 2) ? mk(0, 2, 0) : mk(0, 0, 2);
-            } else {
-                const int c = ap | bp;
-                e1 = !(c & 1) ? mk(-1, 1, 1) : !(c & 2) ? mk(1, -1, 1) : mk(1, 1, -1);
-            }
-        } else {
-            const int c1 = af ? ap : bp;
-            const int c2 = af ? bp : ap;
-            e0 = !(c1 & 1) ? mk(-1, 1, 1) : !(c1 & 2) ? mk(1, -1, 1) : mk(1, 1, -1);
-            if (c2 & 1)      { e1 = mk(2, 0, 0); e1.lx = 2; }
-            else if (c2 & 2) { e1 = mk(0, 2, 0); e1.ly = 2; }
-            else             { e1 = mk(0, 0, 2); e1.lz = 2; }
-        }
-        body = 0x7E;                         // corners 1, 2, 4, 3, 5, 6
+        const bool f1 = p1 > 1, f2 = p2 > 1, f3 = p3 > 1;
+        const double asC = fabs(p1 - 1), bsC = fabs(p2 - 1), scC = fabs(p3 - 1);
+        const bool t1 = asC <= bsC && asC < scC;
+        const bool t2 = !t1 && (asC > bsC && bsC < scC);
+        const unsigned p3c = f3 ? 6u : 1u;
+        const unsigned apC = t1 ? p3c : (f1 ? 3u : 4u), bpC = t2 ? p3c : (f2 ? 5u : 2u);
+        const bool afC = t1 ? f3 : f1, bfC = t2 ? f3 : f2;
+        const unsigned idxC = 128u + (apC | bpC << 3 | (afC ? 64u : 0u) | (bfC ? 128u : 0u));
+        idx = regA ? idxA : (regB ? idxB : idxC);
     }
+    const unsigned pair = lds_u16(T.lut, idx * 2);
 
     // ---- the unit cube's corners.  Every region's vertex list is a subset of the eight corners taken in the order
     // 0,1,2,4,3,5,6,7 (tetra0: 0 1 2 4; octahedron: 1 2 4 3 5 6; tetra1: 3 5 6 7), so all eight are evaluated with COMPILE-TIME
     // offsets -- displacement (d0 - i) - n*SQUISH, hash chain shared per (i) and (i,j) -- and a corner outside the region's
-    // list contributes +0.0, exactly like an out-of-radius vertex.  This replaces per-slot decoding of runtime vertex codes.
+    // list starts its attenuation from -inf instead of 2, i.e. contributes +0.0 exactly like an out-of-radius vertex.
+    const int NINF = (int)0xFFF00000, TWO = 0x40000000;
+    const double two0 = __hiloint2double(regA ? TWO : NINF, 0);                  // corner 0
+    const double two1 = __hiloint2double(regB ? NINF : TWO, 0);                  // corners 1, 2, 4
+    const double two2 = __hiloint2double(regA ? NINF : TWO, 0);                  // corners 3, 5, 6
+    const double two3 = __hiloint2double(regB ? TWO : NINF, 0);                  // corner 7
     const double X[2] = {dx0, dx0 - 1.0}, Y[2] = {dy0, dy0 - 1.0}, Z[2] = {dz0, dz0 - 1.0};
     const double SQ[4] = {0.0, 1.0 * SQUISH3, 2.0 * SQUISH3, 3.0 * SQUISH3};
-    int h0[2], h1[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) h0[i] = T.perm[(xsb + i) & 0xFF];
+    const unsigned xb2 = ((unsigned)xsb & 0xFFu) * 8u, yb2 = ((unsigned)ysb & 0xFFu) * 8u, zb2 = ((unsigned)zsb & 0xFFu) * 8u;
+    const unsigned yo[2] = {yb2, (yb2 + 8u) & 0x7F8u}, zo[2] = {zb2, (zb2 + 8u) & 0x7F8u};
+    unsigned h0[2], h1[2][2];
+    h0[0] = lds_pg(T, xb2).x;
+    h0[1] = lds_pg(T, (xb2 + 8u) & 0x7F8u).x;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) h1[i][j] = T.perm[(h0[i] + ysb + j) & 0xFF];
+        for (int j = 0; j < 2; ++j) h1[i][j] = lds_pg(T, h0[i] + yo[j]).x;
     double value = 0.0;
     constexpr int ORDER[8] = {0, 1, 2, 4, 3, 5, 6, 7};
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < (ABL == 3 ? 4 : 8); ++s) {
         const int code = ORDER[s];
-        const bool listed = (body >> code) & 1;
         const int i = code & 1, j = (code >> 1) & 1, k = (code >> 2) & 1, n = i + j + k;
         const double dx = n ? X[i] - SQ[n] : X[i];
         const double dy = n ? Y[j] - SQ[n] : Y[j];
         const double dz = n ? Z[k] - SQ[n] : Z[k];
-        double attn = 2 - dx * dx - dy * dy - dz * dz;
-        const int g = T.g24[(h1[i][j] + zsb + k) & 0xFF];
-        const int4 gh = T.gradhi[g];
-        const double gx = __hiloint2double(gh.x, 0), gy = __hiloint2double(gh.y, 0), gz = __hiloint2double(gh.z, 0);
-        // attn <= 0 or an unlisted corner -> attn := +0.0, and 0^4 * (g . d) is a signed zero that leaves the sum unchanged
-        attn = listed ? fmax(attn, 0.0) : 0.0;
-        attn *= attn;
-        value += attn * attn * (gx * dx + gy * dy + gz * dz);
+        const double two = code == 0 ? two0 : (code == 7 ? two3 : (n == 1 ? two1 : two2));
+        value += kernel_term(T, two, dx, dy, dz, lds_pg(T, h1[i][j] + zo[k]).y);
     }
-    value += vertex_term(T, xsb, ysb, zsb, dx0, dy0, dz0, e0, true);
-    value += vertex_term(T, xsb, ysb, zsb, dx0, dy0, dz0, e1, true);
+    // ---- the two extra vertices: displacement recipe and hash offsets from the vertex table (simplex_tables.h)
+    if (ABL != 1) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const unsigned id = e == 0 ? (pair & 0x7Fu) : (pair >> 8);
+            const char *row = reinterpret_cast<const char *>(T.vtx) + id * 80u;
+            const double2 a01 = *reinterpret_cast<const double2 *>(row), a23 = *reinterpret_cast<const double2 *>(row + 16);
+            const double2 c01 = *reinterpret_cast<const double2 *>(row + 32);
+            const double cz = *reinterpret_cast<const double *>(row + 48);
+            const int2 ij = *reinterpret_cast<const int2 *>(row + 56);
+            const int k2 = *reinterpret_cast<const int *>(row + 64);
+            const double dx = ((dx0 - a01.x) - a23.y) - c01.x;
+            const double dy = ((dy0 - a01.y) - a23.y) - c01.y;
+            const double dz = ((dz0 - a23.x) - a23.y) - cz;
+            const unsigned e0h = lds_pg(T, (xb2 + (unsigned)ij.x) & 0x7F8u).x;
+            const unsigned e1h = lds_pg(T, e0h + ((yb2 + (unsigned)ij.y) & 0x7F8u)).x;
+            const unsigned goff = lds_pg(T, e1h + ((zb2 + (unsigned)k2) & 0x7F8u)).y;
+            value += kernel_term(T, 2.0, dx, dy, dz, goff);
+        }
+    }
     return div_norm3(value);
 }
 
-template <typename OutT>
+// sum_o persistence^o * noise3(x / f_o, y / f_o, z / f_o), f_o = f0 / 2^o, octave 0 first (simplex.py:89-92, :50-52)
+template <int ABL, bool SAFE>
+__device__ __forceinline__ double octave_sum(const Tables &T, double xd, double yd, double zd, double f0, bool pow2, int octaves,
+                                             double persistence)
+{
+    double acc = 0.0, amp = 1.0, f = f0;
+    double rf = pow2 ? 1.0 / f0 : 0.0;
+    for (int o = 0; o < octaves; ++o) {
+        double cx, cy, cz;
+        if (pow2) { cx = xd * rf; cy = yd * rf; cz = zd * rf; }
+        else      { cx = xd / f; cy = yd / f; cz = zd / f; }
+        const double n = noise3<ABL, SAFE>(T, cx, cy, cz);
+        acc = acc + amp * n;            // noise += amplitude * field, octave 0 first (simplex.py:90)
+        f = f / 2;
+        rf = rf * 2.0;
+        amp = amp * persistence;
+    }
+    return acc;
+}
+
+template <typename OutT, int ABL = 0>
 __global__ __launch_bounds__(256) void simplex3_octaves_kernel(anoddpm_simplex_args a)
 {
     __shared__ Tables T;
@@ -244,20 +252,20 @@ __global__ __launch_bounds__(256) void simplex3_octaves_kernel(anoddpm_simplex_a
     if (x >= a.W || y >= a.H) return;
     const long long zi = a.zvals ? a.zvals[s] : a.z0 + s;
 
-    double acc = 0.0, amp = 1.0, f = a.frequency;
     // x / f: when f is a power of two (every frequency the reference uses: 64, 2^i, and their halvings) the quotient is an
-    // exact scaling and equals x * (1/f) bit for bit; any other f takes the IEEE division
+    // exact scaling and equals x * (1/f) bit for bit -- and 1/f doubles exactly from octave to octave; any other f takes the
+    // IEEE division
+    const double f0 = a.frequency;
     int fe;
-    const bool pow2 = (frexp(f, &fe) == 0.5) && fe > -900 && fe - a.octaves > -900 && fe < 900;
-    for (int o = 0; o < a.octaves; ++o) {
-        double cx, cy, cz;
-        if (pow2) { const double rf = 1.0 / f; cx = (double)x * rf; cy = (double)y * rf; cz = (double)zi * rf; }
-        else      { cx = (double)x / f; cy = (double)y / f; cz = (double)zi / f; }
-        const double n = noise3(T, cx, cy, cz);
-        acc = acc + amp * n;            // noise += amplitude * field, octave 0 first (simplex.py:90)
-        f = f / 2;
-        amp = amp * a.persistence;
-    }
+    const bool pow2 = (frexp(f0, &fe) == 0.5) && fe > -900 && fe - a.octaves > -900 && fe < 900;
+    const double xd = (double)x, yd = (double)y, zd = (double)zi;
+    // largest |coordinate| of any octave (the last one: f0 / 2^(octaves-1)), with room for the stretch term: below 2^31 the lattice
+    // base converts with a plain 32-bit conversion
+    const double fmin = ldexp(f0, -(a.octaves > 0 ? a.octaves - 1 : 0));
+    const bool safe = fmin > 0.0 && fmax(fmax(fabs(xd), fabs(yd)), fabs(zd)) * 2.0 < 2147483000.0 * fmin;
+    double acc = 0.0;
+    if (safe) acc = octave_sum<ABL, true>(T, xd, yd, zd, f0, pow2, a.octaves, a.persistence);
+    else      acc = octave_sum<ABL, false>(T, xd, yd, zd, f0, pow2, a.octaves, a.persistence);
     OutT *out = reinterpret_cast<OutT *>(a.out) + (long long)s * a.out_slice_stride + (long long)y * a.W + x;
     *out = (OutT)acc;
 }
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256) void simplex3_grid_kernel(double *out, const d
         const int ix = (int)(i % nx);
         const int iy = (int)((i / nx) % ny);
         const int iz = (int)(i / ((long long)nx * ny));
-        out[i] = noise3(T, X[ix], Y[iy], Z[iz]);
+        out[i] = noise3<0>(T, X[ix], Y[iy], Z[iz]);
     }
 }
 
@@ -416,7 +424,11 @@ static int launch_simplex(const anoddpm_simplex_args *a, void *stream)
     if (a->nslices == 0 || a->H == 0 || a->W == 0) return ANODDPM_OK;
     dim3 grid((a->W + 63) / 64, (a->H + 3) / 4, a->nslices);
     ANODDPM_REQUIRE(grid.y <= 65535, "simplex3_octaves: H too large");
-    hipLaunchKernelGGL(simplex3_octaves_kernel<OutT>, grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
+    const int abl = anoddpm::g_debug[7];
+    if (abl == 1) hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 1>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
+    else if (abl == 2) hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 2>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
+    else if (abl == 3) hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 3>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
+    else hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 0>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
     return anoddpm::check_launch("simplex3_octaves");
 }
 
