@@ -167,11 +167,14 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
     // 0,1,2,4,3,5,6,7 (tetra0: 0 1 2 4; octahedron: 1 2 4 3 5 6; tetra1: 3 5 6 7), so all eight are evaluated with COMPILE-TIME
     // offsets -- displacement (d0 - i) - n*SQUISH, hash chain shared per (i) and (i,j) -- and a corner outside the region's
     // list starts its attenuation from -inf instead of 2, i.e. contributes +0.0 exactly like an out-of-radius vertex.
+    // Corner 0 is on the list of tetra0 only and corner 7 on that of tetra1 only: they share ONE slot (the lane's region picks
+    // the corner; in the octahedron the slot starts from -inf and is a signed zero).  The slot's term is evaluated once and ADDED
+    // where its region's vertex order has it: first for tetra0, last (of the cube terms) otherwise.  `value` starts at +0.0 and a
+    // sum of terms can never become -0.0 from there, so the zero terms the other positions used to add are exact no-ops.
     const int NINF = (int)0xFFF00000, TWO = 0x40000000;
-    const double two0 = __hiloint2double(regA ? TWO : NINF, 0);                  // corner 0
     const double two1 = __hiloint2double(regB ? NINF : TWO, 0);                  // corners 1, 2, 4
     const double two2 = __hiloint2double(regA ? NINF : TWO, 0);                  // corners 3, 5, 6
-    const double two3 = __hiloint2double(regB ? TWO : NINF, 0);                  // corner 7
+    const double two07 = __hiloint2double((regA || regB) ? TWO : NINF, 0);       // the shared slot
     const double X[2] = {dx0, dx0 - 1.0}, Y[2] = {dy0, dy0 - 1.0}, Z[2] = {dz0, dz0 - 1.0};
     const double SQ[4] = {0.0, 1.0 * SQUISH3, 2.0 * SQUISH3, 3.0 * SQUISH3};
     const unsigned xb2 = ((unsigned)xsb & 0xFFu) * 8u, yb2 = ((unsigned)ysb & 0xFFu) * 8u, zb2 = ((unsigned)zsb & 0xFFu) * 8u;
@@ -183,18 +186,19 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) h1[i][j] = lds_pg(T, h0[i] + yo[j]).x;
-    double value = 0.0;
-    constexpr int ORDER[8] = {0, 1, 2, 4, 3, 5, 6, 7};
+    // shared slot: corner 0 (region A) or corner 7 (otherwise)
+    const double sx = regA ? X[0] : X[1] - SQ[3], sy = regA ? Y[0] : Y[1] - SQ[3], sz = regA ? Z[0] : Z[1] - SQ[3];
+    const double slot = kernel_term(T, two07, sx, sy, sz, lds_pg(T, regA ? h1[0][0] + zo[0] : h1[1][1] + zo[1]).y);
+    double value = regA ? 0.0 + slot : 0.0;                         // tetra0: corner 0 is the first term (0.0 + t: a -0.0 term gives +0.0)
+    constexpr int ORDER[6] = {1, 2, 4, 3, 5, 6};
 #pragma unroll
-    for (int s = 0; s < (ABL == 3 ? 4 : 8); ++s) {
+    for (int s = 0; s < (ABL == 3 ? 3 : 6); ++s) {
         const int code = ORDER[s];
         const int i = code & 1, j = (code >> 1) & 1, k = (code >> 2) & 1, n = i + j + k;
-        const double dx = n ? X[i] - SQ[n] : X[i];
-        const double dy = n ? Y[j] - SQ[n] : Y[j];
-        const double dz = n ? Z[k] - SQ[n] : Z[k];
-        const double two = code == 0 ? two0 : (code == 7 ? two3 : (n == 1 ? two1 : two2));
-        value += kernel_term(T, two, dx, dy, dz, lds_pg(T, h1[i][j] + zo[k]).y);
+        const double dx = X[i] - SQ[n], dy = Y[j] - SQ[n], dz = Z[k] - SQ[n];
+        value += kernel_term(T, n == 1 ? two1 : two2, dx, dy, dz, lds_pg(T, h1[i][j] + zo[k]).y);
     }
+    value += regA ? 0.0 : slot;                                     // tetra1: corner 7 is the last cube term; octahedron: +0.0
     // ---- the two extra vertices: displacement recipe and hash offsets from the vertex table (simplex_tables.h)
     if (ABL != 1) {
 #pragma unroll
