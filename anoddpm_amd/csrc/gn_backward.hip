@@ -113,57 +113,74 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(anoddpm_gn_bwd_args 
     }
 }
 
-// pass 2: grid (groups), 256 threads.  Folds the slabs (thread = (channel, slab lane), fixed order); per image the
-// group means, per channel dgamma / dbeta.
+// pass 2: grid (groups), 256 threads.  Folds the slabs per image (thread = (image, channel, slab lane), fixed order); per
+// image the group means, per channel dgamma / dbeta (images summed in index order).  Up to 256 / cpg images are folded side
+// by side -- the kernel is a latency chain over tiny data, so the images of a batch must not be walked one after the other.
 // coef[b][c] = { rstd*gamma, rstd*mean_g(gamma*dy), rstd*mean_g(gamma*dy*xhat), unused }
 __global__ __launch_bounds__(256) void gn_bwd_fold_kernel(anoddpm_gn_bwd_args a)
 {
     __shared__ double red[256][2];
+    __shared__ double chan[256][2];                                  // [image slot * cpg + channel] per-channel sums
+    __shared__ double grp[64][2];                                    // [image slot] group sums of gamma * c
     const int C = a.c0 + a.c1, cpg = C / a.groups;                  // cpg <= 64 (launcher)
     const int g = blockIdx.x, tid = threadIdx.x;
-    const int S = 256 / cpg;                                         // slab lanes
-    const int cl = tid % cpg, sl = tid / cpg;
-    const int c = g * cpg + cl;
+    int nbp = 256 / cpg;                                             // images folded side by side
+    if (nbp > a.B) nbp = a.B;
+    if (nbp > 64) nbp = 64;
+    const int per = 256 / nbp;                                       // threads per image
+    const int S = per / cpg;                                         // slab lanes per (image, channel)
+    const int bl = tid / per, rem = tid - bl * per;
+    const int cl = rem % cpg, sl = rem / cpg;
     const double n = (double)a.Hs * a.Ws * cpg;
     double dgam = 0.0, dbet = 0.0;
-    for (int b = 0; b < a.B; ++b) {
+    for (int b0 = 0; b0 < a.B; b0 += nbp) {
+        const int b = b0 + bl;
+        const bool live = bl < nbp && b < a.B && sl < S;
         double s1 = 0.0, s2 = 0.0;
-        if (sl < S)
+        if (live)
             for (int k = sl; k < a.nslab; k += S) {
-                const double *p = a.partial + (((int64_t)b * a.nslab + k) * C + c) * 2;
+                const double *p = a.partial + (((int64_t)b * a.nslab + k) * C + g * cpg + cl) * 2;
                 s1 += p[0];
                 s2 += p[1];
             }
         red[tid][0] = s1;
         red[tid][1] = s2;
         __syncthreads();
-        double c1 = 0.0, c2 = 0.0;                                   // per-channel sums (threads of the first wave)
-        if (tid < 64 && tid < cpg)
-            for (int k = 0; k < S; ++k) { c1 += red[k * cpg + tid][0]; c2 += red[k * cpg + tid][1]; }
-        double g1 = 0.0, g2 = 0.0;
-        if (tid < 64) {
-            const double gm = tid < cpg ? (double)a.gamma[g * cpg + tid] : 0.0;
-            g1 = c1 * gm;
-            g2 = c2 * gm;
-            for (int o = 32; o > 0; o >>= 1) {
-                g1 += __shfl_xor(g1, o);
-                g2 += __shfl_xor(g2, o);
+        if (live && sl == 0) {                                       // per (image, channel): the slab lanes in order
+            double c1 = 0.0, c2 = 0.0;
+            for (int k = 0; k < S; ++k) { c1 += red[bl * per + k * cpg + cl][0]; c2 += red[bl * per + k * cpg + cl][1]; }
+            chan[bl * cpg + cl][0] = c1;
+            chan[bl * cpg + cl][1] = c2;
+        }
+        __syncthreads();
+        if (live && sl == 0 && cl == 0) {                            // per image: the group sums, channels in order
+            double g1 = 0.0, g2 = 0.0;
+            for (int c = 0; c < cpg; ++c) {
+                const double gm = (double)a.gamma[g * cpg + c];
+                g1 += chan[bl * cpg + c][0] * gm;
+                g2 += chan[bl * cpg + c][1] * gm;
             }
-            if (tid < cpg) {
-                dbet += c1;
-                dgam += c2;
-                const int cc = g * cpg + tid;
-                const double r = (double)a.rstd[(int64_t)b * a.groups + g];
-                float *k = a.coef + ((int64_t)b * C + cc) * 4;
-                k[0] = (float)(r * gm);
-                k[1] = (float)(r * g1 / n);
-                k[2] = (float)(r * g2 / n);
-                k[3] = 0.f;
-            }
+            grp[bl][0] = g1;
+            grp[bl][1] = g2;
+        }
+        __syncthreads();
+        if (live && sl == 0) {
+            const int cc = g * cpg + cl;
+            const double gm = (double)a.gamma[cc];
+            const double r = (double)a.rstd[(int64_t)b * a.groups + g];
+            float *k = a.coef + ((int64_t)b * C + cc) * 4;
+            k[0] = (float)(r * gm);
+            k[1] = (float)(r * grp[bl][0] / n);
+            k[2] = (float)(r * grp[bl][1] / n);
+            k[3] = 0.f;
+        }
+        if (tid < cpg) {                                             // dgamma / dbeta: this chunk's images in index order
+            const int lim = (a.B - b0) < nbp ? (a.B - b0) : nbp;
+            for (int i = 0; i < lim; ++i) { dbet += chan[i * cpg + tid][0]; dgam += chan[i * cpg + tid][1]; }
         }
         __syncthreads();
     }
-    if (tid < 64 && tid < cpg) {
+    if (tid < cpg) {
         a.dgamma[g * cpg + tid] += (float)dgam;
         a.dbeta[g * cpg + tid] += (float)dbet;
     }
