@@ -409,7 +409,7 @@ def run_reverse(c, args, cfg):
                                            ("linear", 5), ("posemb", 6), ("stem", 7), ("layout", 8), ("chan_stats", 9),
                                            ("gn_finalize", 10), ("head", 11), ("attention", 26))},
                     "instrumented_ms_per_step": prof_ms_per_step}
-        prefix = {14: ["wino43_kernel"], 12: ["wino_kernel"], _lib.OP_IGEMM: ["igemm_kernel", "pointwise_stream_kernel"],
+        prefix = {14: ["wino43_kernel", "wino43r_kernel"], 12: ["wino_kernel"], _lib.OP_IGEMM: ["igemm_kernel", "pointwise_stream_kernel"],
                   _lib.OP_ATTENTION: ["attention_kernel"]}[classes[dom][0]]
         tr = committed_traffic(args.config, B, prefix)
         if tr is not None:

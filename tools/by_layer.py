@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Join `bench.py --dump-plan` (the igemm launch list of one step, in order) with a rocprofv3 kernel trace CSV of eager launches
 (ANODDPM_NO_GRAPH=1): python tools/by_layer.py plan.json kernel_trace.csv [steps_to_skip] -> per layer class: shape, config, us, TFLOP/s.
-Launches are matched by order: every contraction launch of the plan is one igemm_kernel / wino_kernel / wino43_kernel / pointwise_stream_kernel dispatch."""
+Launches are matched by order: every contraction launch of the plan is one igemm_kernel / wino_kernel / wino43_kernel / wino43r_kernel / pointwise_stream_kernel dispatch."""
 import csv
 import json
 import sys
@@ -10,7 +10,7 @@ from collections import defaultdict
 plan = json.load(open(sys.argv[1]))
 skip = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 rows = [r for r in csv.DictReader(open(sys.argv[2]))
-        if any(k in r["Kernel_Name"] for k in ("igemm_kernel", "wino_kernel", "wino43_kernel", "pointwise_stream_kernel"))]
+        if any(k in r["Kernel_Name"] for k in ("igemm_kernel", "wino_kernel", "wino43_kernel", "wino43r_kernel", "pointwise_stream_kernel"))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = len(plan)
 steps = len(rows) // n
