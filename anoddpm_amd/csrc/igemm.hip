@@ -660,7 +660,12 @@ extern "C" int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream)
     int H = a->H, W = a->W, log2TW, TH;
     ANODDPM_REQUIRE(H >= 1 && W >= 1, "igemm: bad image size");
     const int64_t P = (int64_t)H * W;
-    if (a->cfg == 3) return anoddpm::launch_winograd43(a, anoddpm::as_stream(stream));
+    if (a->cfg == 3) {
+        const int rc = anoddpm::launch_winograd43(a, anoddpm::as_stream(stream));
+        if (rc != ANODDPM_OK) return rc;
+        if (a->ksplit > 1) launch_splitk_tail(a, (int64_t)a->B, P, anoddpm::as_stream(stream));
+        return anoddpm::check_launch("igemm(winograd43 split-K tail)");
+    }
     if (a->cfg == 4) return anoddpm::launch_pointwise_stream(a, anoddpm::as_stream(stream));
     if (a->cfg == 2) {
         const int rc = anoddpm::launch_winograd(a, anoddpm::as_stream(stream));

@@ -389,7 +389,8 @@ namespace anoddpm {
 // Called by anoddpm_igemm for cfg == 3 (common arguments already validated there).
 int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
 {
-    ANODDPM_REQUIRE(a->ks == 3 && a->b_mode == 0 && a->heads == 1 && a->ksplit == 1, "winograd43: needs an unsplit 3x3 conv with packed weights");
+    ANODDPM_REQUIRE(a->ks == 3 && a->b_mode == 0 && a->heads == 1, "winograd43: needs a 3x3 conv with packed weights");
+    ANODDPM_REQUIRE(a->ksplit == 1 || (a->N % 128 == 0 && a->ws && (int64_t)a->B * a->ksplit <= 65535), "winograd43: split-K needs N %% 128 == 0 and a workspace");
     ANODDPM_REQUIRE(a->a_mode == 0 || a->a_mode == 1, "winograd43: pooled operand loads use the direct kernel");
     ANODDPM_REQUIRE(a->H % 16 == 0 && a->W % 16 == 0 && a->N % 64 == 0, "winograd43: H, W must be multiples of 16 and N of 64");
     const int K = a->c0 + a->c1;
@@ -408,6 +409,11 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
     // 128-channel grid: the channel-sliced kernel (output transform in registers, winograd43r.hip); ANODDPM_DEBUG5=1 keeps this
     // file's position-sliced kernel
     // (ANODDPM_DEBUG5=3: also where this file's 64-channel variant would be chosen -- the op tests reach the kernel on small shapes)
+    if (a->ksplit > 1) {
+        const int K16 = K / F4_KC, cps = (K16 + a->ksplit - 1) / a->ksplit;
+        ANODDPM_REQUIRE((a->ksplit - 1) * cps < K16, "winograd43: ksplit leaves a slice without channels");
+        return launch_winograd43r(a, s);
+    }
     if (dbg == 0 && ((!half && anoddpm::g_debug[5] != 1) || (a->N % 128 == 0 && anoddpm::g_debug[5] == 3))) return launch_winograd43r(a, s);
     if (fast && dbg == 1) hipLaunchKernelGGL((wino43_kernel<true, 1>), grid, dim3(F4_NT), 0, s, *a);
     else if (fast && dbg == 2) hipLaunchKernelGGL((wino43_kernel<true, 2>), grid, dim3(F4_NT), 0, s, *a);

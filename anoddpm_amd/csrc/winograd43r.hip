@@ -72,7 +72,12 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     const int tiles_x = W >> 4;
     const int y0 = (blockIdx.x / tiles_x) * 16, x0 = (blockIdx.x % tiles_x) * 16;
     const int n0 = blockIdx.y * 128;
-    const int b = blockIdx.z;
+    // split-K (grids that would leave CUs idle, e.g. the 64x64 maps of a batch of four): blockIdx.z = image * ksplit + slice; a
+    // slice accumulates a contiguous range of 16-channel chunks and leaves its output-transformed partial tile in the workspace
+    // (the output transform is linear), anoddpm_igemm's split-K tail adds bias / embedding / residual and the statistics
+    const int ksplit = a.ksplit;
+    const int ksi = blockIdx.z % ksplit;
+    const int b = blockIdx.z / ksplit;
     const int a_mode = a.a_mode;
 
     const float *A0 = a.a0 + (int64_t)b * a.a0_bs;
@@ -80,7 +85,9 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     const float *gsc = a.gn_scale ? a.gn_scale + (int64_t)b * a.gn_ld : nullptr;
     const float *gsh = a.gn_shift ? a.gn_shift + (int64_t)b * a.gn_ld : nullptr;
     const bool affine = gsc != nullptr, act = a.act != 0;
-    const int nchunks = K / R4_KC;
+    const int cps = (K / R4_KC + ksplit - 1) / ksplit;
+    const int cb = ksi * cps;                                       // first chunk of this slice
+    const int nchunks = (cb + cps <= K / R4_KC ? cps : K / R4_KC - cb);
 
     // ---- patch staging (pixel = idx >> 2, quad = idx & 3): geometry fixed for the workgroup
     int spix[R4_PJ];
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     const __amdgpu_buffer_rsrc_t rA0 = rsrc(A0), rA1 = rsrc(A1 ? A1 : A0);
     const __amdgpu_buffer_rsrc_t rSc = rsrc(gsc ? gsc : A0), rSh = rsrc(gsh ? gsh : A0);
     auto load_patch = [&](int chunk) {                              // unconditional loads, clamped addresses
-        const int kbase = chunk * R4_KC;
+        const int kbase = (cb + chunk) * R4_KC;
         const bool first = kbase < a.c0;
         const __amdgpu_buffer_rsrc_t r = first ? rA0 : rA1;
         const unsigned ld = (unsigned)(first ? a.a0_ld : a.a1_ld);
@@ -114,8 +121,8 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     auto store_patch = [&](int buf, int chunk) {                    // GroupNorm-apply + SiLU, zero padding AFTER it
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if (FAST || affine) {
-            asc = bld4(rSc, (unsigned)(pq * 16), (unsigned)(chunk * R4_KC) * 4u);
-            ash = bld4(rSh, (unsigned)(pq * 16), (unsigned)(chunk * R4_KC) * 4u);
+            asc = bld4(rSc, (unsigned)(pq * 16), (unsigned)((cb + chunk) * R4_KC) * 4u);
+            ash = bld4(rSh, (unsigned)(pq * 16), (unsigned)((cb + chunk) * R4_KC) * 4u);
         }
 #pragma unroll
         for (int j = 0; j < R4_PJ; ++j) {
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
 
     f32x4 ring[R4_RING];
     auto load_b = [&](int chunk, int pos, int slot) {
-        ring[slot] = bld4(rU, ulane, (unsigned)pos * xi_bytes + (unsigned)(chunk * 4) * (unsigned)N * 16u);
+        ring[slot] = bld4(rU, ulane, (unsigned)pos * xi_bytes + (unsigned)((cb + chunk) * 4) * (unsigned)N * 16u);
     };
 
     // prologue: patch(0) -> LDS -> V(0); patch(1) -> LDS; patch(2) requested
@@ -254,13 +261,16 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     // ---- epilogue, in registers: lane = (channel nw, tiles kq*4 .. kq*4+3); tile r of the lane sits in component r of every acc.
     // (The transposed form -- D = channels x tiles, one 16-byte store per pixel and lane -- measured slower: 292 vs 282 us on the
     // 256x256 128->128 layer; the stores of a round are HBM-burst-bound, not issue-bound.)
-    const float *TE = a.temb ? a.temb + (int64_t)b * a.temb_ld : nullptr;
-    const __amdgpu_buffer_rsrc_t rO = rsrc(a.out + (int64_t)b * a.o_bs);
+    const bool part = ksplit > 1;
+    const float *TE = (a.temb && !part) ? a.temb + (int64_t)b * a.temb_ld : nullptr;
+    const __amdgpu_buffer_rsrc_t rO = part ? rsrc(a.ws + ((int64_t)ksi * a.B + b) * ((int64_t)H * W * N))
+                                           : rsrc(a.out + (int64_t)b * a.o_bs);
     const __amdgpu_buffer_rsrc_t rR = rsrc(a.res ? a.res + (int64_t)b * a.r_bs : a.out);
-    const bool has_res = a.res != nullptr;
-    const unsigned uW = (unsigned)W, o_ld = (unsigned)a.out_ld, r_ld = (unsigned)a.res_ld;
+    const bool has_res = a.res != nullptr && !part;
+    const unsigned uW = (unsigned)W, o_ld = part ? (unsigned)N : (unsigned)a.out_ld, r_ld = (unsigned)a.res_ld;
+    const float alpha = part ? 1.0f : a.alpha;
     float add = 0.f;
-    if (a.bias) add += a.bias[nw];
+    if (a.bias && !part) add += a.bias[nw];
     if (TE) add += TE[nw];
     // per-lane byte offset of tile (kq, 0)'s first pixel; tile r and pixel (i, j) add the wave-uniform (r*4 + i*W + j) pixels
     const unsigned pix0 = (unsigned)(y0 + kq * 4) * uW + (unsigned)x0;
@@ -301,14 +311,14 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned so = ((unsigned)(r * 4) + (unsigned)i * uW + (unsigned)j) * 4u;      // wave-uniform pixel offset (x ld below)
-                const float v = a.alpha * o4[j] + add + rv[r & 1][i * 4 + j];
+                const float v = alpha * o4[j] + add + rv[r & 1][i * 4 + j];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, (int)vo, (int)(so * o_ld), 0);
                 cs += v;
                 cq += v * v;
             }
         }
     }
-    if (a.stats) {
+    if (a.stats && !part) {
         // the lane's 64 outputs of channel nw; the four kq lane groups hold the other tiles of the same channel
         cs += __shfl_xor(cs, 16);
         cq += __shfl_xor(cq, 16);
@@ -329,7 +339,7 @@ namespace anoddpm {
 // Called by launch_winograd43 for the 128-channel grid (arguments validated there).
 int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
 {
-    dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / 128), (unsigned)a->B);
+    dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / 128), (unsigned)(a->B * a->ksplit));
     const bool fast = a->gn_scale && a->act;
     const int dbg = g_debug[6];
     if (fast && dbg == 1) hipLaunchKernelGGL((wino43r_kernel<true, 1>), grid, dim3(R4_NT), 0, s, *a);

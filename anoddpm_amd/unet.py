@@ -457,7 +457,13 @@ def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None
             wino_ksplit = -(-wch // cps)                   # no empty trailing block
     if wino_ok and f43 and N % 64 == 0 and H * W >= int(os.environ.get("ANODDPM_F43_MIN_PIXELS", 64 * 64)) \
             and (H // 16) * (W // 16) * (N // 64) * Z >= 128 and os.environ.get("ANODDPM_NO_F43", "0") != "1":
-        return 3, 1                                            # the kernel picks 64- or 128-channel workgroups itself
+        # the kernel picks 64- or 128-channel workgroups itself.  ANODDPM_F43_SPLITK=1 (measured slower, off): a 128-channel grid
+        # of 100..199 workgroups (the 64x64 maps of a batch of four) split in two K slices on the channel-sliced kernel + the
+        # split-K tail, instead of the 64-channel variant: config-2 step 9.93 vs 9.84 ms
+        wg128 = (H // 16) * (W // 16) * (N // 128) * Z if N % 128 == 0 else 0
+        if 100 <= wg128 < 200 and K // 16 >= 8 and os.environ.get("ANODDPM_F43_SPLITK", "0") == "1":
+            return 3, 2
+        return 3, 1
     if wino_ok:
         return 2, wino_ksplit
     bm = 128 if cfg == 0 else 64

@@ -292,6 +292,8 @@ F43_CASES = [
     (1, (128, 0), 128, 32, 0, False, 0, False, False),     # data-gradient form: no GroupNorm / activation
     (4, (64, 0), 256, 64, 0, True, 1, True, True),         # 64-channel workgroups (128 of the 128-channel ones would not fill the chip)
     (2, (32, 32), 64, 32, 0, True, 1, False, True),        # N = 64: only the 64-channel variant applies; virtual concat
+    (1, (128, 0), 128, 32, 0, True, 1, True, True, 2),     # split-K 2 on the channel-sliced kernel + the split-K tail
+    (2, (96, 64), 256, 32, 1, True, 1, False, True, 3),    # split-K 3: ragged slices (10 chunks), concat, fused nearest x2
 ]
 
 
@@ -363,6 +365,7 @@ def test_winograd_f43_conv(case, f43_variant):
     measured ~1e-5 of the tensor magnitude per layer; asserted 1e-4 (north star for whole-model activations: 1e-3)."""
     import hipops
     B, (c0, c1), N, Hout, a_mode, use_gn, act, use_temb, use_res = case[:9]
+    ksplit = case[9] if len(case) > 9 else 1
     C = c0 + c1
     Hin = Hout if a_mode == 0 else Hout // 2
     x = rnd(B, C, Hin, Hin, seed=91)
@@ -389,13 +392,13 @@ def test_winograd_f43_conv(case, f43_variant):
     st = []
     got = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), Hout=Hout, ks=3, gn=gn, act=act, a_mode=a_mode,
                             temb=temb.to(dev()) if temb is not None else None,
-                            res=hipops.nhwc(res.to(dev())) if res is not None else None, cfg=3, stats_out=st)
+                            res=hipops.nhwc(res.to(dev())) if res is not None else None, cfg=3, stats_out=st, ksplit=ksplit)
     err = relerr(hipops.nchw(got), ref.float())
     assert err < 1e-4, err
-    # fused statistics: one row per workgroup, sums over its 256 pixels
+    # fused statistics: one row per workgroup, sums over its 256 pixels (split-K: the tail's pixel slabs)
     o = hipops.nchw(got).double().cpu()
     s = st[0].double().cpu()
-    assert s.shape[1] == (Hout // 16) ** 2
+    assert s.shape[1] == ((Hout // 16) ** 2 if ksplit == 1 else 3)
     tot = s.sum(dim=1)                                                # [B][N][2]
     assert torch.allclose(tot[..., 0], o.sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
     assert torch.allclose(tot[..., 1], (o * o).sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
