@@ -9,11 +9,11 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 (OP_WGRAD3, OP_WGRAD1, OP_GN_BWD, OP_PACK, OP_SOFTMAX_BWD, OP_TRANSPOSE, OP_LINEAR_BWD, OP_STEM_BWD, OP_HEAD_BWD,
- OP_COLSUM_FOLD, OP_ATTENTION, OP_PACK_BATCH, OP_LINEAR_BWD_BATCH) = range(16, 29)
+ OP_COLSUM_FOLD, OP_ATTENTION, OP_PACK_BATCH, OP_LINEAR_BWD_BATCH, OP_DROPOUT) = range(16, 30)
 OP_MAX = 32
 
 
@@ -156,6 +156,11 @@ class LossArgs(Structure):
                 ("n", c_int64), ("B", c_int32), ("T", c_int32), ("kind", c_int32)]
 
 
+class DropoutArgs(Structure):
+    _fields_ = [("x", c_void_p), ("out", c_void_p), ("gn_scale", c_void_p), ("gn_shift", c_void_p), ("n", c_int64),
+                ("seed", ctypes.c_uint64), ("B", c_int32), ("C", c_int32), ("mode", c_int32), ("p", c_float)]
+
+
 class WgradArgs(Structure):
     _fields_ = [("a0", c_void_p), ("a1", c_void_p), ("gn_scale", c_void_p), ("gn_shift", c_void_p), ("dy", c_void_p),
                 ("dw", c_void_p), ("ws", c_void_p), ("ws_floats", c_int64),
@@ -239,7 +244,7 @@ ANOMALY_BLOCKS = 64
 _STRUCTS = [SimplexArgs, PUpdateArgs, IgemmArgs, GnArgs, SoftmaxArgs, ResampleArgs, LinearArgs,
             PosembArgs, StemArgs, LayoutArgs, Op, AdamwArgs, ChanStatsArgs, GnFinalizeArgs, HeadArgs, AnomalyArgs, VlbArgs, WgradArgs, GnBwdArgs,
             Wgrad1Args, PackArgs, SoftmaxBwdArgs, TransposeArgs, LinearBwdArgs, StemBwdArgs, HeadBwdArgs, ColsumFoldArgs,
-            MriSliceArgs, ResizeArgs, AttentionArgs, PackBatchArgs, LinearBwdBatchArgs, LossArgs]
+            MriSliceArgs, ResizeArgs, AttentionArgs, PackBatchArgs, LinearBwdBatchArgs, LossArgs, DropoutArgs]
 
 # every symbol include/anoddpm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -254,7 +259,7 @@ SYMBOLS = [
     "anoddpm_wgrad_pointwise", "anoddpm_pack_weights", "anoddpm_softmax_rows_backward", "anoddpm_transpose_square",
     "anoddpm_linear_small_backward", "anoddpm_conv_stem_backward", "anoddpm_conv_head_backward", "anoddpm_colsum_fold",
     "anoddpm_volume_normalise", "anoddpm_mri_slice_prepare", "anoddpm_resize_bilinear_pil", "anoddpm_attention", "anoddpm_wgrad43_groups", "anoddpm_pack_batch", "anoddpm_pack_job_blocks", "anoddpm_linear_small_backward_batch",
-    "anoddpm_loss_forward", "anoddpm_loss_backward",
+    "anoddpm_loss_forward", "anoddpm_loss_backward", "anoddpm_dropout",
 ]
 
 _lib = None
@@ -332,6 +337,7 @@ def lib():
     L.anoddpm_sumsq.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p]
     L.anoddpm_anomaly_map.argtypes = [POINTER(AnomalyArgs), c_void_p]
     L.anoddpm_vlb_terms.argtypes = [POINTER(VlbArgs), c_void_p]
+    L.anoddpm_dropout.argtypes = [POINTER(DropoutArgs), c_void_p]
     L.anoddpm_loss_forward.argtypes = [POINTER(LossArgs), c_void_p]
     L.anoddpm_loss_backward.argtypes = [POINTER(LossArgs), c_void_p]
     L.anoddpm_conv3x3_wgrad.argtypes = [POINTER(WgradArgs), c_void_p]

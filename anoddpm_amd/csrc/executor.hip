@@ -55,6 +55,7 @@ static int dispatch(const anoddpm_op &op, void *stream)
         case ANODDPM_OP_COLSUM_FOLD: return anoddpm_colsum_fold(static_cast<const anoddpm_colsum_fold_args *>(op.args), stream);
         case ANODDPM_OP_ATTENTION: return anoddpm_attention(static_cast<const anoddpm_attention_args *>(op.args), stream);
         case ANODDPM_OP_PACK_BATCH: return anoddpm_pack_batch(static_cast<const anoddpm_pack_batch_args *>(op.args), stream);
+        case ANODDPM_OP_DROPOUT: return anoddpm_dropout(static_cast<const anoddpm_dropout_args *>(op.args), stream);
         case ANODDPM_OP_LINEAR_BWD_BATCH: return anoddpm_linear_small_backward_batch(static_cast<const anoddpm_linear_bwd_batch_args *>(op.args), stream);
         default: set_error("run_ops: unknown op code %d", op.code); return ANODDPM_EINVAL;
     }
@@ -71,7 +72,7 @@ extern "C" int anoddpm_debug_set(int32_t key, int32_t value)
     return ANODDPM_OK;
 }
 
-extern "C" int anoddpm_abi_version(void) { return 17; }
+extern "C" int anoddpm_abi_version(void) { return 18; }
 
 extern "C" const char *anoddpm_last_error(void) { return g_err; }
 
@@ -190,6 +191,7 @@ extern "C" int anoddpm_struct_size(int32_t which)
         case 30: return (int)sizeof(anoddpm_pack_batch_args);
         case 31: return (int)sizeof(anoddpm_linear_bwd_batch_args);
         case 32: return (int)sizeof(anoddpm_loss_args);
+        case 33: return (int)sizeof(anoddpm_dropout_args);
         default: return -1;
     }
 }

@@ -286,8 +286,9 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float *x, int64_t row
 __global__ __launch_bounds__(256) void resample2x_kernel(anoddpm_resample_args a)
 {
     const int C4 = a.C >> 2;
-    const int Ho = a.mode == 1 ? a.H * 2 : a.H / 2;
-    const int Wo = a.mode == 1 ? a.W * 2 : a.W / 2;
+    const bool up = a.mode == 1 || a.mode == 4;
+    const int Ho = up ? a.H * 2 : a.H / 2;
+    const int Wo = up ? a.W * 2 : a.W / 2;
     const int64_t total = (int64_t)a.B * Ho * Wo * C4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int q = (int)(i % C4);
@@ -300,6 +301,9 @@ __global__ __launch_bounds__(256) void resample2x_kernel(anoddpm_resample_args a
         float4 o;
         if (a.mode == 1) {
             o = in[((int64_t)(yo >> 1) * a.W + (xo >> 1)) * C4];
+        } else if (a.mode == 4) {                                  // adjoint of the stride-2 pick: values on the even pixels, zeros elsewhere
+            o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(yo & 1) && !(xo & 1)) o = in[((int64_t)(yo >> 1) * a.W + (xo >> 1)) * C4];
         } else if (a.mode == 3) {                                  // stride-2 pick: the even pixels of a stride-1 result
             o = in[((int64_t)(2 * yo) * a.W + 2 * xo) * C4];
         } else {
@@ -640,6 +644,40 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(anoddpm_layout_args a
     }
 }
 
+// ---------------------------------------------------------------- dropout (training) ----------
+// keep decision of element `idx`: a 64-bit mix (splitmix64 finaliser) of the seed and the index, compared with p * 2^32
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, unsigned thresh)
+{
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32) >= thresh;
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(anoddpm_dropout_args a, unsigned thresh, float inv_keep)
+{
+    const int b = blockIdx.y;
+    const int64_t base = (int64_t)b * a.n;
+    const int64_t n4 = a.n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 v = reinterpret_cast<const float4 *>(a.x + base)[i];
+        if (a.mode == 0) {
+            const int c = (int)((i * 4) % a.C);
+            const float4 sc = *reinterpret_cast<const float4 *>(a.gn_scale + (int64_t)b * a.C + c);
+            const float4 sh = *reinterpret_cast<const float4 *>(a.gn_shift + (int64_t)b * a.C + c);
+            v.x = silu_f(v.x * sc.x + sh.x); v.y = silu_f(v.y * sc.y + sh.y);
+            v.z = silu_f(v.z * sc.z + sh.z); v.w = silu_f(v.w * sc.w + sh.w);
+        }
+        const uint64_t e = (uint64_t)(base + i * 4);
+        v.x = dropout_keep(a.seed, e, thresh) ? v.x * inv_keep : 0.f;
+        v.y = dropout_keep(a.seed, e + 1, thresh) ? v.y * inv_keep : 0.f;
+        v.z = dropout_keep(a.seed, e + 2, thresh) ? v.z * inv_keep : 0.f;
+        v.w = dropout_keep(a.seed, e + 3, thresh) ? v.w * inv_keep : 0.f;
+        reinterpret_cast<float4 *>(a.out + base)[i] = v;
+    }
+}
+
 inline unsigned cap_grid(int64_t blocks) { return (unsigned)(blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks)); }
 
 }  // namespace
@@ -691,13 +729,28 @@ extern "C" int anoddpm_softmax_rows(const anoddpm_softmax_args *a, void *stream)
 extern "C" int anoddpm_resample2x(const anoddpm_resample_args *a, void *stream)
 {
     ANODDPM_REQUIRE(a && a->in && a->out, "resample2x: null pointer");
-    ANODDPM_REQUIRE(a->C % 4 == 0 && (a->mode == 1 || ((a->mode == 2 || a->mode == 3) && a->H % 2 == 0 && a->W % 2 == 0)), "resample2x: bad shape/mode");
+    ANODDPM_REQUIRE(a->C % 4 == 0 && (a->mode == 1 || a->mode == 4 || ((a->mode == 2 || a->mode == 3) && a->H % 2 == 0 && a->W % 2 == 0)), "resample2x: bad shape/mode");
     ANODDPM_REQUIRE(!a->out_act || (a->mode == 2 && a->gn_scale && a->gn_shift), "resample2x: the activated output needs mode 2 and a GroupNorm affine");
-    const int Ho = a->mode == 1 ? a->H * 2 : a->H / 2, Wo = a->mode == 1 ? a->W * 2 : a->W / 2;
+    const bool up = a->mode == 1 || a->mode == 4;
+    const int Ho = up ? a->H * 2 : a->H / 2, Wo = up ? a->W * 2 : a->W / 2;
     const int64_t total = (int64_t)a->B * Ho * Wo * (a->C / 4);
     if (total == 0) return ANODDPM_OK;
     hipLaunchKernelGGL(resample2x_kernel, dim3(cap_grid((total + 255) / 256)), dim3(256), 0, anoddpm::as_stream(stream), *a);
     return anoddpm::check_launch("resample2x");
+}
+
+extern "C" int anoddpm_dropout(const anoddpm_dropout_args *a, void *stream)
+{
+    ANODDPM_REQUIRE(a && a->x && a->out, "dropout: null pointer");
+    ANODDPM_REQUIRE(a->B >= 0 && a->B <= 65535 && a->n >= 0 && a->n % 4 == 0 && a->C > 0 && a->C % 4 == 0 && a->n % a->C == 0, "dropout: bad sizes");
+    ANODDPM_REQUIRE(a->mode == 1 || (a->mode == 0 && a->gn_scale && a->gn_shift), "dropout: mode 0 needs the GroupNorm affine");
+    ANODDPM_REQUIRE(a->p >= 0.f && a->p < 1.f, "dropout: p must be in [0, 1)");
+    if (a->B == 0 || a->n == 0) return ANODDPM_OK;
+    const double t = (double)a->p * 4294967296.0;
+    const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    hipLaunchKernelGGL(dropout_kernel, dim3(cap_grid((a->n / 4 + 255) / 256), (unsigned)a->B), dim3(256), 0, anoddpm::as_stream(stream),
+                       *a, thresh, 1.0f / (1.0f - a->p));
+    return anoddpm::check_launch("dropout");
 }
 
 extern "C" int anoddpm_linear_small(const anoddpm_linear_args *a, void *stream)

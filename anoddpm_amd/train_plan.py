@@ -28,7 +28,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (ChanStatsArgs, ColsumFoldArgs, GnBwdArgs, GnFinalizeArgs, HeadArgs, HeadBwdArgs, LinearArgs, LinearBwdArgs,
+from ._lib import (ChanStatsArgs, ColsumFoldArgs, DropoutArgs, GnBwdArgs, GnFinalizeArgs, HeadArgs, HeadBwdArgs, LinearArgs, LinearBwdArgs,
                    LinearBwdBatchArgs, Op, PackArgs, PackBatchArgs, PosembArgs, ResampleArgs, SoftmaxArgs, SoftmaxBwdArgs, StemArgs, StemBwdArgs, TransposeArgs,
                    Wgrad1Args, WgradArgs, check, lib)
 from .unet import _Plan, _posemb_freqs
@@ -37,12 +37,12 @@ __all__ = ["TrainPlan", "TrainPlanFunction", "eligible"]
 
 
 def eligible(model, B, S):
-    """Shapes the native training plan covers (everything the reference's args files use); others take the generic
-    autograd expression of unet.UNetModel._forward_autograd."""
+    """Shapes the native training plan covers: everything the reference's args files use and every constructor option
+    (dropout, the Downsample / Upsample topology); what is left out are extreme sizes (batch > 16 per GPU, base_channels > 256,
+    more than four image channels), which raise."""
     cfin, nout = model._final_cin, model.in_channels
     head_ok = nout <= 4 and S % 8 == 0 and (100 * (cfin + 16) + 9 * cfin * nout) * 4 <= 64 * 1024 and cfin <= 256
-    return (head_ok and 1 <= B <= 16 and model.model_channels % 4 == 0 and model.model_channels <= 256
-            and getattr(model, "biggan_updown", True))      # Downsample / Upsample layers: generic autograd expression
+    return head_ok and 1 <= B <= 16 and model.model_channels % 4 == 0 and model.model_channels <= 256
 
 
 def _op_array(ops):
@@ -55,8 +55,10 @@ def _op_array(ops):
 
 
 class TrainPlan(_Plan):
-    def __init__(self, model, B, S, device, want_dx=False):
+    def __init__(self, model, B, S, device, want_dx=False, p_drop=0.0):
         self.want_dx = want_dx
+        self.p_drop = float(p_drop)  # nn.Dropout of ResBlock.out_layers (UNet.py:192), training mode only
+        self._drop_ops = []          # (forward struct, backward struct, layer index): the seeds are patched per forward
         self.bops = []               # backward op list
         self.pack_ops = []           # weight packing, runs ahead of the forward
         self._packs = {}
@@ -262,13 +264,14 @@ class TrainPlan(_Plan):
         nitems = B * ipb
         # Winograd-domain weight gradient (csrc/wgrad43.hip: the adjoint of the F(4x4,3x3) forward kernel, 4x fewer MFMAs) on the
         # maps where the forward uses that kernel; ANODDPM_NO_WGRAD43=1 keeps the direct nine-tap kernel everywhere
-        algo = int(a_mode in (0, 1) and H % 8 == 0 and W % 16 == 0 and K % 32 == 0 and N % 64 == 0 and (c1 == 0 or c0 % 16 == 0)
+        # (a plain operand -- dropout output, Downsample / Upsample inputs -- takes the direct kernel: gn is None)
+        algo = int(gn is not None and a_mode in (0, 1) and H % 8 == 0 and W % 16 == 0 and K % 32 == 0 and N % 64 == 0 and (c1 == 0 or c0 % 16 == 0)
                    and B <= 15 and H * W >= int(os.environ.get("ANODDPM_WGRAD43_MIN_PIXELS", 32 * 32))
                    and os.environ.get("ANODDPM_NO_WGRAD43", "0") != "1")
         wa = WgradArgs()
         wa.a0 = srcs[0][0].data_ptr()
         wa.a1 = srcs[1][0].data_ptr() if c1 else None
-        wa.gn_scale, wa.gn_shift = gn[0].data_ptr(), gn[1].data_ptr()
+        wa.gn_scale, wa.gn_shift = (gn[0].data_ptr(), gn[1].data_ptr()) if gn is not None else (None, None)
         wa.dy, wa.dw = dy.data_ptr(), self.dW(wkey)
         wa.algo = algo
         if algo:
@@ -281,7 +284,7 @@ class TrainPlan(_Plan):
         wa.a0_bs, wa.a1_bs, wa.dy_bs = Ps * c0, Ps * c1, H * W * N
         wa.c0, wa.c1, wa.a0_ld, wa.a1_ld, wa.dy_ld = c0, c1, c0, (c1 if c1 else 4), N
         wa.H, wa.W, wa.N, wa.B = H, W, N, B
-        wa.a_mode, wa.act, wa.gn_ld, wa.band, wa.accumulate = a_mode, 1, K, band, 1
+        wa.a_mode, wa.act, wa.gn_ld, wa.band, wa.accumulate = a_mode, (1 if gn is not None else 0), K, band, 1
         colsum = self.buf(B, ipb, N)
         wa.colsum = colsum.data_ptr()
         self.badd(_lib.OP_WGRAD3, wa)
@@ -452,7 +455,22 @@ class TrainPlan(_Plan):
                     raise NotImplementedError("identity skip over a concatenated input (cin == cout) is not built")
                 sk = srcs[0][0]
             h2 = self.buf(B, Pout, cout)
-            conv3([(h1, cout)], Hout, cout, g2, 0, prefix + ".out_layers.3.weight", prefix + ".out_layers.3.bias", h2, res=sk)
+            a2 = None
+            if self.p_drop > 0:
+                # Dropout between the activation and the convolution: the dropped activation is materialised once (one
+                # elementwise launch) and the convolution, its weight gradient and its data gradient see a plain operand
+                a2 = self.buf(B, Pout, cout)
+                dr = DropoutArgs()
+                dr.x, dr.out, dr.gn_scale, dr.gn_shift = h1.data_ptr(), a2.data_ptr(), g2[0].data_ptr(), g2[1].data_ptr()
+                dr.n, dr.B, dr.C, dr.mode, dr.p, dr.seed = Pout * cout, B, cout, 0, self.p_drop, 0
+                self.add(_lib.OP_DROPOUT, dr)
+                drop_entry = [dr, None, len(self._drop_ops)]         # forward order; the backward twin is filled in below
+                self._drop_ops.append(drop_entry)
+                wk, bk = prefix + ".out_layers.3.weight", prefix + ".out_layers.3.bias"
+                self.igemm(srcs=[(a2, cout)], H=Hout, W=Hout, ks=3, N=cout, bmat=lambda: self.pack(wk, 0),
+                           wino=lambda: self.pack(wk, 1), wino43=lambda: self.pack(wk, 5), bias=bias(bk), res=sk, out=h2, want_stats=True)
+            else:
+                conv3([(h1, cout)], Hout, cout, g2, 0, prefix + ".out_layers.3.weight", prefix + ".out_layers.3.bias", h2, res=sk)
 
             def bwd():
                 gh2 = self.G(h2)
@@ -479,8 +497,16 @@ class TrainPlan(_Plan):
                         st.accumulate = self.gacc(src)
                         self.add(_lib.OP_RESAMPLE, st)
                     # 2-4. out_layers: weight gradient, data gradient, GroupNorm + SiLU backward into g(h1)
-                    self.wgrad3([(h1, cout)], Hout, Hout, g2, 0, gh2, cout, prefix + ".out_layers.3.weight", prefix + ".out_layers.3.bias")
-                    da2 = dgrad3(gh2, Hout, cout, cout, prefix + ".out_layers.3.weight")
+                    if a2 is not None:
+                        self.wgrad3([(a2, cout)], Hout, Hout, None, 0, gh2, cout, prefix + ".out_layers.3.weight", prefix + ".out_layers.3.bias")
+                        da2 = dgrad3(gh2, Hout, cout, cout, prefix + ".out_layers.3.weight")
+                        db = DropoutArgs()                           # d(activation) = mask / (1 - p) * d(dropped), in place
+                        db.x, db.out, db.n, db.B, db.C, db.mode, db.p, db.seed = da2.data_ptr(), da2.data_ptr(), Pout * cout, B, cout, 1, self.p_drop, 0
+                        self.add(_lib.OP_DROPOUT, db)
+                        drop_entry[1] = db
+                    else:
+                        self.wgrad3([(h1, cout)], Hout, Hout, g2, 0, gh2, cout, prefix + ".out_layers.3.weight", prefix + ".out_layers.3.bias")
+                        da2 = dgrad3(gh2, Hout, cout, cout, prefix + ".out_layers.3.weight")
                     self.gn_bwd([(h1, cout)], Hout, da2, Pout, g2, prefix + ".out_layers.0", 1, 0)
                     gh1 = self.G(h1)
                     # 5. in_layers weight gradient; its dy column sums are the conv bias and the embedding gradients
@@ -604,11 +630,79 @@ class TrainPlan(_Plan):
                 elif kind == "res":
                     h, Hc = res_block(prefix, srcs, Hc, cout, resample)
                     srcs = [(h, cout)]
+                elif kind in ("downsample", "upsample"):
+                    h, Hc = resample_layer(prefix, kind, srcs[0][0], Hc, cin, resample == "conv")
+                    srcs = [(h, cin)]
                 else:
                     h = attn_block(prefix, srcs[0][0], Hc, cin)
                     srcs = [(h, cin)]
                 self.block_out[prefix] = (srcs[0][0], srcs[0][1], Hc)
             return srcs, Hc
+
+        def resample_layer(prefix, kind, x, Hc, C, conv):
+            """Downsample / Upsample of the biggan_updown=False topology (UNet.py:60-92): raw activations in (no norm, no activation).
+            Forward as the inference plan (unet._Plan); backward: the weight gradient on the plain operand, the data gradient as
+            the forward kernel on the flipped weights, and the adjoint of the resampling around it."""
+            def rs(inp, Hin, mode, out, scale=1.0, acc=0):
+                st = ResampleArgs()
+                st.inp, st.out = inp.data_ptr(), out.data_ptr()
+                st.B, st.H, st.W, st.C, st.mode, st.scale, st.accumulate = B, Hin, Hin, C, mode, scale, acc
+                self.add(_lib.OP_RESAMPLE, st)
+
+            def into_gx(dy, H, wkey):
+                """dx (+)= conv3x3(dy, flipped weights), straight into the gradient buffer of x"""
+                gx = self.G(x)
+                acc = self.gacc(x)
+                self.igemm(srcs=[(dy, C)], H=H, W=H, ks=3, N=C, bmat=lambda: self.pack(wkey, 0, bwd=1),
+                           wino=lambda: self.pack(wkey, 1, bwd=1), wino43=lambda: self.pack(wkey, 5, bwd=1),
+                           res=(gx if acc else None), out=gx)
+
+            if kind == "downsample":
+                Ho = Hc // 2
+                out = self.buf(B, Ho * Ho, C)
+                if not conv:
+                    rs(x, Hc, 2, out)                                   # nn.AvgPool2d(2, 2)
+
+                    def bwd():
+                        with self.in_backward():
+                            rs(self.G(out), Ho, 1, self.G(x), 0.25, self.gacc(x))
+                    self._bw.append(bwd)
+                    return out, Ho
+                wk, bk = prefix + ".downsample.weight", prefix + ".downsample.bias"
+                full = self.buf(B, Hc * Hc, C)                          # the stride-1 result; the stride-2 output = its even pixels
+                self.igemm(srcs=[(x, C)], H=Hc, W=Hc, ks=3, N=C, act=0, bmat=lambda: self.pack(wk, 0), wino=lambda: self.pack(wk, 1),
+                           wino43=lambda: self.pack(wk, 5), bias=bias(bk), out=full)
+                rs(full, Hc, 3, out)
+
+                def bwd():
+                    gfull = self.buf(B, Hc * Hc, C)
+                    with self.in_backward():
+                        rs(self.G(out), Ho, 4, gfull)                   # gradient on the stride-1 grid: zeros off the even pixels
+                        self.wgrad3([(x, C)], Hc, Hc, None, 0, gfull, C, wk, bk)
+                        into_gx(gfull, Hc, wk)
+                self._bw.append(bwd)
+                return out, Ho
+            Ho = Hc * 2
+            out = self.buf(B, Ho * Ho, C)
+            if not conv:
+                rs(x, Hc, 1, out)                                       # F.interpolate(scale_factor=2, mode="nearest")
+
+                def bwd():
+                    with self.in_backward():
+                        rs(self.G(out), Ho, 2, self.G(x), 4.0, self.gacc(x))
+                self._bw.append(bwd)
+                return out, Ho
+            wk, bk = prefix + ".conv.weight", prefix + ".conv.bias"
+            self.igemm(srcs=[(x, C)], H=Ho, W=Ho, ks=3, N=C, act=0, a_mode=1, bmat=lambda: self.pack(wk, 0), wino=lambda: self.pack(wk, 1),
+                       wino43=lambda: self.pack(wk, 5), bias=bias(bk), out=out, want_stats=True)
+
+            def bwd():
+                with self.in_backward():
+                    self.wgrad3([(x, C)], Hc, Ho, None, 1, self.G(out), C, wk, bk)
+                    dup = dgrad3(self.G(out), Ho, C, C, wk)             # gradient of the upsampled operand, at the output resolution
+                    rs(dup, Ho, 2, self.G(x), 4.0, self.gacc(x))        # nearest x2 -> the sum of the four children
+            self._bw.append(bwd)
+            return out, Ho
 
         Hc = S
         srcs = None
@@ -667,6 +761,15 @@ class TrainPlan(_Plan):
         """x: contiguous fp32 [B,C,S,S] on self.device (kept alive by the caller until the backward); t: int64 [B]."""
         self.stem.x = x.data_ptr()
         self.posemb.t = t.data_ptr()
+        if self._drop_ops:
+            # a fresh mask per forward and per layer: the seed mixes torch's seed, a per-plan call counter and the layer index
+            # (the forward launch and the backward launch of a layer get the same value)
+            self._drop_calls = getattr(self, "_drop_calls", 0) + 1
+            base = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._drop_calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+            for fwd, bwd, idx in self._drop_ops:
+                fwd.seed = (base + idx * 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
+                if bwd is not None:
+                    bwd.seed = fwd.seed
         check(lib().anoddpm_run_ops(self.fwd_array, len(self.fwd_list), _lib.current_stream()), "UNet training forward")
         return self.y
 
@@ -706,7 +809,8 @@ class TrainPlan(_Plan):
         else:
             check(lib().anoddpm_run_ops(self.bwd_array, len(self.bops), _lib.current_stream()), "UNet training backward")
         for k in fresh:
-            self.named[k].grad = self.gview[k]
+            if self.named[k].requires_grad:                  # frozen parameters: their gradient stays plan-owned scratch
+                self.named[k].grad = self.gview[k]
         return self.dx
 
     def _bwd_slice(self, lo):

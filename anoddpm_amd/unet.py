@@ -12,9 +12,8 @@ GroupNorm-apply/SiLU/resample/concat fused into their operand load, attention as
 around a softmax, and the batched timestep-embedding projections.  There is no eager-PyTorch or
 CPU fallback for this path: CPU tensors raise.
 
-When autograd is recording (training, diffusion_training.py:99-105) the forward is expressed with
-differentiable PyTorch-ROCm ops so `loss.backward()` works; the hand-written backward kernels are
-the next step of the build plan (SURVEY.md section 7.6 lists this as the legitimate interim).
+When autograd is recording (training, diffusion_training.py:99-105) the forward and the backward are the two
+op lists of the native training plan (train_plan.py) behind one autograd Function.
 """
 import ctypes
 import math
@@ -22,7 +21,6 @@ import os
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
@@ -293,106 +291,35 @@ class UNetModel(nn.Module):
         return plan
 
     # ------------------------------------------------------------------ differentiable forward (training)
-    def _train_plan_for(self, B, S, device, want_dx):
+    def _train_plan_for(self, B, S, device, want_dx, p_drop=0.0):
         from .train_plan import TrainPlan
-        key = (B, S, device, bool(want_dx))
+        key = (B, S, device, bool(want_dx), float(p_drop))
         plan = self._tplans.get(key)
         if plan is None or not plan.params_match():
-            plan = self._tplans[key] = TrainPlan(self, B, S, device, want_dx=want_dx)
+            plan = self._tplans[key] = TrainPlan(self, B, S, device, want_dx=want_dx, p_drop=p_drop)
         return plan
 
     def _forward_autograd(self, x, time):
         """Forward with autograd recording (training, diffusion_training.py:99-102): the native training plan (train_plan.py:
-        forward + backward as flat C-ABI op lists, no ATen / MIOpen compute).  Shapes the plan does not cover yet (dropout > 0,
-        the Downsample / Upsample topology, frozen parameters) -- and ANODDPM_TORCH_BACKWARD=1, the reference expression the
-        parity tests compare against -- run the same forward as differentiable PyTorch-ROCm ops."""
+        forward + backward as flat C-ABI op lists, no ATen / MIOpen compute) -- the ONE training path: every constructor option
+        (dropout, the Downsample / Upsample topology), frozen parameters and input gradients included.  The differentiable
+        PyTorch restatement the parity tests compare against lives in oracle/unet_oracle.py (test infrastructure)."""
         _lib.require_cuda(x, "UNetModel.forward (training)")
-        if (x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[1] == self.in_channels
-                and not (self.dropout > 0 and self.training)
-                and os.environ.get("ANODDPM_TORCH_BACKWARD", "0") != "1"):
-            from . import train_plan
-            params = list(self.parameters())
-            if train_plan.eligible(self, x.shape[0], x.shape[2]) and all(p.requires_grad for p in params):
-                from .training import reducer_of
-                red = reducer_of(self)
-                if red is not None:
-                    red.flat.bind_grads()      # data parallel: gradients live in the flat views on EVERY rank -> same cut backward
-                plan = self._train_plan_for(x.shape[0], x.shape[2], x.device, x.requires_grad)
-                return train_plan.TrainPlanFunction.apply(x, time, params[0], plan)
-        sd = dict(self.named_parameters())
-
-        def P(k):
-            return sd[k]
-
-        def gn(p, h):
-            return F.group_norm(h.float(), 32, P(p + ".weight"), P(p + ".bias"), eps=1e-5)
-
-        half = self.model_channels // 2
-        freqs = _posemb_freqs(half).to(x.device)
-        arg = torch.outer(time * 1, freqs)
-        temb = torch.cat((arg.sin(), arg.cos()), dim=-1)
-        temb = F.linear(temb, P("time_embedding.1.weight"), P("time_embedding.1.bias"))
-        temb = F.linear(F.silu(temb), P("time_embedding.3.weight"), P("time_embedding.3.bias"))
-
-        def res(p, h, resample):
-            xs = h
-            h = F.silu(gn(p + ".in_layers.0", h))
-            if resample == "down":
-                h, xs = F.avg_pool2d(h, 2, 2), F.avg_pool2d(xs, 2, 2)
-            elif resample == "up":
-                h = F.interpolate(h, scale_factor=2, mode="nearest")
-                xs = F.interpolate(xs, scale_factor=2, mode="nearest")
-            h = F.conv2d(h, P(p + ".in_layers.2.weight"), P(p + ".in_layers.2.bias"), padding=1)
-            e = F.linear(F.silu(temb), P(p + ".embed_layers.1.weight"), P(p + ".embed_layers.1.bias"))
-            h = h + e[:, :, None, None]
-            h = F.silu(gn(p + ".out_layers.0", h))
-            h = F.dropout(h, self.dropout, self.training)
-            h = F.conv2d(h, P(p + ".out_layers.3.weight"), P(p + ".out_layers.3.bias"), padding=1)
-            if (p + ".skip_connection.weight") in sd:
-                xs = F.conv2d(xs, P(p + ".skip_connection.weight"), P(p + ".skip_connection.bias"))
-            return xs + h
-
-        def attn(p, h):
-            b, c, hh, ww = h.shape
-            heads = self._heads_for(c)
-            xf = h.reshape(b, c, -1)
-            qkv = F.conv1d(gn(p + ".norm", xf), P(p + ".to_qkv.weight"), P(p + ".to_qkv.bias"))
-            ch = c // heads
-            q, k, v = qkv.reshape(b * heads, 3 * ch, -1).split(ch, dim=1)
-            s = 1.0 / math.sqrt(math.sqrt(ch))
-            w = torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s).float(), dim=-1)
-            a = torch.einsum("bts,bcs->bct", w, v).reshape(b, c, -1)
-            a = F.conv1d(a, P(p + ".proj_out.weight"), P(p + ".proj_out.bias"))
-            return (xf + a).reshape(b, c, hh, ww)
-
-        def run(blks, h):
-            for (p, kind, cin, cout, resample) in blks:
-                if kind == "stem":
-                    h = F.conv2d(h, P(p + ".weight"), P(p + ".bias"), padding=1)
-                elif kind == "res":
-                    h = res(p, h, resample)
-                elif kind == "downsample":             # UNet.py:60-75
-                    h = (F.conv2d(h, P(p + ".downsample.weight"), P(p + ".downsample.bias"), stride=2, padding=1)
-                         if resample == "conv" else F.avg_pool2d(h, 2, 2))
-                elif kind == "upsample":               # UNet.py:77-92
-                    h = F.interpolate(h, scale_factor=2, mode="nearest")
-                    if resample == "conv":
-                        h = F.conv2d(h, P(p + ".conv.weight"), P(p + ".conv.bias"), padding=1)
-                else:
-                    h = attn(p, h)
-            return h
-
-        down, middle, up = self._blocks
-        h = x.float()
-        skips = []
-        for blk in down:
-            h = run(blk, h)
-            skips.append(h)
-        h = run(middle, h)
-        for blk in up:
-            h = run(blk, torch.cat([h, skips.pop()], dim=1))
-        h = F.silu(gn("out.0", h))
-        return F.conv2d(h, P("out.2.weight"), P("out.2.bias"), padding=1).type(x.dtype)
+        if not (x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[1] == self.in_channels):
+            raise ValueError(f"expected [B,{self.in_channels},S,S] input, got {tuple(x.shape)}")
+        from . import train_plan
+        from .training import reducer_of
+        B, S = x.shape[0], x.shape[2]
+        if not train_plan.eligible(self, B, S):
+            raise NotImplementedError(f"UNetModel training at batch {B}, size {S}, base {self.model_channels}: outside the native "
+                                      "training plan (1 <= batch <= 16 per GPU, base_channels % 4 == 0 and <= 256, <= 4 image channels)")
+        red = reducer_of(self)
+        if red is not None:
+            red.flat.bind_grads()              # data parallel: gradients live in the flat views on EVERY rank -> same cut backward
+        p_drop = float(self.dropout) if (self.training and self.dropout > 0) else 0.0
+        plan = self._train_plan_for(B, S, x.device, x.requires_grad, p_drop)
+        anchor = next((p for p in self.parameters() if p.requires_grad), x)       # any tensor that requires grad: makes autograd call backward()
+        return train_plan.TrainPlanFunction.apply(x, time, anchor, plan)
 
 
 def _posemb_freqs(half):

@@ -157,6 +157,7 @@ enum {
     ANODDPM_OP_ATTENTION = 26,   /* anoddpm_attention_args    */
     ANODDPM_OP_PACK_BATCH = 27,  /* anoddpm_pack_batch_args   */
     ANODDPM_OP_LINEAR_BWD_BATCH = 28, /* anoddpm_linear_bwd_batch_args */
+    ANODDPM_OP_DROPOUT = 29,     /* anoddpm_dropout_args      */
     ANODDPM_OP_MAX = 32
 };
 
@@ -299,7 +300,9 @@ int anoddpm_attention(const anoddpm_attention_args *a, void *stream);
 
 /* 2x resampling of an NHWC tensor (the x_upd path of ResBlock, UNet.py:177-181,207):
  * mode 1: nearest x2 up (in H x W -> out 2H x 2W); mode 2: 2x2 average pool (in -> H/2 x W/2); mode 3: the even pixels
- * (2i, 2j) -> H/2 x W/2, i.e. a stride-2 convolution's outputs picked from the stride-1 result (Downsample, UNet.py:60-75).
+ * (2i, 2j) -> H/2 x W/2, i.e. a stride-2 convolution's outputs picked from the stride-1 result (Downsample, UNet.py:60-75);
+ * mode 4: the adjoint of mode 3 -- in H x W -> out 2H x 2W with out[2i][2j] = in[i][j] and zeros elsewhere (the gradient of the
+ * stride-2 convolution's output placed on the stride-1 grid).
  * scale (0 is read as 1) multiplies the result and accumulate != 0 adds it to `out`: the backward of one mode is the
  * other one scaled -- d(avg pool) = nearest-up * 0.25, d(nearest-up) = avg pool * 4 (the sum of the four children). */
 typedef struct {
@@ -503,6 +506,25 @@ typedef struct anoddpm_loss_args {
 
 int anoddpm_loss_forward(const anoddpm_loss_args *a, void *stream);
 int anoddpm_loss_backward(const anoddpm_loss_args *a, void *stream);
+
+/* nn.Dropout(p) of ResBlock.out_layers (UNet.py:192: GroupNorm32 -> SiLU -> Dropout -> conv) in training mode.  The mask is a
+ * counter-based hash of (seed, element index): the same (seed, index) gives the same mask in the forward and the backward launch,
+ * no mask tensor exists.  keep probability 1 - p, kept values scaled by 1 / (1 - p) (torch semantics; the random STREAM is this
+ * library's own -- no implementation reproduces torch's philox offsets, parity tests inject the mask they read back).
+ *   mode 0 (forward):  out[b][i] = keep ? silu(x[b][i] * gn_scale[b][c] + gn_shift[b][c]) / (1 - p) : 0      (c = i % C)
+ *   mode 1 (backward): out[b][i] = keep ? x[b][i] / (1 - p) : 0                                             (x = d(out), may alias out)
+ * x, out: NHWC [B][n]; n = pixels * C. */
+typedef struct anoddpm_dropout_args {
+    const float *x;
+    float *out;
+    const float *gn_scale, *gn_shift;   /* [B][C], mode 0 */
+    int64_t n;                      /* elements per image */
+    uint64_t seed;
+    int32_t B, C, mode;
+    float p;
+} anoddpm_dropout_args;
+
+int anoddpm_dropout(const anoddpm_dropout_args *a, void *stream);
 
 /* ------------------------------------------------------------------ backward twins (training, diffusion_training.py:102)
  * Weight gradient of a 3x3 / stride 1 / pad 1 convolution whose input the forward consumed through the fused operand

@@ -173,7 +173,7 @@ def fill_deterministic(shapes, sigma=0.02):
 def timestep_features(t, dim):
     half = dim // 2
     step = np.log(10000) / half
-    freqs = torch.exp(torch.arange(half) * -step)
+    freqs = torch.exp(torch.arange(half) * -step).to(t.device)     # formed on the host as UNet.py:53-54 does on a CPU run
     arg = torch.outer(t * 1, freqs)
     return torch.cat((arg.sin(), arg.cos()), dim=-1)
 
@@ -182,7 +182,7 @@ def _gn(sd, p, x):
     return F.group_norm(x.float(), 32, sd[p + ".weight"], sd[p + ".bias"], eps=1e-5)
 
 
-def res_block(sd, p, x, temb, resample, record=None):
+def res_block(sd, p, x, temb, resample, record=None, dropout=None):
     h = F.silu(_gn(sd, p + ".in_layers.0", x))
     if resample == "down":
         h = F.avg_pool2d(h, 2, 2)
@@ -194,6 +194,8 @@ def res_block(sd, p, x, temb, resample, record=None):
     e = F.linear(F.silu(temb), sd[p + ".embed_layers.1.weight"], sd[p + ".embed_layers.1.bias"])
     h = h + e[:, :, None, None]
     h = F.silu(_gn(sd, p + ".out_layers.0", h))
+    if dropout is not None:                      # nn.Dropout(p) of UNet.py:192 with an INJECTED keep mask: dropout(p, prefix, h) -> h * mask / (1 - p)
+        h = dropout(p, h)
     h = F.conv2d(h, sd[p + ".out_layers.3.weight"], sd[p + ".out_layers.3.bias"], padding=1)
     if (p + ".skip_connection.weight") in sd:
         x = F.conv2d(x, sd[p + ".skip_connection.weight"], sd[p + ".skip_connection.bias"])
@@ -228,7 +230,7 @@ def resample_layer(sd, p, kind, conv, x):
 
 def forward_autograd(sd, x, t, img_size, base_channels, channel_mults="", num_res_blocks=2,
                      attention_resolutions="32,16,8", in_channels=1, n_heads=1, n_head_channels=-1,
-                     record=None, biggan_updown=True, conv_resample=True):
+                     record=None, biggan_updown=True, conv_resample=True, dropout=None):
     """Returns the model output; if `record` is a dict it receives per-block activations
     keyed by block prefix (NCHW fp32) for layer-wise parity checks.  Autograd is left on: with
     `requires_grad` leaves in `sd` this is the CPU checker for the training gradients
@@ -246,7 +248,7 @@ def forward_autograd(sd, x, t, img_size, base_channels, channel_mults="", num_re
             if kind == "stem":
                 h = F.conv2d(h, sd[p + ".weight"], sd[p + ".bias"], padding=1)
             elif kind == "res":
-                h = res_block(sd, p, h, temb, resample)
+                h = res_block(sd, p, h, temb, resample, dropout=dropout)
             elif kind in ("downsample", "upsample"):
                 h = resample_layer(sd, p, kind, resample == "conv", h)
             else:

@@ -73,8 +73,7 @@ def train_step_c3(batch=4, steps=3):
         loss, _ = train_step(model, diff, x, args, flat, None, opt)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    mode = ("torch / MIOpen fwd+bwd (ANODDPM_TORCH_BACKWARD=1)" if os.environ.get("ANODDPM_TORCH_BACKWARD") == "1"
-            else "hand-written fused 3x3 blocks fwd+bwd")
+    mode = "native training plan fwd+bwd"
     return {"what": f"config3 per-GPU share: train step batch {batch} @256^2 base128 ({mode} + fused AdamW+EMA)",
             "sec_per_step": dt, "images_per_s": batch / dt, "loss": float(loss), "params": flat.numel,
             "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}

@@ -184,10 +184,10 @@ def test_train_step_matches_reference_fixture(name, monkeypatch):
                                   (dict(img_size=64, base_channels=32, n_heads=1), 2),
                                   # BASELINE config 3's per-GPU share: 256^2, base 128, attention at 16/8, batch 4
                                   (dict(img_size=256, base_channels=128, n_heads=2, attention_resolutions="16,8"), 4)])
-def test_native_backward_matches_torch_autograd(kw, B, monkeypatch):
-    """The training forward/backward with the hand-written fused 3x3 blocks (train_ops.FusedGNSiLUConv3x3: Winograd /
-    direct forward, wgrad, dgrad, GroupNorm+SiLU backward kernels) against the all-torch differentiable path:
-    same output, same gradient for every parameter and for the input."""
+def test_native_backward_matches_torch_autograd(kw, B):
+    """The native training plan (train_plan.py: Winograd / direct forward, wgrad, dgrad, GroupNorm+SiLU backward kernels)
+    against the differentiable PyTorch-ROCm restatement of the same forward (oracle/unet_oracle.forward_autograd, test
+    infrastructure, run on the device): same output, same gradient for every parameter and for the input."""
     from UNet import UNetModel
     from oracle import unet_oracle as uo
     torch.manual_seed(3)
@@ -203,18 +203,20 @@ def test_native_backward_matches_torch_autograd(kw, B, monkeypatch):
     t = torch.tensor([17, 640, 3, 999][:B], device=DEV)
     tgt = torch.randn(B, 1, S, S, device=DEV)
 
-    def run(torch_only):
-        monkeypatch.setenv("ANODDPM_TORCH_BACKWARD", "1" if torch_only else "0")
-        m.zero_grad(set_to_none=True)
-        if x.grad is not None:
-            x.grad = None
-        y = m(x, t)
-        loss = ((y - tgt) ** 2).mean()
-        loss.backward()
-        return y.detach().clone(), loss.item(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}, x.grad.detach().clone()
-
-    y_ref, l_ref, g_ref, gx_ref = run(True)
-    y_nat, l_nat, g_nat, gx_nat = run(False)
+    # reference: stock differentiable ops on the same weights
+    leaves = {k: v.to(DEV).clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.detach().clone().requires_grad_(True)
+    y_ref = uo.forward_autograd(leaves, xr, t, **kw)
+    l_ref = ((y_ref - tgt) ** 2).mean()
+    l_ref.backward()
+    g_ref, gx_ref = {k: v.grad.detach() for k, v in leaves.items()}, xr.grad.detach()
+    # native
+    y = m(x, t)
+    assert len(m._tplans) == 1
+    loss = ((y - tgt) ** 2).mean()
+    loss.backward()
+    y_nat, l_nat, g_nat, gx_nat = y.detach(), loss.item(), {k: p.grad.detach() for k, p in m.named_parameters()}, x.grad.detach()
+    y_ref, l_ref = y_ref.detach(), l_ref.item()
     rel = lambda a, b: ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
     assert rel(y_nat, y_ref) < 1e-4 and abs(l_nat - l_ref) < 1e-4 * abs(l_ref)
     assert rel(gx_nat, gx_ref) < 5e-4, rel(gx_nat, gx_ref)
@@ -227,17 +229,81 @@ def test_native_backward_matches_torch_autograd(kw, B, monkeypatch):
     assert worst[0] < 1e-3, worst
 
 
+def test_dropout_trains_natively_with_the_masks_it_reports():
+    """dropout > 0 in training mode (UNet.py:192) runs on the native plan: the hash-generated masks are read back from the plan's
+    dropped-activation buffers and injected into the differentiable restatement -- same output, same gradients; a second
+    forward draws different masks; eval mode drops nothing."""
+    from UNet import UNetModel
+    from oracle import unet_oracle as uo
+    kw = dict(img_size=32, base_channels=32, n_heads=2, attention_resolutions="16,8")
+    p_drop = 0.3
+    torch.manual_seed(4)
+    m = UNetModel(dropout=p_drop, **kw)
+    sd = uo.perturb(uo.fill_deterministic({k: tuple(v.shape) for k, v in m.state_dict().items()}))
+    m.load_state_dict(sd)
+    m.to(DEV).train()
+    B = 2
+    x = torch.rand(B, 1, 32, 32, device=DEV) * 2 - 1
+    t = torch.tensor([40, 911], device=DEV)
+    tgt = torch.randn(B, 1, 32, 32, device=DEV)
+    y = m(x, t)
+    plan = next(iter(m._tplans.values()))
+    res_prefixes = [b[0] for grp in (m._blocks[0], [m._blocks[1]], m._blocks[2]) for blk in grp for b in blk if b[1] == "res"]
+    assert plan.p_drop == p_drop and len(plan._drop_ops) == len(res_prefixes)  # one per ResBlock, forward order
+    # keep masks of this forward, per block prefix: the dropped activation is exactly zero where dropped (NHWC buffers)
+    masks, kept = {}, []
+    for prefix, (fwd, _, _) in zip(res_prefixes, plan._drop_ops):
+        C = fwd.C
+        n = fwd.n
+        buf = next(tn for tn in plan.keep if torch.is_tensor(tn) and tn.data_ptr() == fwd.out)
+        a2 = buf.reshape(B, n // C, C)
+        Hh = int(round((n // C) ** 0.5))
+        masks[prefix] = (a2 != 0).reshape(B, Hh, Hh, C).permute(0, 3, 1, 2).float()
+        kept.append(masks[prefix].mean().item())
+    assert abs(np.mean(kept) - (1 - p_drop)) < 0.02, np.mean(kept)
+    loss = ((y - tgt) ** 2).mean()
+    loss.backward()
+    leaves = {k: v.to(DEV).clone().requires_grad_(True) for k, v in sd.items()}
+    y_ref = uo.forward_autograd(leaves, x, t, dropout=lambda p, h: h * masks[p] / (1 - p_drop), **kw)
+    ((y_ref - tgt) ** 2).mean().backward()
+    assert ((y.detach() - y_ref.detach()).abs().max() / y_ref.detach().abs().max()).item() < 1e-4
+    gmax = max(v.grad.abs().max().item() for v in leaves.values())
+    worst = max((((p.grad - leaves[k].grad).abs().max() / max(leaves[k].grad.abs().max().item(), 1e-4 * gmax)).item(), k)
+                for k, p in m.named_parameters())
+    assert worst[0] < 1e-3, worst
+    y2 = m(x, t)                                                             # another forward: other masks
+    assert not torch.equal(y2.detach(), y.detach())
+    m.eval()
+    with torch.no_grad():
+        y_eval = m(x, t)
+    y_plain = uo.forward(leaves, x, t, **kw)
+    assert ((y_eval - y_plain).abs().max() / y_plain.abs().max()).item() < 1e-4
+
+
+def test_frozen_parameters_get_no_gradient():
+    """Parameters with requires_grad=False (fine-tuning a sub-network) take the native path too: no .grad appears on them."""
+    from UNet import UNetModel
+    m = UNetModel(32, 32, n_heads=2, attention_resolutions="16,8").to(DEV).train()
+    frozen = [p for k, p in m.named_parameters() if k.startswith("down.")]
+    for p in frozen:
+        p.requires_grad_(False)
+    x = torch.rand(2, 1, 32, 32, device=DEV)
+    m(x, torch.tensor([5, 6], device=DEV)).square().mean().backward()
+    assert all(p.grad is None for p in frozen)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters() if p.requires_grad)
+
+
 @pytest.mark.parametrize("conv", [True, False])
 def test_conv_resample_variant_gradients_match_cpu_oracle(conv):
-    """biggan_updown=False (Downsample / Upsample layers, UNet.py:60-92): not a training-plan shape, so the step runs the
-    per-operator autograd expression (fused 3x3 blocks native, the resampling layers on PyTorch-ROCm).  Output, loss and every
-    gradient against the CPU oracle's autograd on the same weights."""
+    """biggan_updown=False (Downsample / Upsample layers, UNet.py:60-92) on the native training plan: the stride-2 convolution's
+    backward goes through the zero-stuffed gradient, the nearest-x2 + convolution through the fused operand load.  Output, loss
+    and every gradient against the CPU oracle's autograd on the same weights."""
     from UNet import UNetModel
     from oracle import unet_oracle as uo
     from anoddpm_amd import train_plan
     kw = dict(img_size=32, base_channels=32, n_heads=2, attention_resolutions="16,8", biggan_updown=False, conv_resample=conv)
     m = UNetModel(**kw)
-    assert not train_plan.eligible(m, 2, 32)
+    assert train_plan.eligible(m, 2, 32)
     assert any(".downsample." in k for k in m.state_dict()) == conv and any(k.endswith(".conv.weight") for k in m.state_dict()) == conv
     sd = uo.perturb(uo.fill_deterministic({k: tuple(v.shape) for k, v in m.state_dict().items()}))
     m.load_state_dict(sd)
@@ -247,6 +313,7 @@ def test_conv_resample_variant_gradients_match_cpu_oracle(conv):
     tgt = torch.randn(2, 1, 32, 32, generator=g)
     t = torch.tensor([40, 911])
     y = m(x.to(DEV), t.to(DEV))
+    assert len(m._tplans) == 1                                               # the native plan, not a PyTorch expression
     loss = ((y - tgt.to(DEV)) ** 2).mean()
     loss.backward()
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
