@@ -706,29 +706,6 @@ class GaussianDiffusionModel:
         with torch.no_grad():
             return self._reverse_chain(model, x, int(t_distance), "gauss", None)      # sample_p default noise, :508
 
-    @staticmethod
-    def _figure_dirs(paths):
-        import os
-        for d in paths:
-            try:
-                os.makedirs(d)
-            except OSError:
-                pass
-
-    @staticmethod
-    def _save_grid(out, nrow, filename):
-        try:
-            import matplotlib
-            matplotlib.use("Agg")
-            import matplotlib.pyplot as plt
-        except Exception:                                               # pragma: no cover
-            return
-        from .helpers import gridify_output
-        plt.imshow(gridify_output(out, nrow), cmap='gray')
-        plt.axis('off')
-        plt.savefig(filename)
-        plt.clf()
-
     def _detection_record(self, x_0, output, mask, extra):
         from . import metrics
         maps, counts = metrics.anomaly_maps(x_0, output, mask, threshold=0.5)
@@ -737,37 +714,24 @@ class GaussianDiffusionModel:
                    counts=counts)
         return rec, maps
 
-    def detection_A(self, model, x_0, args, file, mask, total_avg=2, save=True):
-        """GaussianDiffusion.py:480-529: simplex frequencies 2^7..2^1 x t_distance 50..0.6T step 50, `total_avg`
-        chains each (batched here).  Returns None as upstream; per-setting results are kept in
-        `self.last_detection` (mean / mse / threshold images and the segmentation counts, all on the device)."""
-        import os
-        base = f"./diffusion-videos/ARGS={args['arg_num']}/Anomalous/{file[0]}"
-        if save:
-            self._figure_dirs([base, f"{base}/{file[1]}/", f"{base}/{file[1]}/A"])
+    def detection_A(self, model, x_0, args, file, mask, total_avg=2):
+        """GaussianDiffusion.py:480-529: simplex frequencies 2^7..2^1 x t_distance 50..0.6T step 50, `total_avg` chains each
+        (batched here).  Returns None as upstream; the per-setting results upstream only plots (the figure files are file / plot
+        I/O, out of scope) are kept in `self.last_detection`: mean / mse / threshold images and the segmentation counts, on the device."""
         self.last_detection = []
         for i in range(7, 0, -1):
             freq = 2 ** i
             self.noise_fn = SimplexNoiseFn(self.simplex, frequency=freq, in_channels=self.img_channels)     # :491-494
             for t_distance in range(50, int(args["T"] * 0.6), 50):
                 output = self._avg_chains(model, x_0, t_distance, total_avg)
-                rec, maps = self._detection_record(x_0, output, mask, {"freq": i, "t_distance": t_distance})
+                rec, _ = self._detection_record(x_0, output, mask, {"freq": i, "t_distance": t_distance})
                 self.last_detection.append(rec)
-                if save:
-                    out = torch.cat([x_0, output[:3], maps["mean"], maps["mse_img"], maps["thr_img"], mask])
-                    temp = os.listdir(f"{base}/{file[1]}/A")
-                    self._save_grid(out, 4, f"{base}/{file[1]}/A/freq={i}-t={t_distance}-{len(temp) + 1}.png")
 
-    def detection_B(self, model, x_0, args, file, mask, denoise_fn="gauss", total_avg=5, save=True):
+    def detection_B(self, model, x_0, args, file, mask, denoise_fn="gauss", total_avg=5):
         """GaussianDiffusion.py:531-594: t_distance 50..end step 50 with gaussian or 6-octave simplex forward noise,
-        `total_avg` chains each (batched here).  Returns the list upstream returns -- the values of
-        `evaluation.heatmap(...)`, which are None -- and keeps the device-side results in `self.last_detection`."""
-        import os
-        from . import metrics
+        `total_avg` chains each (batched here).  Returns the list upstream returns -- the values of `evaluation.heatmap(...)`,
+        which are None -- and keeps the device-side results in `self.last_detection` (the figures upstream writes are out of scope)."""
         assert type(file) == tuple
-        base = f"./diffusion-videos/ARGS={args['arg_num']}/Anomalous/{file[0]}"
-        if save:
-            self._figure_dirs([base, f"{base}/{file[1]}", f"{base}/{file[1]}/{denoise_fn}"])
         if denoise_fn == "octave":
             end = int(args["T"] * 0.6)
             self.noise_fn = SimplexNoiseFn(self.simplex, octave=6, persistence=0.8, frequency=64)           # :547-550
@@ -778,14 +742,7 @@ class GaussianDiffusionModel:
         self.last_detection = []
         for t_distance in range(50, end, 50):
             output = self._avg_chains(model, x_0, t_distance, total_avg)
-            rec, maps = self._detection_record(x_0, output, mask, {"t_distance": t_distance})
+            rec, _ = self._detection_record(x_0, output, mask, {"t_distance": t_distance})
             self.last_detection.append(rec)
-            dice = None
-            if save:
-                temp = os.listdir(f"{base}/{file[1]}/{denoise_fn}")
-                dice = metrics.heatmap(real=x_0, recon=maps["mean"], mask=mask,
-                                       filename=f"{base}/{file[1]}/{denoise_fn}/heatmap-t={t_distance}-{len(temp) + 1}.png")
-                out = torch.cat([x_0, output[:3], maps["mean"], maps["mse_img"], maps["thr_img"], mask])
-                self._save_grid(out, 4, f"{base}/{file[1]}/{denoise_fn}/t={t_distance}-{len(temp) + 1}.png")
-            dice_coeff.append(dice)
+            dice_coeff.append(None)                                 # evaluation.heatmap() returns None (evaluation.py:12-22)
         return dice_coeff

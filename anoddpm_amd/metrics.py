@@ -95,21 +95,9 @@ def anomaly_metrics(real, recon, mask, threshold=0.5):
 
 # ---------------------------------------------------------------------------------- evaluation.py surface
 def heatmap(real, recon, mask, filename, save=True):
-    """evaluation.py:12-22.  Returns None as upstream; the figure is written when `save` and matplotlib is usable."""
-    maps, _ = anomaly_maps(real, recon, None, want=("mse_img", "thr_img"))
-    if save:
-        from .helpers import gridify_output
-        try:
-            import matplotlib
-            matplotlib.use("Agg")
-            import matplotlib.pyplot as plt
-        except Exception:                                            # pragma: no cover
-            return None
-        output = torch.cat((real, recon.reshape(1, *recon.shape[-3:]), maps["mse_img"], maps["thr_img"], mask))
-        plt.imshow(gridify_output(output, 5)[..., 0], cmap="gray")
-        plt.axis('off')
-        plt.savefig(filename)
-        plt.clf()
+    """evaluation.py:12-22 computes the squared-error / threshold images, plots them and returns None.  The images come from the
+    fused pass (anomaly_maps); writing the figure is plot I/O, out of scope: `filename` / `save` are accepted and ignored."""
+    anomaly_maps(real, recon, None, want=("mse_img", "thr_img"))
     return None
 
 

@@ -55,7 +55,7 @@ def test_detection_B_records_and_return(tmp_path, monkeypatch):
     x_0 = torch.rand(1, 1, 32, 32, device=DEV) * 2 - 1
     mask = (torch.rand(1, 1, 32, 32, device=DEV) > 0.7).float()
     args = {"arg_num": 9, "T": 100, "img_size": [32, 32]}
-    out = d.detection_B(m, x_0, args, ("vol", "slice"), mask, denoise_fn="gauss", total_avg=2, save=False)
+    out = d.detection_B(m, x_0, args, ("vol", "slice"), mask, denoise_fn="gauss", total_avg=2)
     assert out == [None]                                     # range(50, 80, 50): upstream appends heatmap()'s None
     assert not os.path.exists(tmp_path / "diffusion-videos")
     rec = d.last_detection[0]
@@ -68,25 +68,26 @@ def test_detection_B_records_and_return(tmp_path, monkeypatch):
     # octave variant re-assigns noise_fn (stateful, like upstream) and shortens the range; like upstream it needs
     # a model constructed with a simplex noise type (self.simplex only exists then, GaussianDiffusion.py:164-165)
     with pytest.raises(AttributeError):
-        d.detection_B(m, x_0, args, ("vol", "slice"), mask, denoise_fn="octave", total_avg=2, save=False)
+        d.detection_B(m, x_0, args, ("vol", "slice"), mask, denoise_fn="octave", total_avg=2)
     d = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(100, "linear"), noise="simplex")
     np.random.seed(4)
-    out = d.detection_B(m, x_0, args, ("vol", "slice"), mask, denoise_fn="octave", total_avg=2, save=False)
+    out = d.detection_B(m, x_0, args, ("vol", "slice"), mask, denoise_fn="octave", total_avg=2)
     assert out == [None] and d.last_detection[0]["output"].shape == (2, 1, 32, 32)
     n = d.noise_fn(x_0, torch.zeros(1, dtype=torch.int64, device=DEV))
     assert n.shape == x_0.shape and n.is_cuda
 
 
-def test_detection_B_writes_figures(tmp_path, monkeypatch):
-    pytest.importorskip("matplotlib")
+def test_detection_B_returns_upstream_list_and_keeps_device_results(tmp_path, monkeypatch):
     GD, m, d = tiny()
     monkeypatch.chdir(tmp_path)
     x_0 = torch.rand(1, 1, 32, 32, device=DEV) * 2 - 1
     mask = torch.zeros(1, 1, 32, 32, device=DEV)
     args = {"arg_num": 9, "T": 100, "img_size": [32, 32]}
-    d.detection_B(m, x_0, args, ("vol", "slice"), mask, denoise_fn="gauss", total_avg=3)
-    files = sorted(os.listdir(tmp_path / "diffusion-videos/ARGS=9/Anomalous/vol/slice/gauss"))
-    assert len(files) == 2 and files[0].startswith("heatmap-t=50-") and files[1].startswith("t=50-")
+    out = d.detection_B(m, x_0, args, ("vol", "slice"), mask, denoise_fn="gauss", total_avg=3)
+    assert out == [None]                                             # upstream appends evaluation.heatmap()'s return value
+    rec = d.last_detection[0]
+    assert rec["t_distance"] == 50 and rec["output"].shape == (3, 1, 32, 32) and rec["mean"].is_cuda
+    assert not os.listdir(tmp_path)                                  # no figure / directory output from the product
 
 
 def test_detection_A_frequency_sweep(tmp_path, monkeypatch):
@@ -97,7 +98,7 @@ def test_detection_A_frequency_sweep(tmp_path, monkeypatch):
     x_0 = torch.rand(1, 1, 32, 32, device=DEV) * 2 - 1
     mask = torch.zeros(1, 1, 32, 32, device=DEV)
     args = {"arg_num": 9, "T": 100, "img_size": [32, 32]}
-    assert d.detection_A(m, x_0, args, ("vol", "slice"), mask, total_avg=2, save=False) is None
+    assert d.detection_A(m, x_0, args, ("vol", "slice"), mask, total_avg=2) is None
     recs = d.last_detection
     assert [r["freq"] for r in recs] == [7, 6, 5, 4, 3, 2, 1] and all(r["t_distance"] == 50 for r in recs)
     assert all(torch.isfinite(r["output"]).all() and r["output"].abs().max() <= 1.0 + 1e-6 for r in recs)
