@@ -271,6 +271,10 @@ TRAIN_CASES = {
                    dict(lr=1e-4, weight_decay=0.0), [[17, 640], [799, 3]]),
     "i128_b32_hc32": (dict(img_size=128, base_channels=32, n_head_channels=32, attention_resolutions="16,8"), 2,
                       dict(lr=2e-4, weight_decay=0.01), [[250, 0], [31, 555]]),
+    # the shapes that reach the Winograd F(4x4,3x3) forward / data-gradient kernels (both variants: 128-channel grids of >= 200
+    # workgroups at 128^2, 64-channel workgroups at 64^2) and the Winograd-domain weight gradient: base 128, batch 4; one step
+    "i128_b128_f43": (dict(img_size=128, base_channels=128, n_heads=2, attention_resolutions="16,8"), 4,
+                      dict(lr=1e-4, weight_decay=0.0), [[17, 640, 3, 799]]),
 }
 
 

@@ -135,7 +135,7 @@ def test_train_step_decreases_loss_and_refreshes_hip_plan():
     assert ((yg.detach() - yt).abs().max() / yt.abs().max().clamp_min(1e-6)) < 1e-3
 
 
-@pytest.mark.parametrize("name", ["i64_b64_h2", "i128_b32_hc32"])
+@pytest.mark.parametrize("name", ["i64_b64_h2", "i128_b32_hc32", "i128_b128_f43"])
 def test_train_step_matches_reference_fixture(name, monkeypatch):
     """Two optimiser steps of the reference's own loop body (diffusion_training.py:99-107, run by the reference's classes
     on CPU: tests/golden/train_*.npz) against `p_loss` -> backward (hand-written kernels) -> FusedAdamWEMA on the device,
@@ -146,9 +146,9 @@ def test_train_step_matches_reference_fixture(name, monkeypatch):
     from anoddpm_amd.training import FlatBuffers, FusedAdamWEMA
     from conftest import GOLDEN
     from oracle import unet_oracle as uo
-    from test_oracle_training import CASES, check_against_fixture
+    from test_oracle_training import CASES, GPU_ONLY_CASES, check_against_fixture
     g = np.load(os.path.join(GOLDEN, f"train_{name}.npz"))
-    kw = CASES[name]
+    kw = {**CASES, **GPU_ONLY_CASES}[name]
     S = kw["img_size"]
     model = UNetModel(**kw)
     keys = [str(k) for k in g["keys"]]
@@ -163,7 +163,8 @@ def test_train_step_matches_reference_fixture(name, monkeypatch):
     diff = GD.GaussianDiffusionModel([S, S], GD.get_beta_schedule(1000, "linear"), loss_type="l2", noise="gauss")
     args = {"train_start": True, "sample_distance": 800, "Batch_Size": int(g["s0/x0"].shape[0])}
     real_randint = torch.randint
-    for step in range(2):
+    nsteps = sum(f"s{i}/x0" in g.files for i in range(4))
+    for step in range(nsteps):
         x0, noise, t = (torch.from_numpy(g[f"s{step}/{n}"]).to(DEV) for n in ("x0", "noise", "t"))
         diff.noise_fn = lambda a, b, _n=noise: _n
         monkeypatch.setattr(torch, "randint", lambda *a, **k: t.clone())
@@ -178,6 +179,15 @@ def test_train_step_matches_reference_fixture(name, monkeypatch):
         assert np.abs(probe(eps, 1024) - g[f"s{step}/eps"]).max() < 1e-3 * np.abs(g[f"s{step}/eps"]).max()
         check_against_fixture(g, step, keys, loss.item(), grads, norm.item(), dict(model.named_parameters()),
                               dict(ema.named_parameters()), lr)
+    if name == "i128_b128_f43":
+        # this fixture exists to pin the Winograd F(4x4,3x3) kernels to a REFERENCE-run gradient: make sure the plan used them
+        # (forward + data gradient on both kernel variants, the Winograd-domain weight gradient)
+        from anoddpm_amd import _lib
+        plan = next(iter(model._tplans.values()))
+        f43 = [st for code, st in plan.ops + plan.bops if code == _lib.OP_IGEMM and st.cfg == 3]
+        assert any(st.H == 128 and st.N == 128 for st in f43) and any(st.H == 64 for st in f43)
+        assert sum(1 for code, st in plan.bops if code == _lib.OP_IGEMM and st.cfg == 3) >= 4
+        assert any(st.algo == 1 for code, st in plan.bops if code == _lib.OP_WGRAD3)
 
 
 @pytest.mark.parametrize("kw,B", [(dict(img_size=32, base_channels=32, n_heads=2, attention_resolutions="16,8"), 2),

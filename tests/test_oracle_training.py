@@ -13,6 +13,13 @@ CASES = {
     "i128_b32_hc32": dict(img_size=128, base_channels=32, n_head_channels=32, attention_resolutions="16,8"),
 }
 
+# reference-run fixtures that are only replayed on the device (the CPU oracle would need minutes per step at this width):
+# base 128 at 128^2, batch 4 -- the smallest shape whose 3x3 layers run on the Winograd F(4x4,3x3) forward / data-gradient /
+# weight-gradient kernels (tests/test_gpu_training.py)
+GPU_ONLY_CASES = {
+    "i128_b128_f43": dict(img_size=128, base_channels=128, n_heads=2, attention_resolutions="16,8"),
+}
+
 
 def probe(v, n=256):
     f = v.detach().flatten()
