@@ -14,6 +14,8 @@ Other BASELINE configurations, same JSON contract (`--config`):
       -> backward -> [RCCL bucketed all-reduce when N > 1] -> clip + AdamW + EMA; value = trained images/s
   c4  simplex microbench: rand_3d_octaves((1000,256,256), 8 octaves) volumes on the device; value = noise voxels/s
   c1  config 1's 64x64 model on the GPU (used by the contract test; runs in seconds)
+  det one detection_B setting end to end (5 averaged chains x 50 reverse steps, batched, + on-device anomaly maps): the loop the
+      reference runs around the hot path; value = reverse chain-steps/s; a side line, no roofline object
 
 Multi-GPU: one process per GPU (torchrun), each rank works on its own shard; inference and the simplex microbench
 have no data-path collective -- RCCL is used only for the timing barrier and the max-over-ranks
@@ -50,6 +52,9 @@ CONFIGS = {
     "c4": dict(kind="simplex", img=256, slices=1000, octaves=8, batch=1,
                name="simplex rand_3d_octaves volume 1000x256x256, 8 octaves, persistence 0.8, frequency 64, fp64 "
                     "(BASELINE config 4)"),
+    "det": dict(kind="detect", img=256, base=128, mults="", attn="16,8", heads=2, batch=5, t_distance=50,
+                name="detection_B setting @256x256 (GaussianDiffusion.py:531-594): 5 averaged chains x 50 reverse steps from "
+                     "octave-simplex-noised x_0 + anomaly maps, base128 attn16,8, one image per GPU (SURVEY 8f row 1)"),
 }
 T_STEPS = 1000
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -637,6 +642,39 @@ def run_simplex(c, args, cfg):
     return out, roofline, (lambda: cpu_baseline_simplex(cfg))
 
 
+def run_detect(c, args, cfg):
+    """The product loop around the hot path: one (t_distance) setting of detection_B for one image per GPU =
+    forward-noise `total_avg` copies, run them as ONE batched reverse chain (graph replay), reduce to the mean / mse / threshold
+    maps and the segmentation counts on the device.  A step is one whole setting; value = reverse chain-steps per second."""
+    import GaussianDiffusion as GD
+    from UNet import UNetModel
+    navg, td = args.batch or cfg["batch"], cfg["t_distance"]
+    torch.manual_seed(1234)
+    np.random.seed(1234 + c.rank)
+    model = UNetModel(cfg["img"], cfg["base"], channel_mults=cfg["mults"], n_heads=cfg["heads"], attention_resolutions=cfg["attn"])
+    fill_weights(model)
+    model.to(c.dev).eval()
+    diff = GD.GaussianDiffusionModel([cfg["img"]] * 2, GD.get_beta_schedule(T_STEPS, "linear"), noise="simplex")
+    diff.noise_fn = GD.SimplexNoiseFn(diff.simplex, octave=6, persistence=0.8, frequency=64)          # detection_B "octave", :547-550
+    x0 = mri_like(1, cfg["img"], c.dev, seed=1234 + c.rank)
+    mask = (mri_like(1, cfg["img"], c.dev, seed=99 + c.rank) > 0.2).float()
+    last = {}
+
+    def step():
+        output = diff._avg_chains(model, x0, td, navg)
+        last["rec"], _ = diff._detection_record(x0, output, mask, {"t_distance": td})
+    elapsed = timed(c, args, step)
+    ms_per_step = 1000.0 * elapsed / args.steps
+    value = navg * td * c.world / (ms_per_step / 1000.0)
+    out = {"metric": f"detection_B reverse chain-steps/sec @{cfg['img']}x{cfg['img']} ({navg} averaged chains x {td} steps + anomaly maps per setting)",
+           "value": value, "unit": "chain-steps/s", "ms_per_step": ms_per_step, "scaling": "weak", "dtype": "f32",
+           "config": {"workload": cfg["name"], "chains_per_setting": navg, "t_distance": td,
+                      "ms_per_chain_step_batched": ms_per_step / td,
+                      "parallelism": f"images x{c.world} (one image's settings per rank, no collective)",
+                      "output_finite": bool(torch.isfinite(last["rec"]["mse"]).all().item())}}
+    return out, None, (lambda: {"value": None, "note": "see config c2: the per-step CPU baseline is the same reverse step"})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -654,7 +692,7 @@ def main():
         spawn_ranks(args)
     c = setup_dist(args)
     cfg = dict(CONFIGS[args.config])
-    run = {"reverse": run_reverse, "train": run_train, "simplex": run_simplex}[cfg["kind"]]
+    run = {"reverse": run_reverse, "train": run_train, "simplex": run_simplex, "detect": run_detect}[cfg["kind"]]
     out, roofline, cpu_fn = run(c, args, cfg)
     line = {"metric": out.pop("metric"), "value": out.pop("value"), "unit": out.pop("unit"), "n_gpus": c.world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": out.pop("ms_per_step"), "higher_is_better": True,

@@ -64,6 +64,14 @@ def test_bench_line_simplex_and_training_configs():
     assert any("wgrad43_kernel" in k for k in kernels) and all(0 < k["achieved"] <= r["peak"] for k in r["other_contraction_kernels"])
 
 
+def test_bench_line_detection_setting():
+    """`--config det`: one detection_B setting end to end (batched chains + on-device anomaly maps), a side line."""
+    d = run_bench("--config", "det", "--no-cpu-baseline")
+    assert d["unit"] == "chain-steps/s" and d["value"] > 0 and d["config"]["output_finite"] is True
+    assert d["config"]["chains_per_setting"] == 5 and d["config"]["t_distance"] == 50
+    assert abs(d["value"] - 250 / (d["ms_per_step"] / 1000.0)) < 1e-6 * d["value"]
+
+
 def test_bench_under_torchrun_one_rank_uses_rccl():
     """The driver launches N > 1 as `python -m torch.distributed.run ... bench.py --gpus N`; with one GPU here the same
     launcher at --nproc-per-node 1 plus ANODDPM_BENCH_FORCE_DIST=1 executes the process-group / barrier / all-reduce path."""
