@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 (OP_WGRAD3, OP_WGRAD1, OP_GN_BWD, OP_PACK, OP_SOFTMAX_BWD, OP_TRANSPOSE, OP_LINEAR_BWD, OP_STEM_BWD, OP_HEAD_BWD,
@@ -112,7 +112,8 @@ class PosembArgs(Structure):
 
 class StemArgs(Structure):
     _fields_ = [("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("out", c_void_p),
-                ("B", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32)]
+                ("B", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32),
+                ("stats", c_void_p), ("stats_rows", c_int32)]
 
 
 class LayoutArgs(Structure):
@@ -253,7 +254,7 @@ SYMBOLS = [
     "anoddpm_simplex3_grid_f64", "anoddpm_simplex2_octaves_f64", "anoddpm_simplex2_grid_f64",
     "anoddpm_q_sample", "anoddpm_p_sample_update", "anoddpm_chain_advance",
     "anoddpm_igemm", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
-    "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_conv_head", "anoddpm_nhwc_to_nchw",
+    "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_stem_stats_rows", "anoddpm_conv_head", "anoddpm_nhwc_to_nchw",
     "anoddpm_run_ops", "anoddpm_prof_enable", "anoddpm_prof_active", "anoddpm_prof_collect",
     "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map", "anoddpm_vlb_terms", "anoddpm_conv3x3_wgrad", "anoddpm_gn_silu_backward", "anoddpm_pack_conv3x3",
     "anoddpm_wgrad_pointwise", "anoddpm_pack_weights", "anoddpm_softmax_rows_backward", "anoddpm_transpose_square",
@@ -328,6 +329,7 @@ def lib():
     L.anoddpm_linear_small.argtypes = [POINTER(LinearArgs), c_void_p]
     L.anoddpm_posemb.argtypes = [POINTER(PosembArgs), c_void_p]
     L.anoddpm_conv_stem.argtypes = [POINTER(StemArgs), c_void_p]
+    L.anoddpm_stem_stats_rows.argtypes = [c_int32, c_int32, c_int32, c_int32]
     L.anoddpm_conv_head.argtypes = [POINTER(HeadArgs), c_void_p]
     L.anoddpm_nhwc_to_nchw.argtypes = [POINTER(LayoutArgs), c_void_p]
     L.anoddpm_run_ops.argtypes = [POINTER(Op), c_int32, c_void_p]
@@ -355,7 +357,7 @@ def lib():
     L.anoddpm_volume_normalise.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
     L.anoddpm_mri_slice_prepare.argtypes = [POINTER(MriSliceArgs), c_void_p]
     L.anoddpm_resize_bilinear_pil.argtypes = [POINTER(ResizeArgs), c_void_p]
-    for i in range(8):
+    for i in range(16):
         if os.environ.get(f"ANODDPM_DEBUG{i}"):
             L.anoddpm_debug_set(i, int(os.environ[f"ANODDPM_DEBUG{i}"], 0))
     _lib = L

@@ -9,7 +9,7 @@
 namespace anoddpm {
 
 static thread_local char g_err[512] = "";
-int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+int g_debug[16] = {0};
 
 void set_error(const char *fmt, ...)
 {
@@ -67,12 +67,12 @@ using namespace anoddpm;
 
 extern "C" int anoddpm_debug_set(int32_t key, int32_t value)
 {
-    if (key < 0 || key >= 8) return ANODDPM_EINVAL;
+    if (key < 0 || key >= 16) return ANODDPM_EINVAL;
     g_debug[key] = value;
     return ANODDPM_OK;
 }
 
-extern "C" int anoddpm_abi_version(void) { return 18; }
+extern "C" int anoddpm_abi_version(void) { return 19; }
 
 extern "C" const char *anoddpm_last_error(void) { return g_err; }
 

@@ -29,10 +29,11 @@ __device__ __forceinline__ f32x4 load_da(const anoddpm_gn_bwd_args &a, const flo
 struct ChanParams { f32x4 sc, sh, mu, rs; };
 
 // y = sc*x + sh (sc = gamma*rstd);  dy = da * silu'(y);  xhat = (x - mu)*rs
-__device__ __forceinline__ void dy_xhat(const anoddpm_gn_bwd_args &a, const ChanParams &k, f32x4 x, f32x4 g, f32x4 &dy, f32x4 &xh)
+template <bool ACT>
+__device__ __forceinline__ void dy_xhat(const ChanParams &k, f32x4 x, f32x4 g, f32x4 &dy, f32x4 &xh)
 {
     xh = (x - k.mu) * k.rs;
-    if (a.act) {
+    if (ACT) {
         const f32x4 y = x * k.sc + k.sh;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -60,7 +61,14 @@ __device__ __forceinline__ ChanParams chan_params(const anoddpm_gn_bwd_args &a, 
     return k;
 }
 
-// pass 1: grid (nslab, B).  partial[b][slab][c] = { sum_p dy, sum_p dy*xhat } over the slab's pixels
+constexpr int RED_UNROLL = 4;
+
+// pass 1: grid (nslab, B).  partial[b][slab][c] = { sum_p dy, sum_p dy*xhat } over the slab's pixels.
+// The common case -- no resampling between the activation and the conv (A_MODE 0) -- walks its streams with pointer increments
+// (the generic form pays a 64-bit address and an integer division per 16-byte load).  Stashing dy = da * silu'(y) over da for
+// pass 3 was measured and dropped: the passes are HBM-bound (up to five streams in pass 3), not bound by the derivative's
+// v_exp + v_rcp, and the extra 134 MB write per 256^2 layer cost 0.4 ms per step.
+template <int A_MODE, bool ACT>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(anoddpm_gn_bwd_args a)
 {
     __shared__ float lds_s[256 * 4];
@@ -85,13 +93,41 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(anoddpm_gn_bwd_args 
             const bool first = c < a.c0;
             const float *src = first ? a.x0 + (int64_t)b * a.x0_bs + c : a.x1 + (int64_t)b * a.x1_bs + (c - a.c0);
             const int ld = first ? a.x0_ld : a.x1_ld;
-            for (int p = p0 + tr; p < p1; p += R) {
-                const f32x4 x = *reinterpret_cast<const f32x4 *>(src + (int64_t)p * ld);
-                const f32x4 g = load_da(a, da, p / a.Ws, p % a.Ws, c);
-                f32x4 dy, xh;
-                dy_xhat(a, k, x, g, dy, xh);
-                s += dy;
-                q += dy * xh;
+            int p = p0 + tr;
+            if (A_MODE == 0) {
+                const float *xp = src + (int64_t)p * ld;
+                const float *gp = da + (int64_t)p * a.da_ld + c;
+                const int64_t sx = (int64_t)R * ld, sg = (int64_t)R * a.da_ld;
+                for (; p + (RED_UNROLL - 1) * R < p1; p += RED_UNROLL * R, xp += RED_UNROLL * sx, gp += RED_UNROLL * sg) {
+                    f32x4 x[RED_UNROLL], g[RED_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < RED_UNROLL; ++u) {
+                        x[u] = *reinterpret_cast<const f32x4 *>(xp + u * sx);
+                        g[u] = *reinterpret_cast<const f32x4 *>(gp + u * sg);
+                    }
+#pragma unroll
+                    for (int u = 0; u < RED_UNROLL; ++u) {
+                        f32x4 dy, xh;
+                        dy_xhat<ACT>(k, x[u], g[u], dy, xh);
+                        s += dy;
+                        q += dy * xh;
+                    }
+                }
+                for (; p < p1; p += R, xp += sx, gp += sg) {
+                    f32x4 dy, xh;
+                    dy_xhat<ACT>(k, *reinterpret_cast<const f32x4 *>(xp), *reinterpret_cast<const f32x4 *>(gp), dy, xh);
+                    s += dy;
+                    q += dy * xh;
+                }
+            } else {
+                for (; p < p1; p += R) {
+                    const f32x4 x = *reinterpret_cast<const f32x4 *>(src + (int64_t)p * ld);
+                    const f32x4 g = load_da(a, da, p / a.Ws, p % a.Ws, c);
+                    f32x4 dy, xh;
+                    dy_xhat<ACT>(k, x, g, dy, xh);
+                    s += dy;
+                    q += dy * xh;
+                }
             }
         }
         if (tr < R) {
@@ -186,35 +222,88 @@ __global__ __launch_bounds__(256) void gn_bwd_fold_kernel(anoddpm_gn_bwd_args a)
     }
 }
 
-// pass 3: dx = coef0*dy - coef1 - xhat*coef2, written (or added) to the source gradients
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(anoddpm_gn_bwd_args a)
+// pass 3: dx = coef0*dy - coef1 - xhat*coef2, written (or added) to the source gradients.  A workgroup owns a CONTIGUOUS slab of
+// pixels (tools/hbm_patterns.hip: interleaved ownership with many workgroups per CU loses a quarter of the write bandwidth), a
+// thread keeps one channel quad -- its 28 per-channel constants are loaded once, not per 16 bytes of payload -- and walks the
+// slab with pointer increments, APPLY_UNROLL independent 16-byte loads per stream in flight.  grid (slabs, B).
+constexpr int APPLY_UNROLL = 4;
+
+template <int A_MODE, bool ACT>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(anoddpm_gn_bwd_args a, int sp)
 {
     const int C = a.c0 + a.c1, C4 = C >> 2, P = a.Hs * a.Ws;
+    const int TQ = C4 < 256 ? C4 : 256;
+    const int R = 256 / TQ;
+    const int npass = (C4 + TQ - 1) / TQ;
+    const int tid = threadIdx.x;
+    const int tq = tid % TQ, tr = tid / TQ;
+    if (tr >= R) return;
     const int b = blockIdx.y;
+    const int p0 = blockIdx.x * sp, p1 = (p0 + sp < P) ? p0 + sp : P;
     const float *da = a.da + (int64_t)b * a.da_bs;
-    const int64_t total = (int64_t)P * C4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int quad = (int)(i % C4);
-        const int p = (int)(i / C4);
+    for (int pass = 0; pass < npass; ++pass) {
+        const int quad = pass * TQ + tq;
+        if (quad >= C4) break;
         const int c = quad * 4;
         const ChanParams k = chan_params(a, b, c);
         const bool first = c < a.c0;
         const float *src = first ? a.x0 + (int64_t)b * a.x0_bs + c : a.x1 + (int64_t)b * a.x1_bs + (c - a.c0);
         const int ld = first ? a.x0_ld : a.x1_ld;
-        const f32x4 x = *reinterpret_cast<const f32x4 *>(src + (int64_t)p * ld);
-        const f32x4 g = load_da(a, da, p / a.Ws, p % a.Ws, c);
-        f32x4 dy, xh;
-        dy_xhat(a, k, x, g, dy, xh);
+        float *dst0 = first ? a.dx0 + (int64_t)b * a.dx0_bs + c : a.dx1 + (int64_t)b * a.dx1_bs + (c - a.c0);
+        const int dld = first ? a.dx0_ld : a.dx1_ld;
+        const float *res = a.dres ? a.dres + (int64_t)b * a.dres_bs + c : nullptr;
+        const bool acc = (a.acc_dx & (first ? 1 : 2)) != 0;
         const float *kc = a.coef + ((int64_t)b * C + c) * 4;
-        f32x4 dx;
+        f32x4 k0, k1, k2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dx[e] = kc[e * 4 + 0] * dy[e] - kc[e * 4 + 1] - xh[e] * kc[e * 4 + 2];
-        float *dst = first ? a.dx0 + (int64_t)b * a.dx0_bs + (int64_t)p * a.dx0_ld + c
-                           : a.dx1 + (int64_t)b * a.dx1_bs + (int64_t)p * a.dx1_ld + (c - a.c0);
-        if (a.dres) dx += *reinterpret_cast<const f32x4 *>(a.dres + (int64_t)b * a.dres_bs + (int64_t)p * a.dres_ld + c);
-        if (a.acc_dx & (first ? 1 : 2)) dx += *reinterpret_cast<const f32x4 *>(dst);
-        *reinterpret_cast<f32x4 *>(dst) = dx;
+        for (int e = 0; e < 4; ++e) { k0[e] = kc[e * 4 + 0]; k1[e] = kc[e * 4 + 1]; k2[e] = kc[e * 4 + 2]; }
+        int p = p0 + tr;
+        const float *xp = src + (int64_t)p * ld;
+        const float *gp = da + (int64_t)p * a.da_ld + c;                 // A_MODE 0 only
+        const float *rp = res ? res + (int64_t)p * a.dres_ld : nullptr;
+        float *op = dst0 + (int64_t)p * dld;
+        const int64_t sx = (int64_t)R * ld, sg = (int64_t)R * a.da_ld, sr = (int64_t)R * a.dres_ld, so = (int64_t)R * dld;
+        for (; p + (APPLY_UNROLL - 1) * R < p1; p += APPLY_UNROLL * R) {
+            f32x4 x[APPLY_UNROLL], g[APPLY_UNROLL], r[APPLY_UNROLL], o[APPLY_UNROLL];
+#pragma unroll
+            for (int u = 0; u < APPLY_UNROLL; ++u) {
+                x[u] = *reinterpret_cast<const f32x4 *>(xp + u * sx);
+                if (A_MODE == 0) g[u] = *reinterpret_cast<const f32x4 *>(gp + u * sg);
+                else { const int pp = p + u * R; g[u] = load_da(a, da, pp / a.Ws, pp % a.Ws, c); }
+                if (res) r[u] = *reinterpret_cast<const f32x4 *>(rp + u * sr);
+                if (acc) o[u] = *reinterpret_cast<const f32x4 *>(op + u * so);
+            }
+#pragma unroll
+            for (int u = 0; u < APPLY_UNROLL; ++u) {
+                f32x4 dy, xh;
+                dy_xhat<ACT>(k, x[u], g[u], dy, xh);
+                f32x4 dx = k0 * dy - k1 - xh * k2;
+                if (res) dx += r[u];
+                if (acc) dx += o[u];
+                *reinterpret_cast<f32x4 *>(op + u * so) = dx;
+            }
+            xp += APPLY_UNROLL * sx; gp += APPLY_UNROLL * sg; op += APPLY_UNROLL * so;
+            if (res) rp += APPLY_UNROLL * sr;
+        }
+        for (; p < p1; p += R, xp += sx, gp += sg, op += so) {
+            const f32x4 x = *reinterpret_cast<const f32x4 *>(xp);
+            const f32x4 g = A_MODE == 0 ? *reinterpret_cast<const f32x4 *>(gp) : load_da(a, da, p / a.Ws, p % a.Ws, c);
+            f32x4 dy, xh;
+            dy_xhat<ACT>(k, x, g, dy, xh);
+            f32x4 dx = k0 * dy - k1 - xh * k2;
+            if (res) { dx += *reinterpret_cast<const f32x4 *>(rp); rp += sr; }
+            if (acc) dx += *reinterpret_cast<const f32x4 *>(op);
+            *reinterpret_cast<f32x4 *>(op) = dx;
+        }
     }
+}
+
+template <int A_MODE, bool ACT>
+void launch_reduce_apply(const anoddpm_gn_bwd_args *a, hipStream_t s, int slabs, int sp)
+{
+    hipLaunchKernelGGL((gn_bwd_reduce_kernel<A_MODE, ACT>), dim3(a->nslab, a->B), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(a->groups), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL((gn_bwd_apply_kernel<A_MODE, ACT>), dim3((unsigned)slabs, a->B), dim3(256), 0, s, *a, sp);
 }
 
 }  // namespace
@@ -233,10 +322,15 @@ extern "C" int anoddpm_gn_silu_backward(const anoddpm_gn_bwd_args *a, void *stre
     ANODDPM_REQUIRE(a->x0_ld % 4 == 0 && a->da_ld % 4 == 0 && a->dx0_ld % 4 == 0 && (a->c1 == 0 || (a->x1_ld % 4 == 0 && a->dx1_ld % 4 == 0)),
                     "gn_silu_backward: pixel strides must be multiples of 4 floats");
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(a->nslab, a->B), dim3(256), 0, s, *a);
-    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(a->groups), dim3(256), 0, s, *a);
-    const int64_t work = (int64_t)a->Hs * a->Ws * (C / 4);
-    const int64_t blocks = (work + 255) / 256;
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks), a->B), dim3(256), 0, s, *a);
+    // apply: contiguous pixel slabs, ~8 workgroups per CU over the batch, at least one unrolled trip per thread
+    const int P = a->Hs * a->Ws, C4 = C / 4;
+    const int R = C4 < 256 ? 256 / C4 : 1;
+    int sp = (int)(((int64_t)P * a->B + 2047) / 2048);
+    const int min_sp = R * APPLY_UNROLL;
+    sp = ((sp + min_sp - 1) / min_sp) * min_sp;
+    const int slabs = (P + sp - 1) / sp;
+    if (a->a_mode == 0) { if (a->act) launch_reduce_apply<0, true>(a, s, slabs, sp); else launch_reduce_apply<0, false>(a, s, slabs, sp); }
+    else if (a->a_mode == 1) { if (a->act) launch_reduce_apply<1, true>(a, s, slabs, sp); else launch_reduce_apply<1, false>(a, s, slabs, sp); }
+    else { if (a->act) launch_reduce_apply<2, true>(a, s, slabs, sp); else launch_reduce_apply<2, false>(a, s, slabs, sp); }
     return check_launch("gn_silu_backward");
 }

@@ -171,6 +171,46 @@ __global__ __launch_bounds__(256) void wgrad1_fold_kernel(const anoddpm_wgrad1_a
     }
 }
 
+// The same fold for layers with many work items (the 1x1 skip convolutions on the large maps: 256 items of a 128 KB slab) and
+// N % 32 == 0: workgroup = 8 item lanes x 32 output channels of ONE input channel, so the launch has 8x the threads -- and
+// loads in flight -- of the one-thread-per-weight kernel, which is parallelism-bound there (128 workgroups x 16 loads per thread
+// = 2 MB in flight: 0.5 TB/s).  Order of the sum per weight: each item lane in item order, then the lanes in order -- fixed.
+__global__ __launch_bounds__(256) void wgrad1_fold_lanes_kernel(const anoddpm_wgrad1_args a, const int nitems)
+{
+    __shared__ float part[8][32];
+    const int K = a.c0 + a.c1, N = a.N;
+    const int tiles_n = N >> 5;
+    const int ci = blockIdx.x / tiles_n, co0 = (blockIdx.x % tiles_n) * 32;
+    const int il = threadIdx.x >> 5, ol = threadIdx.x & 31;
+    const int64_t item = (int64_t)K * N;
+    const float *p = a.ws + (int64_t)ci * N + co0 + ol;
+    float s = 0.f;
+    int it = il;
+    for (; it + 8 * 15 < nitems; it += 8 * 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(p + (int64_t)(it + 8 * u) * item);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; it < nitems; it += 8) s += p[(int64_t)it * item];
+    part[il][ol] = s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) t += part[l][threadIdx.x];
+        float *dst = a.dw + (int64_t)(co0 + threadIdx.x) * K + ci;
+        *dst = a.accumulate ? *dst + t : t;
+        if (a.dbias && ci == 0) {
+            float b = 0.f;
+            const float *cs = a.ws + (int64_t)nitems * K * N;
+            for (int k = 0; k < nitems; ++k) b += cs[(int64_t)k * N + co0 + threadIdx.x];
+            a.dbias[co0 + threadIdx.x] += b;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight packing
 __global__ __launch_bounds__(256) void pack_pointwise_kernel(const anoddpm_pack_args a)
 {
@@ -609,7 +649,10 @@ extern "C" int anoddpm_wgrad_pointwise(const anoddpm_wgrad1_args *a, void *strea
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(wgrad1_kernel, dim3(tiles, (unsigned)nitems), dim3(256), 0, s, *a, nspan);
     const int64_t kn = (int64_t)K * a->N;
-    hipLaunchKernelGGL(wgrad1_fold_kernel, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, s, *a, (int)nitems);
+    if (nitems >= 32 && a->N % 32 == 0 && g_debug[8] != 1)             // ANODDPM_DEBUG8=1: the one-thread-per-weight kernel everywhere
+        hipLaunchKernelGGL(wgrad1_fold_lanes_kernel, dim3((unsigned)(kn / 32)), dim3(256), 0, s, *a, (int)nitems);
+    else
+        hipLaunchKernelGGL(wgrad1_fold_kernel, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, s, *a, (int)nitems);
     return check_launch("wgrad_pointwise");
 }
 

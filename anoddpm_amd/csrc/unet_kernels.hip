@@ -402,59 +402,95 @@ __global__ void posemb_kernel(anoddpm_posemb_args a)
 // Cin > 2 keeps the generic per-pixel form (the reference's MRI models have Cin = 1).
 constexpr int STEM_STRIP = 8;
 
-template <int CIN>
-__global__ __launch_bounds__(256) void conv_stem_strip_kernel(anoddpm_stem_args a)
+// A workgroup owns `iters` x (256 / (Cout/4)) consecutive strips = one contiguous range of the NHWC output (32 KB per trip at
+// Cout = 128).  With a.stats the kernel also emits the GroupNorm partial sums of its range --
+// one row {sum, sum of squares} per channel, the format of the contraction kernels' epilogues -- so that the stem output is not
+// read back by a statistics pass (134 MB at 256^2 x 128 x batch 4).
+template <int CIN, bool LOOP>
+__global__ __launch_bounds__(256) void conv_stem_strip_kernel(anoddpm_stem_args a, int iters_arg)
 {
+    __shared__ float lds_s[256 * 4];
+    __shared__ float lds_q[256 * 4];
     const int QP = a.Cout >> 2;
-    const int spb = 256 / QP;                        // strips per block
+    const int spb = 256 / QP;                        // strips per block and trip
     const int q = threadIdx.x % QP;
     const int sl = threadIdx.x / QP;
-    if (sl >= spb) return;
+    const bool lane_on = sl < spb;
+    const int iters = LOOP ? iters_arg : 1;                        // one trip: no loop-carried addressing state (registers)
     const int strips_x = a.W / STEM_STRIP;
     const int64_t nstrips = (int64_t)a.B * a.H * strips_x;
-    const int64_t strip = (int64_t)blockIdx.x * spb + sl;
-    if (strip >= nstrips) return;
-    const int sx = (int)(strip % strips_x);
-    const int y = (int)((strip / strips_x) % a.H);
-    const int b = (int)(strip / ((int64_t)strips_x * a.H));
-    const int x0 = sx * STEM_STRIP;
+    const int64_t strip0 = (int64_t)blockIdx.x * spb * iters;
     const float4 *w = reinterpret_cast<const float4 *>(a.w);
     float4 wr[9 * CIN];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) wr[t * CIN + ci] = w[(t * CIN + ci) * QP + q];
-    const float4 bias = a.bias ? reinterpret_cast<const float4 *>(a.bias)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float in[CIN][3][STEM_STRIP + 2];
+        for (int ci = 0; ci < CIN; ++ci) wr[t * CIN + ci] = w[(t * CIN + ci) * QP + (lane_on ? q : 0)];
+    const float4 bias = a.bias ? reinterpret_cast<const float4 *>(a.bias)[lane_on ? q : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int it = 0; it < iters; ++it) {
+        const int64_t strip = strip0 + (int64_t)it * spb + sl;
+        if (!lane_on || strip >= nstrips) continue;
+        const int sx = (int)(strip % strips_x);
+        const int y = (int)((strip / strips_x) % a.H);
+        const int b = (int)(strip / ((int64_t)strips_x * a.H));
+        const int x0 = sx * STEM_STRIP;
+        // the three input rows of the strip: every load is unconditional (clamped row / column, zeroed afterwards) -- two
+        // 16-byte loads for the strip's own eight columns (W % 8 == 0: aligned, always inside) and one scalar per edge
+        float in[CIN][3][STEM_STRIP + 2];
+        const bool has_l = x0 > 0, has_r = x0 + STEM_STRIP < a.W;
 #pragma unroll
-    for (int ci = 0; ci < CIN; ++ci) {
-        const float *plane = a.x + ((int64_t)b * CIN + ci) * a.H * a.W;
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float *plane = a.x + ((int64_t)b * CIN + ci) * a.H * a.W;
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int yy = y + dy - 1;
-#pragma unroll
-            for (int i = 0; i < STEM_STRIP + 2; ++i) {
-                const int xx = x0 + i - 1;
-                in[ci][dy][i] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? plane[(int64_t)yy * a.W + xx] : 0.f;
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = y + dy - 1;
+                const bool yin = yy >= 0 && yy < a.H;
+                const float *row = plane + (int64_t)(yin ? yy : y) * a.W + x0;
+                const float4 m0 = *reinterpret_cast<const float4 *>(row), m1 = *reinterpret_cast<const float4 *>(row + 4);
+                const float l = row[has_l ? -1 : 0], r = row[has_r ? STEM_STRIP : STEM_STRIP - 1];
+                in[ci][dy][0] = (yin && has_l) ? l : 0.f;
+                in[ci][dy][1] = yin ? m0.x : 0.f; in[ci][dy][2] = yin ? m0.y : 0.f;
+                in[ci][dy][3] = yin ? m0.z : 0.f; in[ci][dy][4] = yin ? m0.w : 0.f;
+                in[ci][dy][5] = yin ? m1.x : 0.f; in[ci][dy][6] = yin ? m1.y : 0.f;
+                in[ci][dy][7] = yin ? m1.z : 0.f; in[ci][dy][8] = yin ? m1.w : 0.f;
+                in[ci][dy][9] = (yin && has_r) ? r : 0.f;
             }
         }
+        float4 *out = reinterpret_cast<float4 *>(a.out) + (((int64_t)b * a.H + y) * a.W + x0) * QP + q;
+#pragma unroll
+        for (int i = 0; i < STEM_STRIP; ++i) {
+            float4 acc = bias;
+            // same accumulation order as the per-pixel kernel: ci outermost, then dy, dx
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float v = in[ci][dy][i + dx];
+                        const float4 wv = wr[(dy * 3 + dx) * CIN + ci];
+                        acc.x += v * wv.x; acc.y += v * wv.y; acc.z += v * wv.z; acc.w += v * wv.w;
+                    }
+            out[(int64_t)i * QP] = acc;
+            ssum.x += acc.x; ssum.y += acc.y; ssum.z += acc.z; ssum.w += acc.w;
+            ssq.x += acc.x * acc.x; ssq.y += acc.y * acc.y; ssq.z += acc.z * acc.z; ssq.w += acc.w * acc.w;
+        }
     }
-    float4 *out = reinterpret_cast<float4 *>(a.out) + (((int64_t)b * a.H + y) * a.W + x0) * QP + q;
-#pragma unroll
-    for (int i = 0; i < STEM_STRIP; ++i) {
-        float4 acc = bias;
-        // same accumulation order as the per-pixel kernel: ci outermost, then dy, dx
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float v = in[ci][dy][i + dx];
-                    const float4 wv = wr[(dy * 3 + dx) * CIN + ci];
-                    acc.x += v * wv.x; acc.y += v * wv.y; acc.z += v * wv.z; acc.w += v * wv.w;
-                }
-        out[(int64_t)i * QP] = acc;
+    if (!a.stats) return;
+    // fold the strips of the workgroup per channel (fixed order) and write this range's row
+    if (lane_on) {
+        const int o = (sl * QP + q) * 4;
+        lds_s[o] = ssum.x; lds_s[o + 1] = ssum.y; lds_s[o + 2] = ssum.z; lds_s[o + 3] = ssum.w;
+        lds_q[o] = ssq.x; lds_q[o + 1] = ssq.y; lds_q[o + 2] = ssq.z; lds_q[o + 3] = ssq.w;
+    }
+    __syncthreads();
+    float *row = a.stats + (int64_t)blockIdx.x * a.Cout * 2;        // rows are numbered like the workgroups: [B][stats_rows]
+    for (int c = threadIdx.x; c < a.Cout; c += 256) {
+        float s = 0.f, qq = 0.f;
+        for (int r = 0; r < spb; ++r) { s += lds_s[r * QP * 4 + c]; qq += lds_q[r * QP * 4 + c]; }
+        row[c * 2] = s;
+        row[c * 2 + 1] = qq;
     }
 }
 
@@ -773,6 +809,22 @@ extern "C" int anoddpm_posemb(const anoddpm_posemb_args *a, void *stream)
     return anoddpm::check_launch("posemb");
 }
 
+// rows per image of the fused stem statistics: one per workgroup range.  One trip per workgroup up to 1024 rows (256^2 x 128: 4096
+// workgroups of 32 KB -- measured 27 us against 38 us with four trips per workgroup: the trips of a workgroup serialise on their
+// input loads and halve the waves in flight); beyond that (512^2) the trips double until the finalize kernel's row walk fits
+extern "C" int anoddpm_stem_stats_rows(int H, int W, int Cin, int Cout)
+{
+    if (Cin < 1 || Cin > 2 || W <= 0 || H <= 0 || W % STEM_STRIP || Cout <= 0 || Cout % 4 || Cout / 4 > 256) return 0;
+    const int ppb = 256 / (Cout / 4);
+    const int64_t per_image = (int64_t)H * W / STEM_STRIP;
+    if (per_image % ppb) return 0;
+    const int64_t trips = per_image / ppb;
+    int64_t iters = 1;
+    while (trips / iters > 1024) iters *= 2;
+    while (iters > 1 && trips % iters) iters /= 2;
+    return (int)(trips / iters);
+}
+
 extern "C" int anoddpm_conv_stem(const anoddpm_stem_args *a, void *stream)
 {
     ANODDPM_REQUIRE(a && a->x && a->w && a->out, "conv_stem: null pointer");
@@ -780,13 +832,26 @@ extern "C" int anoddpm_conv_stem(const anoddpm_stem_args *a, void *stream)
     const int ppb = 256 / (a->Cout / 4);
     const int64_t npix = (int64_t)a->B * a->H * a->W;
     if (npix == 0) return ANODDPM_OK;
-    if (a->Cin <= 2 && a->W % STEM_STRIP == 0) {
+    if (a->Cin <= 2 && a->W % STEM_STRIP == 0 && (uintptr_t)a->x % 16 == 0) {     // the strip kernel reads its rows with 16-byte loads
         const int64_t nstrips = npix / STEM_STRIP;
-        const dim3 grid((unsigned)((nstrips + ppb - 1) / ppb));
-        if (a->Cin == 1) hipLaunchKernelGGL(conv_stem_strip_kernel<1>, grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
-        else             hipLaunchKernelGGL(conv_stem_strip_kernel<2>, grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
+        const int64_t per_image = nstrips / a->B;
+        int iters;
+        if (a->stats) {
+            // one statistics row per workgroup, stats_rows workgroups per image: the range of a workgroup must not straddle images
+            ANODDPM_REQUIRE(a->stats_rows > 0 && per_image % ((int64_t)a->stats_rows * ppb) == 0, "conv_stem: stats_rows must divide the strips of an image into whole workgroup trips");
+            iters = (int)(per_image / ((int64_t)a->stats_rows * ppb));
+        } else {
+            iters = 1;
+        }
+        const dim3 grid((unsigned)((nstrips + (int64_t)ppb * iters - 1) / ((int64_t)ppb * iters)));
+        hipStream_t st = anoddpm::as_stream(stream);
+        if (a->Cin == 1 && iters == 1) hipLaunchKernelGGL((conv_stem_strip_kernel<1, false>), grid, dim3(256), 0, st, *a, 1);
+        else if (a->Cin == 1)          hipLaunchKernelGGL((conv_stem_strip_kernel<1, true>), grid, dim3(256), 0, st, *a, iters);
+        else if (iters == 1)           hipLaunchKernelGGL((conv_stem_strip_kernel<2, false>), grid, dim3(256), 0, st, *a, 1);
+        else                           hipLaunchKernelGGL((conv_stem_strip_kernel<2, true>), grid, dim3(256), 0, st, *a, iters);
         return anoddpm::check_launch("conv_stem");
     }
+    ANODDPM_REQUIRE(!a->stats, "conv_stem: fused statistics need Cin <= 2, W %% 8 == 0 and a 16-byte aligned input (use anoddpm_chan_stats)");
     hipLaunchKernelGGL(conv_stem_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0, anoddpm::as_stream(stream), *a);
     return anoddpm::check_launch("conv_stem");
 }

@@ -233,6 +233,50 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const anoddpm_wgrad_arg
     o[0] = s0; o[1] = s1; o[2] = s2;
 }
 
+// The same fold for K % 8 == 0, N % 32 == 0 (every convolution of the shipped models) with the transposition to OIHW done in LDS:
+// thread = (ci, co) of an 8 x 32 tile, all nine taps, every load of its items in flight (lanes run along co: 128-byte rows);
+// the tile's results leave as 32 runs of 72 contiguous floats (co, ci0..ci0+7, 9 taps).  The row kernel above writes -- and
+// with `accumulate` re-reads -- 12 bytes per lane at a stride of 36*K bytes: every 128-byte line of dW is touched by a dozen
+// waves on different XCDs, and on the 512-channel layers that costs more than reading the 75 MB of partial slabs.
+// Sums run in item order per (ci, co, tap) exactly like the row kernel (bit-identical results).
+__global__ __launch_bounds__(256) void wgrad_fold_tile_kernel(const anoddpm_wgrad_args a, const int nitems)
+{
+    __shared__ float tile[32][8 * 9 + 1];
+    const int K = a.c0 + a.c1, N = a.N;
+    const int tiles_n = N >> 5;
+    const int ci0 = (blockIdx.x / tiles_n) * 8, co0 = (blockIdx.x % tiles_n) * 32;
+    const int cl = threadIdx.x >> 5, ol = threadIdx.x & 31;
+    const int64_t plane = (int64_t)K * N, item = 9 * plane;
+    const float *p = a.ws + (int64_t)(ci0 + cl) * N + co0 + ol;
+    float s[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] = 0.f;
+    int it = 0;
+    for (; it + 4 <= nitems; it += 4) {
+        float v[4][9];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[u][t] = __builtin_nontemporal_load(p + (int64_t)(it + u) * item + t * plane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) s[t] += v[u][t];
+    }
+    for (; it < nitems; ++it)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s[t] += p[(int64_t)it * item + t * plane];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tile[ol][cl * 9 + t] = s[t];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 72; i += 256) {
+        const int o = i / 72, r = i - o * 72;
+        float *dst = a.dw + ((int64_t)(co0 + o) * K + ci0) * 9 + r;
+        const float v = tile[o][r];
+        *dst = a.accumulate ? *dst + v : v;
+    }
+}
+
 // Weight packing for the 3x3 kernels on the device (training re-packs after every optimizer step): OIHW ->
 //   mode 0: direct layout  [9 taps][I/4][O][4]                    (unet.py:_pack_conv)
 //   mode 1: Winograd       [16 xi = 4u+v][I/4][O][4], U = G g G^T  (unet.py:_pack_wino; fp64 like the host version)
@@ -272,7 +316,10 @@ extern "C" int anoddpm_conv3x3_wgrad(const anoddpm_wgrad_args *a, void *stream)
     else if (TW == 4)  hipLaunchKernelGGL(wgrad_kernel<4>, dim3(tiles, (unsigned)nitems), dim3(256), 0, s, *a, nseg, nband);
     else               hipLaunchKernelGGL(wgrad_kernel<2>, dim3(tiles, (unsigned)nitems), dim3(256), 0, s, *a, nseg, nband);
     const int64_t kn = (int64_t)K * a->N;
-    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((kn + 255) / 256), 3), dim3(256), 0, s, *a, (int)nitems);
+    if (K % 8 == 0 && a->N % 32 == 0 && g_debug[8] != 1)              // ANODDPM_DEBUG8=1: the row kernel everywhere
+        hipLaunchKernelGGL(wgrad_fold_tile_kernel, dim3((unsigned)(kn / 256)), dim3(256), 0, s, *a, (int)nitems);
+    else
+        hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((kn + 255) / 256), 3), dim3(256), 0, s, *a, (int)nitems);
     return check_launch("conv3x3_wgrad");
 }
 

@@ -336,6 +336,55 @@ __global__ __launch_bounds__(256) void wgrad43_out_kernel(const anoddpm_wgrad_ar
         }
 }
 
+// Both steps in one launch: workgroup = one input channel k x 32 output channels x the six rows u of the 6x6 position grid
+// (192 threads).  A thread folds its six positions (u, 0..5) over the PG slabs (slab order, 16 loads in flight, lanes along n),
+// applies the column transform, the rows meet in LDS and 32 x 9 threads apply the row transform and write dw[n][k][3][3].
+// Same order of every sum as wgrad43_sum_kernel + wgrad43_out_kernel (bit-identical), one launch and one pass over the slabs
+// instead of two launches and a round trip of the folded slab.
+__global__ __launch_bounds__(192) void wgrad43_fold_kernel(const anoddpm_wgrad_args a, const int PG)
+{
+    __shared__ float rr[6][3][32];
+    const int K = a.c0 + a.c1, N = a.N;
+    const int tiles_n = N >> 5;
+    const int k = blockIdx.x / tiles_n, n0 = (blockIdx.x % tiles_n) * 32;
+    const int u = threadIdx.x >> 5, nl = threadIdx.x & 31;
+    const int64_t plane = (int64_t)K * N, slab = 36 * plane;
+    const float G[6][3] = {{1.f / 4, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    float d[6];
+#pragma unroll
+    for (int v = 0; v < 6; ++v) {
+        const float *p = a.ws + ((int64_t)(u * 6 + v) * K + k) * N + n0 + nl;
+        float s = 0.f;
+        int g = 0;
+        for (; g + 16 <= PG; g += 16) {
+            float x[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = __builtin_nontemporal_load(p + (int64_t)(g + i) * slab);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += x[i];
+        }
+        for (; g < PG; ++g) s += p[(int64_t)g * slab];
+        d[v] = s;
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < 6; ++v) s += d[v] * G[v][b];
+        rr[u][b][nl] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 9; i += 192) {
+        const int n = i / 9, ab = i - n * 9, aa = ab / 3, b = ab - aa * 3;
+        float s = 0.f;
+#pragma unroll
+        for (int uu = 0; uu < 6; ++uu) s += G[uu][aa] * rr[uu][b][n];
+        float *o = a.dw + ((int64_t)(n0 + n) * K + k) * 9 + ab;
+        *o = a.accumulate ? *o + s : s;
+    }
+}
+
 }  // namespace
 
 namespace anoddpm {
@@ -368,6 +417,10 @@ int launch_wgrad43(const anoddpm_wgrad_args *a, hipStream_t s)
     ANODDPM_REQUIRE(a->ws_floats >= (int64_t)pg * slab, "wgrad (Winograd): workspace too small");
     const dim3 grid((unsigned)pg, (unsigned)((K / G4_KB) * (a->N / G4_NB)));
     hipLaunchKernelGGL(wgrad43_kernel, grid, dim3(G4_NT), 0, s, *a, pg, a->W / 16, a->H / 8, 1.0f / (float)(a->W / 16));
+    if (g_debug[8] != 1) {                                           // ANODDPM_DEBUG8=1: the two-launch fold
+        hipLaunchKernelGGL(wgrad43_fold_kernel, dim3((unsigned)((int64_t)K * (a->N / 32))), dim3(192), 0, s, *a, pg);
+        return check_launch("conv3x3_wgrad (Winograd)");
+    }
     if (pg > 1) hipLaunchKernelGGL(wgrad43_sum_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, a->ws, slab, pg);
     hipLaunchKernelGGL(wgrad43_out_kernel, dim3((unsigned)(((int64_t)K * a->N + 255) / 256)), dim3(256), 0, s, *a);
     return check_launch("conv3x3_wgrad (Winograd)");

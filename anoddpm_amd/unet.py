@@ -878,6 +878,12 @@ class _Plan:
                     self.stem.bias = self.packed(prefix + ".bias", "copy").data_ptr()
                     self.stem.out = h0.data_ptr()
                     self.stem.B, self.stem.H, self.stem.W, self.stem.Cin, self.stem.Cout = B, S, S, cin, cout
+                    rows = lib().anoddpm_stem_stats_rows(S, S, cin, cout)
+                    if rows > 0 and os.environ.get("ANODDPM_NO_STEM_STATS", "0") != "1":
+                        # GroupNorm partial sums of the stem output from the stem kernel itself (no chan_stats pass over it)
+                        sstats = self.buf(B, rows, cout, 2)
+                        self.stem.stats, self.stem.stats_rows = sstats.data_ptr(), rows
+                        self.stats_of[h0.data_ptr()] = ("rows", sstats, rows)
                     self.add(_lib.OP_STEM, self.stem)
                     self.flops["conv3"] += 2.0 * cin * cout * 9 * S * S * B
                     srcs = [(h0, cout)]

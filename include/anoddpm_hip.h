@@ -356,7 +356,15 @@ typedef struct {
     const float *bias;
     float *out;                     /* [B][H][W][Cout] */
     int32_t B, H, W, Cin, Cout;
+    /* optional (Cin <= 2, W % 8 == 0, x 16-byte aligned): GroupNorm partial sums of the output, [B][stats_rows][Cout][2] floats
+     * {sum, sum of squares}, one row per workgroup range -- the row format of anoddpm_chan_stats / the contraction epilogues.
+     * stats_rows must be anoddpm_stem_stats_rows() of the shape. */
+    float *stats;
+    int32_t stats_rows;
 } anoddpm_stem_args;
+
+/* rows per image the fused stem statistics use for this shape, 0 when the shape has no fused form */
+int anoddpm_stem_stats_rows(int H, int W, int Cin, int Cout);
 
 int anoddpm_conv_stem(const anoddpm_stem_args *a, void *stream);
 

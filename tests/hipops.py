@@ -258,7 +258,8 @@ def posemb(t, freqs, dim):
     return out
 
 
-def stem(x, w, b):
+def stem(x, w, b, with_stats=False):
+    """-> NHWC output [, fused GroupNorm partial sums [B][rows][Cout][2] (None when the shape has no fused form)]"""
     B, Cin, H, W = x.shape
     Cout = w.shape[0]
     wp = w.permute(2, 3, 1, 0).reshape(-1, Cout).contiguous()
@@ -266,9 +267,15 @@ def stem(x, w, b):
     st = StemArgs()
     st.x, st.w, st.bias, st.out = x.data_ptr(), wp.data_ptr(), b.data_ptr(), out.data_ptr()
     st.B, st.H, st.W, st.Cin, st.Cout = B, H, W, Cin, Cout
+    stats = None
+    if with_stats:
+        rows = lib().anoddpm_stem_stats_rows(H, W, Cin, Cout)
+        if rows > 0:
+            stats = torch.full((B, rows, Cout, 2), float("nan"), device=x.device)
+            st.stats, st.stats_rows = stats.data_ptr(), rows
     check(lib().anoddpm_conv_stem(ctypes.byref(st), current_stream()), "stem")
     torch.cuda.synchronize()
-    return out
+    return (out, stats) if with_stats else out
 
 
 def head(x, w, b, scale, shift):
@@ -329,6 +336,7 @@ def gn_silu_backward(srcs, da, gamma, beta, mean, rstd, *, act=1, a_mode=0, acc_
     Returns (dx list, dgamma, dbeta)."""
     from anoddpm_amd._lib import GnBwdArgs
     dev = srcs[0].device
+    da = da.clone()                 # the kernel may use da as scratch (act != 0, a_mode == 0): keep the caller's tensor intact
     B, Hs, Ws, c0 = srcs[0].shape
     c1 = srcs[1].shape[3] if len(srcs) > 1 else 0
     C, P = c0 + c1, Hs * Ws

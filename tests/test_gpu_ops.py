@@ -250,6 +250,27 @@ def test_stem(case):
     assert relerr(hipops.nchw(got), ref) < TOL
 
 
+@pytest.mark.parametrize("case", [(2, 1, 32, 64), (4, 1, 256, 128), (1, 2, 64, 32), (1, 1, 512, 128), (1, 1, 16, 1024), (1, 3, 64, 128)])
+def test_stem_fused_groupnorm_sums(case):
+    """The stem kernel's own GroupNorm partial sums (one row per workgroup range, the contraction epilogues' row format):
+    rows sum to the per-channel sum / sum of squares of the output it wrote; shapes without a fused form report 0 rows."""
+    import hipops
+    from anoddpm_amd._lib import lib
+    B, Cin, H, Cout = case
+    x, w, b = rnd(B, Cin, H, H, seed=54), rnd(Cout, Cin, 3, 3, seed=55, scale=0.3), rnd(Cout, seed=56)
+    got, stats = hipops.stem(x.to(dev()), w.to(dev()), b.to(dev()), with_stats=True)
+    ref = F.conv2d(x, w, b, padding=1)
+    assert relerr(hipops.nchw(got), ref) < TOL
+    rows = lib().anoddpm_stem_stats_rows(H, H, Cin, Cout)
+    if Cin > 2:
+        assert rows == 0 and stats is None
+        return
+    assert 0 < rows <= 1024 and stats.shape == (B, rows, Cout, 2) and torch.isfinite(stats).all()
+    o = got.double().reshape(B, rows, -1, Cout)                     # a row = one contiguous pixel range of one image
+    assert (stats[..., 0].double() - o.sum(2)).abs().max() <= 1e-5 * o.abs().sum(2).max()
+    assert (stats[..., 1].double() - (o * o).sum(2)).abs().max() <= 1e-5 * (o * o).sum(2).max()
+
+
 @pytest.mark.parametrize("case", [(2, 128, 32, 1), (1, 64, 64, 3), (1, 32, 8, 2), (1, 128, 256, 1)])
 def test_head_conv(case):
     import hipops
