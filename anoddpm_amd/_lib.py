@@ -259,7 +259,7 @@ SYMBOLS = [
     "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map", "anoddpm_vlb_terms", "anoddpm_conv3x3_wgrad", "anoddpm_gn_silu_backward", "anoddpm_pack_conv3x3",
     "anoddpm_wgrad_pointwise", "anoddpm_pack_weights", "anoddpm_softmax_rows_backward", "anoddpm_transpose_square",
     "anoddpm_linear_small_backward", "anoddpm_conv_stem_backward", "anoddpm_conv_head_backward", "anoddpm_colsum_fold",
-    "anoddpm_volume_normalise", "anoddpm_mri_slice_prepare", "anoddpm_resize_bilinear_pil", "anoddpm_attention", "anoddpm_wgrad43_groups", "anoddpm_pack_batch", "anoddpm_pack_job_blocks", "anoddpm_linear_small_backward_batch",
+    "anoddpm_volume_normalise", "anoddpm_mri_slice_prepare", "anoddpm_resize_bilinear_pil", "anoddpm_attention", "anoddpm_wgrad43_groups", "anoddpm_wgrad43_patches", "anoddpm_pack_batch", "anoddpm_pack_job_blocks", "anoddpm_linear_small_backward_batch",
     "anoddpm_loss_forward", "anoddpm_loss_backward", "anoddpm_dropout",
 ]
 
@@ -344,6 +344,7 @@ def lib():
     L.anoddpm_loss_backward.argtypes = [POINTER(LossArgs), c_void_p]
     L.anoddpm_conv3x3_wgrad.argtypes = [POINTER(WgradArgs), c_void_p]
     L.anoddpm_wgrad43_groups.argtypes = [c_int32] * 5
+    L.anoddpm_wgrad43_patches.argtypes = [c_int32] * 2
     L.anoddpm_gn_silu_backward.argtypes = [POINTER(GnBwdArgs), c_void_p]
     L.anoddpm_pack_conv3x3.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]
     L.anoddpm_wgrad_pointwise.argtypes = [POINTER(Wgrad1Args), c_void_p]

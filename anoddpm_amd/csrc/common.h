@@ -34,6 +34,7 @@ int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s); // winograd4
 int launch_pointwise_stream(const anoddpm_igemm_args *a, hipStream_t s); // pointwise.hip (cfg == 4)
 int launch_wgrad43(const anoddpm_wgrad_args *a, hipStream_t s);      // wgrad43.hip (algo == 1 of anoddpm_conv3x3_wgrad)
 int wgrad43_groups(int K, int N, int B, int H, int W);
+int wgrad43_patches(int H, int W);                               // column-sum items per image of algo 1
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 

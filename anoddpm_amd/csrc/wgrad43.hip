@@ -391,10 +391,13 @@ namespace anoddpm {
 
 // Patch groups of the Winograd-domain weight gradient: one workgroup per CU in total (shared with the host side through
 // anoddpm_wgrad43_groups so that the caller can size the workspace: PG * 36 * K * N floats).
+// column-sum items per image = the kernel's 16 x 8 output patches (exported so that callers do not hard-code the patch shape)
+int wgrad43_patches(int H, int W) { return (H / 8) * (W / 16); }
+
 int wgrad43_groups(int K, int N, int B, int H, int W)
 {
     const int blocks = (K / G4_KB) * (N / G4_NB);
-    const int patches = B * (H / 8) * (W / 16);
+    const int patches = B * wgrad43_patches(H, W);
     int pg = 256 / (blocks > 0 ? blocks : 1);
     if (pg < 1) pg = 1;
     if (pg > patches) pg = patches;

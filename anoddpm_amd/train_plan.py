@@ -276,7 +276,7 @@ class TrainPlan(_Plan):
         wa.algo = algo
         if algo:
             wa.ws_floats = lib().anoddpm_wgrad43_groups(K, N, B, H, W) * 36 * K * N
-            ipb = (H // 8) * (W // 16)                           # column sums per 16x8 output patch
+            ipb = lib().anoddpm_wgrad43_patches(H, W)            # column sums per output patch of the kernel
         else:
             wa.ws_floats = nitems * 9 * K * N
         self.tws(wa, "ws", wa.ws_floats)

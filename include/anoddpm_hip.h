@@ -563,11 +563,12 @@ typedef struct anoddpm_wgrad_args {
                                        the adjoint of the cfg-3 forward kernel: dU = sum_tiles V (.) Z, dg = G^T dU G -- needs
                                        gn + act == 1, a_mode 0 / 1, H % 8 == 0, W % 16 == 0, K % 32 == 0, N % 64 == 0,
                                        c0 % 16 == 0, B <= 15; ws: anoddpm_wgrad43_groups(...) * 36 * K * N floats; colsum items =
-                                       the 16x8 output patches, [B][(H/8)*(W/16)][N]; `band` is ignored */
+                                       the kernel's output patches, [B][anoddpm_wgrad43_patches(H, W)][N]; `band` is ignored */
 } anoddpm_wgrad_args;
 
 int anoddpm_conv3x3_wgrad(const anoddpm_wgrad_args *a, void *stream);
 int anoddpm_wgrad43_groups(int32_t K, int32_t N, int32_t B, int32_t H, int32_t W);   /* workgroup sets (workspace slabs) of algo 1 */
+int anoddpm_wgrad43_patches(int32_t H, int32_t W);                                    /* column-sum items per image of algo 1 */
 
 /* Device-side weight packing for the 3x3 kernels (training re-packs after every optimizer step).  w: OIHW [N][K][3][3].
  * mode 0: direct layout [9][I/4][O][4]; mode 1: Winograd F(2x2,3x3) U = G g G^T as [16][I/4][O][4]; mode 2: Winograd
