@@ -669,6 +669,95 @@ __global__ __launch_bounds__(256) void conv_head_taps_kernel(anoddpm_head_args a
     }
 }
 
+// The same layer with the tap products on the matrix pipe (round 3): T[pixel][tap * COUT + o] = act[pixel][C] x w[C][9 * COUT] is a
+// GEMM with N = 9 * COUT <= 16 * NT, v_mfma_f32_16x16x4_f32 with M = 16 pixels of a tile row.  What it buys over the VALU form
+// above is not arithmetic but LOADS: there a lane owns a pixel and every wave-level load touches 64 different cache lines (16
+// bytes of each), which costs the texture-address unit as much time as HBM needs for the data (46 us for 134 MB); here the
+// four lanes (m, q = 0..3) of a pixel read 64 contiguous bytes per load and a wave instruction covers sixteen consecutive pixels.
+// Lane (m = lane & 15, q = lane >> 4) holds channels 16 j + 4 q + s (s = 0..3) of pixel m for channel group j: one float4 load
+// feeds four MFMAs; the B operand (weights of those channels for column n = m) sits in NT * NJ * 4 registers for the whole kernel.
+// GroupNorm-apply + SiLU run on the loaded float4 (affine of the image in LDS).  The tile's products go through LDS once and an
+// output pixel adds its nine neighbours' entries, as above.  NJ = C / 16.
+typedef float hf32x4 __attribute__((ext_vector_type(4)));
+
+template <int COUT, int NJ>
+__global__ __launch_bounds__(256) void conv_head_mfma_kernel(anoddpm_head_args a)
+{
+    constexpr int NT = (9 * COUT + 15) / 16;
+    __shared__ float T[9 * COUT][HT * HT];
+    __shared__ hf32x4 aff[2][NJ * 4];
+    const int C = NJ * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int tiles_x = (a.W + HT - 3) / (HT - 2);
+    const int b = blockIdx.y;
+    const int oy0 = (blockIdx.x / tiles_x) * (HT - 2), ox0 = (blockIdx.x % tiles_x) * (HT - 2);
+    for (int i = tid; i < NJ * 4; i += 256) {
+        aff[0][i] = reinterpret_cast<const hf32x4 *>(a.gn_scale + (int64_t)b * C)[i];
+        aff[1][i] = reinterpret_cast<const hf32x4 *>(a.gn_shift + (int64_t)b * C)[i];
+    }
+    // B operand: column n = nt * 16 + m is (tap, o) = (n / COUT, n % COUT); rows = this lane's channels
+    float bw[NT][NJ][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + m;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                bw[nt][j][s] = n < 9 * COUT ? a.w[((int64_t)(n / COUT) * C + 16 * j + 4 * q + s) * COUT + n % COUT] : 0.f;
+    }
+    __syncthreads();
+    // tile row ty = wave * 4 + mt, pixel tx = m.  Four float4 (64 channels) of loads in flight per lane: latency is covered by the
+    // other workgroups of the CU (a double-buffered row needs 192 registers at C = 128 and halves the occupancy).
+#pragma unroll 1
+    for (int mt = 0; mt < 4; ++mt) {
+        const int gy = oy0 + wave * 4 + mt - 1, gx = ox0 + m - 1;
+        const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const float *xp = a.x + (((int64_t)b * a.H + (inside ? gy : 0)) * a.W + (inside ? gx : 0)) * C + 4 * q;
+        hf32x4 accr[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accr[nt] = hf32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int JB = NJ > 4 ? 4 : NJ;                          // channel groups per batch of loads (64 channels)
+#pragma unroll
+        for (int j0 = 0; j0 < NJ; j0 += JB) {
+            hf32x4 v[JB];
+#pragma unroll
+            for (int j = 0; j < JB; ++j) v[j] = *reinterpret_cast<const hf32x4 *>(xp + 16 * (j0 + j));
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+                const hf32x4 sc = aff[0][4 * (j0 + j) + q], sh = aff[1][4 * (j0 + j) + q];
+                const hf32x4 x4 = v[j] * sc + sh;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float av = inside ? silu_f(x4[s]) : 0.f;  // zero padding of the ACTIVATED map
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) accr[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[nt][j0 + j][s], accr[nt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                      // keep the batches apart (registers)
+        }
+        // D[row = 4 q + r][col = m]: this lane holds column n = nt * 16 + m for pixels 4 q .. 4 q + 3 of the row
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 16 + m;
+            if (n < 9 * COUT) *reinterpret_cast<hf32x4 *>(&T[n][(wave * 4 + mt) * HT + 4 * q]) = accr[nt];
+        }
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    const int oy = oy0 + ty - 1, ox = ox0 + tx - 1;                 // thread (ty, tx), 1 <= ty, tx <= HT - 2, also owns output (oy, ox)
+    if (ty >= 1 && ty <= HT - 2 && tx >= 1 && tx <= HT - 2 && oy < a.H && ox < a.W) {
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            float r = a.bias ? a.bias[o] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) r += T[k * COUT + o][(ty + k / 3 - 1) * HT + tx + k % 3 - 1];
+            a.out[(((int64_t)b * COUT + o) * a.H + oy) * a.W + ox] = r;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(anoddpm_layout_args a)
 {
     const int64_t total = (int64_t)a.B * a.C * a.P;
@@ -864,6 +953,15 @@ extern "C" int anoddpm_conv_head(const anoddpm_head_args *a, void *stream)
         const int tx = (a->W + HT - 3) / (HT - 2), tyy = (a->H + HT - 3) / (HT - 2);
         dim3 grid(tx * tyy, a->B);
         hipStream_t s = anoddpm::as_stream(stream);
+        // matrix-pipe form for the shipped widths (B operand in registers: NT * NJ <= 24); ANODDPM_DEBUG4=2: the VALU tap kernel
+        const bool aligned = ((uintptr_t)a->x | (uintptr_t)a->gn_scale | (uintptr_t)a->gn_shift) % 16 == 0;
+        if (aligned && anoddpm::g_debug[4] != 2) {
+#define HEAD_MFMA(CO, NJ_) { hipLaunchKernelGGL((conv_head_mfma_kernel<CO, NJ_>), grid, dim3(256), 0, s, *a); return anoddpm::check_launch("conv_head"); }
+            if (a->C == 128) { if (a->Cout == 1) HEAD_MFMA(1, 8) if (a->Cout == 2) HEAD_MFMA(2, 8) if (a->Cout == 3) HEAD_MFMA(3, 8) if (a->Cout == 4) HEAD_MFMA(4, 8) }
+            if (a->C == 64)  { if (a->Cout == 1) HEAD_MFMA(1, 4) if (a->Cout == 2) HEAD_MFMA(2, 4) if (a->Cout == 3) HEAD_MFMA(3, 4) if (a->Cout == 4) HEAD_MFMA(4, 4) }
+            if (a->C == 256 && a->Cout == 1) HEAD_MFMA(1, 16)
+#undef HEAD_MFMA
+        }
         switch (a->Cout) {
             case 1: hipLaunchKernelGGL(conv_head_taps_kernel<1>, grid, dim3(256), 0, s, *a); break;
             case 2: hipLaunchKernelGGL(conv_head_taps_kernel<2>, grid, dim3(256), 0, s, *a); break;

@@ -167,6 +167,30 @@ class ReverseChain:
         # callable, a user-replaced `noise_fn`, the randParam / random mixtures -- draws from numpy / `random` on the
         # host every step (newSeed(), GaussianDiffusion.py:102) and uploads a table: captured once, every replay
         # would reuse the first step's seed.  Those run eagerly.
+        fn, capture_safe = self._resolve_noise(owner, denoise_fn)
+        self._last_seed = None
+        self.reuse_key = None
+        if isinstance(fn, SimplexNoiseFn):
+            self.simplex_fn = fn
+            self.noise = torch.empty_like(self.x)
+            # room for the permutation tables of a full-length chain, so that reset() can start another chain on the same buffers
+            self.tables = torch.empty((max(self.remaining, owner.num_timesteps) * fn.in_channels, 512), dtype=torch.int16, device=x.device)
+            self._draw_tables(self.remaining)
+        self.reuse_key = self._reuse_key_of(owner, denoise_fn)
+        self.capture_safe = capture_safe
+        # HIP-graph replay of the step: on by default for the built-in UNetModel (every launch of a step is
+        # stream-ordered, allocation-free C-ABI work) with a capture-safe noise source; ANODDPM_NO_GRAPH=1 forces
+        # eager launches.  An explicit use_graph=True with an unsafe noise source is refused, not silently wrong.
+        if use_graph is None:
+            use_graph = self.hip_model and capture_safe and os.environ.get("ANODDPM_NO_GRAPH", "0") != "1"
+        elif use_graph and not capture_safe:
+            raise ValueError("ReverseChain(use_graph=True): this denoise_fn draws host-side random numbers every step "
+                             "and cannot be replayed from a captured graph; pass a SimplexNoiseFn or 'gauss'")
+        self.use_graph = bool(use_graph)
+
+    @staticmethod
+    def _resolve_noise(owner, denoise_fn):
+        """-> (SimplexNoiseFn or the original denoise_fn, capture_safe): how the reverse loop's noise request is served."""
         fn = denoise_fn
         capture_safe = False
         if type(fn) == str:
@@ -184,27 +208,47 @@ class ReverseChain:
                 fn = SimplexNoiseFn(owner.simplex, in_channels=owner.img_channels)          # :310 defaults
         if isinstance(fn, SimplexNoiseFn):
             capture_safe = True
-            # draw every seed of the chain now, in the order the per-step newSeed() calls would
-            C = fn.in_channels
-            tabs = np.empty((self.remaining * C, 512), dtype=np.int16)
-            self._last_seed = None
-            for i in range(self.remaining * C):
-                seed = np.random.randint(-10000000000, 10000000000)
-                tabs[i] = perm_tables(seed)
-                self._last_seed = seed
-            self.tables = torch.from_numpy(tabs).to(x.device)
-            self.simplex_fn = fn
-            self.noise = torch.empty_like(self.x)
-        self.capture_safe = capture_safe
-        # HIP-graph replay of the step: on by default for the built-in UNetModel (every launch of a step is
-        # stream-ordered, allocation-free C-ABI work) with a capture-safe noise source; ANODDPM_NO_GRAPH=1 forces
-        # eager launches.  An explicit use_graph=True with an unsafe noise source is refused, not silently wrong.
-        if use_graph is None:
-            use_graph = self.hip_model and capture_safe and os.environ.get("ANODDPM_NO_GRAPH", "0") != "1"
-        elif use_graph and not capture_safe:
-            raise ValueError("ReverseChain(use_graph=True): this denoise_fn draws host-side random numbers every step "
-                             "and cannot be replayed from a captured graph; pass a SimplexNoiseFn or 'gauss'")
-        self.use_graph = bool(use_graph)
+        return fn, capture_safe
+
+    @staticmethod
+    def _reuse_key_of(owner, denoise_fn):
+        """Key under which a graph-replaying chain for this noise request may be restarted with reset() (None: never)."""
+        fn, capture_safe = ReverseChain._resolve_noise(owner, denoise_fn)
+        if isinstance(fn, SimplexNoiseFn):
+            return ("simplex", id(fn.simplex), fn.octave, fn.persistence, fn.frequency, fn.in_channels)
+        return ("gauss",) if capture_safe else None
+
+    def _draw_tables(self, nsteps):
+        """Every seed of the chain, drawn now in the order the per-step newSeed() calls would (numpy global stream), and the
+        permutation tables uploaded in one copy."""
+        fn = self.simplex_fn
+        n = nsteps * fn.in_channels
+        tabs = np.empty((n, 512), dtype=np.int16)
+        self._last_seed = None
+        for i in range(n):
+            seed = np.random.randint(-10000000000, 10000000000)
+            tabs[i] = perm_tables(seed)
+            self._last_seed = seed
+        if n:
+            self.tables[:n].copy_(torch.from_numpy(tabs))
+
+    def reset(self, x, t_distance):
+        """Start another chain of the same batch shape on this chain's device buffers: the captured HIP graph (and the plan behind
+        it) is reused instead of being built again -- the detection loops run hundreds of chains of one shape."""
+        if tuple(x.shape) != tuple(self.x.shape) or x.device != self.x.device:
+            raise ValueError("ReverseChain.reset: shape / device differ from the chain's buffers")
+        if not 0 <= int(t_distance) <= self.owner.num_timesteps:
+            raise IndexError(f"t_distance {t_distance} is out of range for a {self.owner.num_timesteps}-step schedule")
+        self.x.copy_(self.owner._f32(x.detach()))
+        self.t.fill_(int(t_distance) - 1)
+        self.step_idx.zero_()
+        self.remaining = int(t_distance)
+        if self.tables is not None:
+            self._draw_tables(self.remaining)
+        if self.hip_model and self._graph_state == 2:
+            # the replayed graph reads the plan's packed weights: let the plan re-pack them if the parameters moved since
+            self.model._plan_for(self.B, self.x.shape[2], self.x.device)
+        return self
 
     def step(self):
         if self.use_graph and lib().anoddpm_prof_active() == 0:
@@ -542,9 +586,31 @@ class GaussianDiffusionModel:
 
     p_sample_loop = forward_backward          # north-star alias
 
+    def _chain_for(self, model, x, t_distance, denoise_fn):
+        """A ReverseChain for (model, batch shape, noise source): chains that replay a captured graph are kept and restarted with
+        reset() (same device buffers, same graph); anything else is built fresh."""
+        import weakref
+        cache = self.__dict__.setdefault("_chains", {})
+        probe_key = (tuple(x.shape), str(x.device))
+        for key, (ref, chain) in list(cache.items()):
+            if ref() is None:
+                del cache[key]
+        for key, (ref, chain) in cache.items():
+            if key[:2] == probe_key and ref() is model:
+                # same noise source? (a chain built for 'gauss' must not serve a simplex request and vice versa)
+                trial = ReverseChain._reuse_key_of(self, denoise_fn)
+                if trial is not None and trial == chain.reuse_key and key[2] == trial:
+                    return chain.reset(x, t_distance)
+        chain = ReverseChain(self, model, x, t_distance, denoise_fn)
+        if chain.use_graph and chain.reuse_key is not None:
+            if len(cache) >= 8:
+                cache.pop(next(iter(cache)))
+            cache[probe_key + (chain.reuse_key,)] = (weakref.ref(model), chain)
+        return chain
+
     def _reverse_chain(self, model, x, t_distance, denoise_fn, seq):
         """t = t_distance-1 ... 0 of sample_p with a device-resident timestep (no per-step H2D)."""
-        chain = ReverseChain(self, model, x, t_distance, denoise_fn)
+        chain = self._chain_for(model, x, t_distance, denoise_fn)
         for _ in range(t_distance):
             chain.step()
             if seq is not None:

@@ -47,6 +47,49 @@ def test_batched_chains_equal_serial_chains():
         assert torch.allclose(batched[b:b + 1], x, atol=1e-4, rtol=0), float((batched[b:b + 1] - x).abs().max())
 
 
+def test_reverse_chain_is_reused_across_settings_and_matches_a_fresh_chain():
+    """The detection loops run many chains of one batch shape: after the first, a chain is restarted on the same device buffers
+    and the same captured graph (ReverseChain.reset).  Restarted chains give bit-identical results to freshly built ones -- other
+    input, other length, re-drawn simplex seeds, and weights that changed in between."""
+    GD, m, _ = tiny()
+    mk = lambda: GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(100, "linear"), noise="simplex")
+    d = mk()
+    fn = GD.SimplexNoiseFn(d.simplex, octave=4, persistence=0.6, frequency=16)
+    torch.manual_seed(5)
+    xa, xb = torch.rand(2, 1, 32, 32, device=DEV) * 2 - 1, torch.rand(2, 1, 32, 32, device=DEV) * 2 - 1
+
+    def fresh(x, tdist, seed):
+        d2 = mk()                                                    # no cached chain
+        np.random.seed(seed)
+        with torch.no_grad():
+            return d2._reverse_chain(m, x, tdist, GD.SimplexNoiseFn(d2.simplex, octave=4, persistence=0.6, frequency=16), None).clone()
+
+    np.random.seed(3)
+    with torch.no_grad():
+        a = d._reverse_chain(m, xa, 7, fn, None).clone()
+    assert len(d._chains) == 1
+    chain = next(iter(d._chains.values()))[1]
+    assert chain.use_graph and chain.graph is not None
+    np.random.seed(4)
+    with torch.no_grad():
+        b = d._reverse_chain(m, xb, 5, fn, None).clone()             # restarted: other input, shorter
+    assert len(d._chains) == 1 and next(iter(d._chains.values()))[1] is chain
+    assert torch.equal(a, fresh(xa, 7, 3)) and torch.equal(b, fresh(xb, 5, 4))
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.01)
+    m.mark_weights_changed()
+    np.random.seed(6)
+    with torch.no_grad():
+        c = d._reverse_chain(m, xa, 6, fn, None).clone()             # restarted after the weights moved
+    assert torch.equal(c, fresh(xa, 6, 6)) and not torch.equal(c[:, :, :4], a[:, :, :4])
+    # another noise source or batch shape gets its own chain
+    with torch.no_grad():
+        d._reverse_chain(m, xa, 3, "gauss", None)
+        d._reverse_chain(m, xa[:1], 3, fn, None)
+    assert len(d._chains) == 3
+
+
 def test_detection_B_records_and_return(tmp_path, monkeypatch):
     from oracle import metrics_oracle as mo
     GD, m, d = tiny()

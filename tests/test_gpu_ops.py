@@ -271,7 +271,8 @@ def test_stem_fused_groupnorm_sums(case):
     assert (stats[..., 1].double() - (o * o).sum(2)).abs().max() <= 1e-5 * (o * o).sum(2).max()
 
 
-@pytest.mark.parametrize("case", [(2, 128, 32, 1), (1, 64, 64, 3), (1, 32, 8, 2), (1, 128, 256, 1)])
+@pytest.mark.parametrize("case", [(2, 128, 32, 1), (1, 64, 64, 3), (1, 32, 8, 2), (1, 128, 256, 1),
+                                  (1, 256, 16, 1), (2, 128, 24, 4), (1, 64, 40, 2), (1, 96, 16, 1)])   # matrix-pipe widths, 96: tap kernel
 def test_head_conv(case):
     import hipops
     B, C, H, Cout = case
