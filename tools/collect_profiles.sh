@@ -16,10 +16,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stats -o c4 -- $
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY --output-format csv -d $OUT/c4_sq -o c4 -- $B --config c4 > $OUT/c4_sq.log 2>&1
 unset ANODDPM_NO_GRAPH
 cd $GRAFT_REPO_ROOT
-python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
-python bench.py --config c3 --steps 5 --warmup 2 > $OUT/bench_c3.json 2> $OUT/bench_c3.err
-python bench.py --config c4 --steps 10 > $OUT/bench_c4.json 2> $OUT/bench_c4.err
-python bench.py --config c5 --steps 10 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
 python bench.py --dump-plan $OUT/plan_c2.json --steps 2 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
 python tools/by_layer.py $OUT/plan_c2.json $(find $OUT/c2_stats -name "*kernel_trace.csv" | head -1) 2 > $OUT/c2_igemm_by_layer.csv 2> $OUT/by_layer.err
 # keep what is small: summaries only (the raw traces can be hundreds of MB)
@@ -35,4 +31,11 @@ for d in c2_stats c2_fetch c2_write c2_sq c3_stats c4_stats c4_sq; do
 done
 # HBM-side bytes per launch for bench.py's roofline.traffic (calibration: tools/calib_hbm.sh -> profiles/r3_hbm_calibration.json)
 python tools/traffic_from_pmc.py traffic profiles/r3_hbm_calibration.json $OUT/c2_fetch_by_kernel.csv $OUT/c2_write_by_kernel.csv 4 "${2:-}" > $OUT/traffic_c2.json
+# the bench lines last: roofline.traffic of the c2 line reads the traffic file of THIS build (committed later under the same name)
+cp $OUT/traffic_c2.json profiles/${1:-prof}_traffic_c2.json
+python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
+python bench.py --config c3 --steps 5 --warmup 2 > $OUT/bench_c3.json 2> $OUT/bench_c3.err
+python bench.py --config c4 --steps 10 > $OUT/bench_c4.json 2> $OUT/bench_c4.err
+python bench.py --config c5 --steps 10 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
+python bench.py --config det --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_det.json 2> $OUT/bench_det.err
 ls -la $OUT
