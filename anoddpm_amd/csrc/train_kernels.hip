@@ -180,10 +180,14 @@ __global__ __launch_bounds__(256) void wgrad1_fold_lanes_kernel(const anoddpm_wg
     __shared__ float part[8][32];
     const int K = a.c0 + a.c1, N = a.N;
     const int tiles_n = N >> 5;
+    // row K (one more row of workgroups, launched only with dbias) folds the column sums stored behind the items' tiles the same
+    // way: the serial walk `for k < nitems: b += cs[k][co]` by 32 threads of the first row was the kernel's critical path (256
+    // dependent-latency loads: 66 us for a 17 us fold)
     const int ci = blockIdx.x / tiles_n, co0 = (blockIdx.x % tiles_n) * 32;
+    const bool bias_row = ci == K;
     const int il = threadIdx.x >> 5, ol = threadIdx.x & 31;
-    const int64_t item = (int64_t)K * N;
-    const float *p = a.ws + (int64_t)ci * N + co0 + ol;
+    const int64_t item = bias_row ? (int64_t)N : (int64_t)K * N;
+    const float *p = (bias_row ? a.ws + (int64_t)nitems * K * N : a.ws + (int64_t)ci * N) + co0 + ol;
     float s = 0.f;
     int it = il;
     for (; it + 8 * 15 < nitems; it += 8 * 16) {
@@ -200,13 +204,11 @@ __global__ __launch_bounds__(256) void wgrad1_fold_lanes_kernel(const anoddpm_wg
         float t = 0.f;
 #pragma unroll
         for (int l = 0; l < 8; ++l) t += part[l][threadIdx.x];
-        float *dst = a.dw + (int64_t)(co0 + threadIdx.x) * K + ci;
-        *dst = a.accumulate ? *dst + t : t;
-        if (a.dbias && ci == 0) {
-            float b = 0.f;
-            const float *cs = a.ws + (int64_t)nitems * K * N;
-            for (int k = 0; k < nitems; ++k) b += cs[(int64_t)k * N + co0 + threadIdx.x];
-            a.dbias[co0 + threadIdx.x] += b;
+        if (bias_row) {
+            a.dbias[co0 + threadIdx.x] += t;
+        } else {
+            float *dst = a.dw + (int64_t)(co0 + threadIdx.x) * K + ci;
+            *dst = a.accumulate ? *dst + t : t;
         }
     }
 }
@@ -650,7 +652,7 @@ extern "C" int anoddpm_wgrad_pointwise(const anoddpm_wgrad1_args *a, void *strea
     hipLaunchKernelGGL(wgrad1_kernel, dim3(tiles, (unsigned)nitems), dim3(256), 0, s, *a, nspan);
     const int64_t kn = (int64_t)K * a->N;
     if (nitems >= 32 && a->N % 32 == 0 && g_debug[8] != 1)             // ANODDPM_DEBUG8=1: the one-thread-per-weight kernel everywhere
-        hipLaunchKernelGGL(wgrad1_fold_lanes_kernel, dim3((unsigned)(kn / 32)), dim3(256), 0, s, *a, (int)nitems);
+        hipLaunchKernelGGL(wgrad1_fold_lanes_kernel, dim3((unsigned)(kn / 32 + (a->dbias ? a->N / 32 : 0))), dim3(256), 0, s, *a, (int)nitems);
     else
         hipLaunchKernelGGL(wgrad1_fold_kernel, dim3((unsigned)((kn + 255) / 256)), dim3(256), 0, s, *a, (int)nitems);
     return check_launch("wgrad_pointwise");

@@ -336,50 +336,52 @@ __global__ __launch_bounds__(256) void wgrad43_out_kernel(const anoddpm_wgrad_ar
         }
 }
 
-// Both steps in one launch: workgroup = one input channel k x 32 output channels x the six rows u of the 6x6 position grid
-// (192 threads).  A thread folds its six positions (u, 0..5) over the PG slabs (slab order, 16 loads in flight, lanes along n),
-// applies the column transform, the rows meet in LDS and 32 x 9 threads apply the row transform and write dw[n][k][3][3].
+// Both steps in one launch: workgroup = one input channel k x 32 output channels, 288 threads.  Thread (position pos = 0..35, lane
+// quad q) folds four output channels of its position over the PG slabs (slab order; sixteen 16-byte loads in flight), the 36 x 32
+// sums meet in LDS, then the column transform (18 x 32 items) and the row transform (9 x 32 items, writing dw[n][k][3][3]).
 // Same order of every sum as wgrad43_sum_kernel + wgrad43_out_kernel (bit-identical), one launch and one pass over the slabs
 // instead of two launches and a round trip of the folded slab.
-__global__ __launch_bounds__(192) void wgrad43_fold_kernel(const anoddpm_wgrad_args a, const int PG)
+__constant__ float G63[6][3] = {{1.f / 4, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                                {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+
+__global__ __launch_bounds__(288) void wgrad43_fold_kernel(const anoddpm_wgrad_args a, const int PG)
 {
+    __shared__ __attribute__((aligned(16))) float dd[36][32];
     __shared__ float rr[6][3][32];
     const int K = a.c0 + a.c1, N = a.N;
     const int tiles_n = N >> 5;
     const int k = blockIdx.x / tiles_n, n0 = (blockIdx.x % tiles_n) * 32;
-    const int u = threadIdx.x >> 5, nl = threadIdx.x & 31;
+    const int pos = threadIdx.x >> 3, q = threadIdx.x & 7;
     const int64_t plane = (int64_t)K * N, slab = 36 * plane;
-    const float G[6][3] = {{1.f / 4, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
-                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
-    float d[6];
-#pragma unroll
-    for (int v = 0; v < 6; ++v) {
-        const float *p = a.ws + ((int64_t)(u * 6 + v) * K + k) * N + n0 + nl;
-        float s = 0.f;
+    {
+        const float *p = a.ws + ((int64_t)pos * K + k) * N + n0 + 4 * q;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
         int g = 0;
         for (; g + 16 <= PG; g += 16) {
-            float x[16];
+            f32x4 x[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) x[i] = __builtin_nontemporal_load(p + (int64_t)(g + i) * slab);
+            for (int i = 0; i < 16; ++i) x[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p + (int64_t)(g + i) * slab));
 #pragma unroll
             for (int i = 0; i < 16; ++i) s += x[i];
         }
-        for (; g < PG; ++g) s += p[(int64_t)g * slab];
-        d[v] = s;
+        for (; g < PG; ++g) s += *reinterpret_cast<const f32x4 *>(p + (int64_t)g * slab);
+        *reinterpret_cast<f32x4 *>(&dd[pos][4 * q]) = s;
     }
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 18 * 32; i += 288) {              // r[u][b] = sum_v d[u][v] G[v][b]
+        const int ub = i >> 5, nl = i & 31, u = ub / 3, b = ub - u * 3;
         float s = 0.f;
 #pragma unroll
-        for (int v = 0; v < 6; ++v) s += d[v] * G[v][b];
+        for (int v = 0; v < 6; ++v) s += dd[u * 6 + v][nl] * G63[v][b];
         rr[u][b][nl] = s;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 32 * 9; i += 192) {
+    {
+        const int i = threadIdx.x;                                  // 288 = 32 x 9 outputs
         const int n = i / 9, ab = i - n * 9, aa = ab / 3, b = ab - aa * 3;
         float s = 0.f;
 #pragma unroll
-        for (int uu = 0; uu < 6; ++uu) s += G[uu][aa] * rr[uu][b][n];
+        for (int uu = 0; uu < 6; ++uu) s += G63[uu][aa] * rr[uu][b][n];
         float *o = a.dw + ((int64_t)(n0 + n) * K + k) * 9 + ab;
         *o = a.accumulate ? *o + s : s;
     }
@@ -421,7 +423,7 @@ int launch_wgrad43(const anoddpm_wgrad_args *a, hipStream_t s)
     const dim3 grid((unsigned)pg, (unsigned)((K / G4_KB) * (a->N / G4_NB)));
     hipLaunchKernelGGL(wgrad43_kernel, grid, dim3(G4_NT), 0, s, *a, pg, a->W / 16, a->H / 8, 1.0f / (float)(a->W / 16));
     if (g_debug[8] != 1) {                                           // ANODDPM_DEBUG8=1: the two-launch fold
-        hipLaunchKernelGGL(wgrad43_fold_kernel, dim3((unsigned)((int64_t)K * (a->N / 32))), dim3(192), 0, s, *a, pg);
+        hipLaunchKernelGGL(wgrad43_fold_kernel, dim3((unsigned)((int64_t)K * (a->N / 32))), dim3(288), 0, s, *a, pg);
         return check_launch("conv3x3_wgrad (Winograd)");
     }
     if (pg > 1) hipLaunchKernelGGL(wgrad43_sum_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, a->ws, slab, pg);
