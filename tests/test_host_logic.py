@@ -179,3 +179,40 @@ def test_conv_launch_policy_on_config2_shapes():
     assert pick(256, 256, 256, 128, Z, ks=1)[0] == 0 and pick(256, 256, 192, 128, Z, ks=1, plain=True)[0] == 0
     cfg, ks = pick(32, 32, 768, 256, Z)
     assert cfg == 2 and (768 // 16) % 1 == 0 and (ks - 1) * -(-(768 // 16) // ks) < 768 // 16      # no empty K slice
+
+
+def test_host_side_shape_helpers_of_the_library():
+    """Pure host functions of the C ABI (no device needed): statistics rows of the fused stem sums, patch / group counts of
+    the Winograd-domain weight gradient -- the values the plans size their buffers with."""
+    from anoddpm_amd._lib import lib
+    L = lib()
+    # stem: one row per workgroup range; 8 strips of 8 pixels per workgroup at Cout = 128, at most 1024 rows per image
+    assert L.anoddpm_stem_stats_rows(256, 256, 1, 128) == 1024 and L.anoddpm_stem_stats_rows(512, 512, 1, 128) == 1024
+    assert L.anoddpm_stem_stats_rows(128, 128, 1, 128) == 256 and L.anoddpm_stem_stats_rows(64, 64, 2, 64) == 32
+    assert L.anoddpm_stem_stats_rows(64, 64, 3, 128) == 0 and L.anoddpm_stem_stats_rows(60, 60, 1, 128) == 0     # no fused form
+    for (H, C) in ((256, 128), (512, 128), (64, 64), (16, 1024)):
+        rows = L.anoddpm_stem_stats_rows(H, H, 1, C)
+        assert rows > 0 and (H * H) % rows == 0 and (H * H // rows) % (8 * (256 // (C // 4))) == 0     # whole workgroup trips
+    # weight gradient, algo 1: column-sum items per image = the kernel's 16 x 8 patches; groups x blocks fill the 256 CUs
+    assert L.anoddpm_wgrad43_patches(256, 256) == 512 and L.anoddpm_wgrad43_patches(32, 32) == 8
+    assert L.anoddpm_wgrad43_groups(128, 128, 4, 256, 256) == 32 and L.anoddpm_wgrad43_groups(512, 512, 4, 32, 32) == 2
+    assert L.anoddpm_wgrad43_groups(32, 64, 1, 16, 16) == 2                                       # fewer patches than groups
+
+
+def test_reverse_chain_reuse_keys():
+    """Which reverse chains may be restarted on their buffers (ReverseChain.reset): keyed by the noise source the captured
+    graph contains -- 'gauss' / 'random' / a gaussian default noise_fn share one key, every simplex parameter set has its own,
+    a host-RNG callable has none (it is never captured)."""
+    import GaussianDiffusion as GD
+    from anoddpm_amd.diffusion import ReverseChain
+    d = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(100, "linear"), noise="simplex")
+    g = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(100, "linear"), noise="gauss")
+    key = ReverseChain._reuse_key_of
+    assert key(d, "gauss") == key(d, "random") == key(g, "noise_fn") == ("gauss",)
+    fa = GD.SimplexNoiseFn(d.simplex, octave=4, persistence=0.6, frequency=16)
+    fb = GD.SimplexNoiseFn(d.simplex, octave=4, persistence=0.6, frequency=32)
+    assert key(d, fa) == key(d, GD.SimplexNoiseFn(d.simplex, octave=4, persistence=0.6, frequency=16)) != key(d, fb)
+    assert key(d, "noise_fn")[0] == "simplex" and key(d, "noise_fn") == key(d, "simplex")        # both: the :179-181 / :310 defaults
+    assert key(d, lambda x, t: x) is None
+    d.noise_fn = lambda x, t: x                                                                   # user-replaced noise_fn: host side, eager
+    assert key(d, "noise_fn") is None
