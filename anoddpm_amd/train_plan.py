@@ -854,6 +854,8 @@ class TrainPlanFunction(torch.autograd.Function):
         xin = x.detach()
         if xin.dtype != torch.float32 or not xin.is_contiguous():
             xin = xin.float().contiguous()
+        if xin.data_ptr() % 16:
+            xin = xin.clone()                        # a view at an odd storage offset: the stem kernel reads 16-byte rows
         tt = t.detach()
         if tt.dtype != torch.int64 or tt.device != x.device or not tt.is_contiguous():
             tt = tt.to(device=x.device, dtype=torch.int64).contiguous()

@@ -272,6 +272,8 @@ class UNetModel(nn.Module):
         xin = x.detach()
         if xin.dtype != torch.float32 or not xin.is_contiguous():
             xin = xin.float().contiguous()
+        if xin.data_ptr() % 16:
+            xin = xin.clone()                        # a view at an odd storage offset: the stem kernel reads 16-byte rows
         t = time.detach()
         if t.dtype != torch.int64 or t.device != x.device or not t.is_contiguous():
             t = t.to(device=x.device, dtype=torch.int64).contiguous()

@@ -187,3 +187,21 @@ def test_packed_weights_are_not_repacked_every_forward():
             p.mul_(1.01)
         y1 = m(x, t)
     assert plan.pack_count == 2 and not torch.equal(y0, y1)
+
+
+def test_input_view_at_an_odd_storage_offset():
+    """A contiguous input that starts 4 bytes into its storage (not 16-byte aligned): the stem kernel's 16-byte row loads must
+    not see it -- the forward copies such a view; result identical to the aligned tensor's, with and without autograd."""
+    name = "i32_b32_h1"
+    g = np.load(os.path.join(GOLDEN, f"unet_{name}.npz"))
+    m, sd, kw = build(name)
+    x, t = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["t"]).to(DEV)
+    flat = torch.zeros(x.numel() + 1, device=DEV)
+    flat[1:].copy_(x.reshape(-1))
+    xo = flat[1:].view_as(x)
+    assert xo.is_contiguous() and xo.data_ptr() % 16 == 4
+    with torch.no_grad():
+        assert torch.equal(m(xo, t), m(x, t))
+    m.train()
+    ya, yb = m(xo, t), m(x, t)
+    assert ya.requires_grad and torch.equal(ya.detach(), yb.detach())
