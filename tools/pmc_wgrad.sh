@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON the MI355X box: SQ counters of the 3x3 weight-gradient kernels on the layer shapes of config 3 (tools/bench_conv.py WG=1).
-# $1 = output tag; ANODDPM_DEBUG8=2 in the environment selects the round-2 Winograd-domain kernel.
+# $1 = output tag.  Two passes: the eight SQ counters, then the LDS counters (counters never share a run with other trace domains).
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/${1:-wgrad_pmc}
 mkdir -p $O
