@@ -587,25 +587,21 @@ class GaussianDiffusionModel:
     p_sample_loop = forward_backward          # north-star alias
 
     def _chain_for(self, model, x, t_distance, denoise_fn):
-        """A ReverseChain for (model, batch shape, noise source): chains that replay a captured graph are kept and restarted with
-        reset() (same device buffers, same graph); anything else is built fresh."""
-        import weakref
+        """A ReverseChain for (model, batch shape, noise source): chains that replay a captured graph are kept -- at most eight,
+        oldest dropped first; they hold their model -- and restarted with reset() (same device buffers, same graph); anything
+        else is built fresh."""
         cache = self.__dict__.setdefault("_chains", {})
-        probe_key = (tuple(x.shape), str(x.device))
-        for key, (ref, chain) in list(cache.items()):
-            if ref() is None:
-                del cache[key]
-        for key, (ref, chain) in cache.items():
-            if key[:2] == probe_key and ref() is model:
-                # same noise source? (a chain built for 'gauss' must not serve a simplex request and vice versa)
-                trial = ReverseChain._reuse_key_of(self, denoise_fn)
-                if trial is not None and trial == chain.reuse_key and key[2] == trial:
-                    return chain.reset(x, t_distance)
+        want = ReverseChain._reuse_key_of(self, denoise_fn)
+        if want is not None:
+            key = (id(model), tuple(x.shape), str(x.device), want)
+            chain = cache.get(key)
+            if chain is not None and chain.model is model:
+                return chain.reset(x, t_distance)
         chain = ReverseChain(self, model, x, t_distance, denoise_fn)
         if chain.use_graph and chain.reuse_key is not None:
             if len(cache) >= 8:
                 cache.pop(next(iter(cache)))
-            cache[probe_key + (chain.reuse_key,)] = (weakref.ref(model), chain)
+            cache[(id(model), tuple(x.shape), str(x.device), chain.reuse_key)] = chain
         return chain
 
     def _reverse_chain(self, model, x, t_distance, denoise_fn, seq):

@@ -68,12 +68,12 @@ def test_reverse_chain_is_reused_across_settings_and_matches_a_fresh_chain():
     with torch.no_grad():
         a = d._reverse_chain(m, xa, 7, fn, None).clone()
     assert len(d._chains) == 1
-    chain = next(iter(d._chains.values()))[1]
+    chain = next(iter(d._chains.values()))
     assert chain.use_graph and chain.graph is not None
     np.random.seed(4)
     with torch.no_grad():
         b = d._reverse_chain(m, xb, 5, fn, None).clone()             # restarted: other input, shorter
-    assert len(d._chains) == 1 and next(iter(d._chains.values()))[1] is chain
+    assert len(d._chains) == 1 and next(iter(d._chains.values())) is chain
     assert torch.equal(a, fresh(xa, 7, 3)) and torch.equal(b, fresh(xb, 5, 4))
     with torch.no_grad():
         for p in m.parameters():
