@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 (OP_WGRAD3, OP_WGRAD1, OP_GN_BWD, OP_PACK, OP_SOFTMAX_BWD, OP_TRANSPOSE, OP_LINEAR_BWD, OP_STEM_BWD, OP_HEAD_BWD,
@@ -249,7 +249,7 @@ _STRUCTS = [SimplexArgs, PUpdateArgs, IgemmArgs, GnArgs, SoftmaxArgs, ResampleAr
 
 # every symbol include/anoddpm_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "anoddpm_abi_version", "anoddpm_last_error", "anoddpm_device_count", "anoddpm_debug_set", "anoddpm_struct_size",
+    "anoddpm_abi_version", "anoddpm_last_error", "anoddpm_device_count", "anoddpm_struct_size",
     "anoddpm_simplex_perm_init", "anoddpm_simplex3_octaves_f64", "anoddpm_simplex3_octaves_f32",
     "anoddpm_simplex3_grid_f64", "anoddpm_simplex2_octaves_f64", "anoddpm_simplex2_grid_f64",
     "anoddpm_q_sample", "anoddpm_p_sample_update", "anoddpm_chain_advance",
@@ -358,9 +358,14 @@ def lib():
     L.anoddpm_volume_normalise.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
     L.anoddpm_mri_slice_prepare.argtypes = [POINTER(MriSliceArgs), c_void_p]
     L.anoddpm_resize_bilinear_pil.argtypes = [POINTER(ResizeArgs), c_void_p]
+    # kernel-variant selectors (internal, not in the public header).  A product build accepts only the keys whose values all
+    # compute correct results; a key that names a timing ablation raises instead of silently corrupting outputs
+    L.anoddpm_internal_variant.argtypes = [ctypes.c_int32, ctypes.c_int32]
     for i in range(16):
         if os.environ.get(f"ANODDPM_DEBUG{i}"):
-            L.anoddpm_debug_set(i, int(os.environ[f"ANODDPM_DEBUG{i}"], 0))
+            if L.anoddpm_internal_variant(i, int(os.environ[f"ANODDPM_DEBUG{i}"], 0)) != 0:
+                raise AnoddpmError(f"ANODDPM_DEBUG{i} selects a timing ablation (wrong results by design): rebuild with "
+                                   "ANODDPM_ABLATE=1 python -m anoddpm_amd.build --force to use it")
     _lib = L
     return L
 

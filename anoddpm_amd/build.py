@@ -46,6 +46,14 @@ def hipcc():
 
 def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
+    # ANODDPM_ABLATE=1: measurement build that also contains the timing ablations (kernels that skip work and produce wrong
+    # results by design; selected through anoddpm_internal_variant / ANODDPM_DEBUGn).  The product build has none of them.
+    flags = list(COMMON) + (["-DANODDPM_ABLATE"] if os.environ.get("ANODDPM_ABLATE", "0") == "1" else [])
+    stamp = os.path.join(OBJDIR, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
+        with open(stamp, "w") as f:
+            f.write(" ".join(flags))
     deps = [HEADER, os.path.join(CSRC, "common.h"), os.path.abspath(__file__)]
     dep_m = max(os.path.getmtime(d) for d in deps)
     objs, rebuilt = [], False
@@ -55,7 +63,7 @@ def build(force=False, verbose=False):
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), dep_m):
-            cmd = [hipcc(), *COMMON, *extra, "-c", s, "-o", o]
+            cmd = [hipcc(), *flags, *extra, "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -8,7 +8,7 @@
 namespace anoddpm {
 
 void set_error(const char *fmt, ...);
-extern int g_debug[16];      // experiment knobs (anoddpm_debug_set); all zero in normal operation
+extern int g_debug[16];      // kernel-variant selectors (anoddpm_internal_variant, executor.hip); all zero in normal operation
 
 #define ANODDPM_REQUIRE(cond, ...)                       \
     do {                                                 \

@@ -168,15 +168,20 @@ int launch_pointwise_stream(const anoddpm_igemm_args *a, hipStream_t s)
     if (gx > need) gx = (int)need;
     if (gx < 1) gx = 1;
     const dim3 grid((unsigned)gx, (unsigned)ny);
+#ifdef ANODDPM_ABLATE
     const int dbg = anoddpm::g_debug[3];
+#endif
     const int tpi = (int)(P / 32);
 #define PW_LAUNCH(NB_, KMAX_, DBG_) \
     hipLaunchKernelGGL((pointwise_stream_kernel<NB_, KMAX_, DBG_>), grid, dim3(PW_NT), 0, s, *a, (int)tiles, tpi)
+#ifdef ANODDPM_ABLATE           // timing ablations (wrong results): measurement builds only
     if (wide && dbg == 1) PW_LAUNCH(128, 256, 1);
     else if (wide && dbg == 2) PW_LAUNCH(128, 256, 2);
     else if (wide && dbg == 3) PW_LAUNCH(128, 256, 3);
     else if (wide && dbg == 4) PW_LAUNCH(128, 256, 4);
-    else if (wide) PW_LAUNCH(128, 256, 0);
+    else
+#endif
+    if (wide) PW_LAUNCH(128, 256, 0);
     else PW_LAUNCH(64, 512, 0);
 #undef PW_LAUNCH
     return check_launch("igemm(pointwise stream)");

@@ -428,11 +428,14 @@ static int launch_simplex(const anoddpm_simplex_args *a, void *stream)
     if (a->nslices == 0 || a->H == 0 || a->W == 0) return ANODDPM_OK;
     dim3 grid((a->W + 63) / 64, (a->H + 3) / 4, a->nslices);
     ANODDPM_REQUIRE(grid.y <= 65535, "simplex3_octaves: H too large");
+#ifdef ANODDPM_ABLATE           // timing ablations (wrong results): measurement builds only
     const int abl = anoddpm::g_debug[7];
     if (abl == 1) hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 1>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
     else if (abl == 2) hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 2>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
     else if (abl == 3) hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 3>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
-    else hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 0>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
+    else
+#endif
+    hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 0>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
     return anoddpm::check_launch("simplex3_octaves");
 }
 

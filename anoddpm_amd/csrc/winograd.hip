@@ -480,7 +480,11 @@ int launch_winograd(const anoddpm_igemm_args *a, hipStream_t s)
     const int dbg = anoddpm::g_debug[0];
     const int wmw = dbg == 1 ? 2 : 1;
     const bool fast = a->gn_scale && a->act;
-    const bool probe = anoddpm::g_debug[1] == 1 && fast && a->ksplit == 1 && a->ws && wmw == 1;   // tools/wino_phases.py
+#ifdef ANODDPM_ABLATE
+    const bool probe = anoddpm::g_debug[1] == 1 && fast && a->ksplit == 1 && a->ws && wmw == 1;   // tools/wino_phases.py (writes ticks into ws)
+#else
+    const bool probe = false;
+#endif
     const int wnw = (wmw == 1 && dbg != 2 && !probe && a->N % 128 == 0) ? 4 : 2;
     const int wbn = 32 * wnw;
     dim3 grid((unsigned)((a->H / (8 * wmw)) * (a->W / 16)), (unsigned)((a->N + wbn - 1) / wbn), (unsigned)(a->B * a->ksplit));
@@ -491,8 +495,10 @@ int launch_winograd(const anoddpm_igemm_args *a, hipStream_t s)
     if (wmw == 2) {
         if (fast) hipLaunchKernelGGL((wino_kernel<true, 2, 2>), grid, dim3(512), 0, s, *a);
         else      hipLaunchKernelGGL((wino_kernel<false, 2, 2>), grid, dim3(512), 0, s, *a);
+#ifdef ANODDPM_ABLATE
     } else if (probe) {
         hipLaunchKernelGGL((wino_kernel<true, 1, 2, true>), grid, dim3(256), 0, s, *a);
+#endif
     } else if (wnw == 4 && dbg != 3) {                              // shared input transform (ANODDPM_DEBUG0=3 disables)
         if (fast) hipLaunchKernelGGL((wino_kernel<true, 1, 4, false, true>), grid, dim3(512), 0, s, *a);
         else      hipLaunchKernelGGL((wino_kernel<false, 1, 4, false, true>), grid, dim3(512), 0, s, *a);

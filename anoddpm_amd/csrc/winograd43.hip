@@ -405,7 +405,11 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
     dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / nblk), (unsigned)a->B);
     ANODDPM_REQUIRE(a->B <= 65535, "winograd43: batch too large");
     const bool fast = a->gn_scale && a->act;
+#ifdef ANODDPM_ABLATE
     const int dbg = anoddpm::g_debug[2];
+#else
+    const int dbg = 0;
+#endif
     // 128-channel grid: the channel-sliced kernel (output transform in registers, winograd43r.hip); ANODDPM_DEBUG5=1 keeps this
     // file's position-sliced kernel
     // (ANODDPM_DEBUG5=3: also where this file's 64-channel variant would be chosen -- the op tests reach the kernel on small shapes)
@@ -415,11 +419,14 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
         return launch_winograd43r(a, s);
     }
     if (dbg == 0 && ((!half && anoddpm::g_debug[5] != 1) || (a->N % 128 == 0 && anoddpm::g_debug[5] == 3))) return launch_winograd43r(a, s);
+#ifdef ANODDPM_ABLATE           // timing ablations (wrong results): measurement builds only
     if (fast && dbg == 1) hipLaunchKernelGGL((wino43_kernel<true, 1>), grid, dim3(F4_NT), 0, s, *a);
     else if (fast && dbg == 2) hipLaunchKernelGGL((wino43_kernel<true, 2>), grid, dim3(F4_NT), 0, s, *a);
     else if (fast && dbg == 3) hipLaunchKernelGGL((wino43_kernel<true, 3>), grid, dim3(F4_NT), 0, s, *a);
     else if (fast && dbg == 4) hipLaunchKernelGGL((wino43_kernel<true, 4>), grid, dim3(F4_NT), 0, s, *a);
-    else if (fast && half) hipLaunchKernelGGL((wino43_kernel<true, 0, 4>), grid, dim3(F4_NT), 0, s, *a);
+    else
+#endif
+    if (fast && half) hipLaunchKernelGGL((wino43_kernel<true, 0, 4>), grid, dim3(F4_NT), 0, s, *a);
     else if (half) hipLaunchKernelGGL((wino43_kernel<false, 0, 4>), grid, dim3(F4_NT), 0, s, *a);
     else if (fast) hipLaunchKernelGGL((wino43_kernel<true>), grid, dim3(F4_NT), 0, s, *a);
     else      hipLaunchKernelGGL((wino43_kernel<false>), grid, dim3(F4_NT), 0, s, *a);

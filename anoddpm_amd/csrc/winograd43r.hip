@@ -341,6 +341,7 @@ int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
 {
     dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / 128), (unsigned)(a->B * a->ksplit));
     const bool fast = a->gn_scale && a->act;
+#ifdef ANODDPM_ABLATE           // timing ablations (wrong results) and ring-depth variants: measurement builds only
     const int dbg = g_debug[6];
     if (fast && dbg == 1) hipLaunchKernelGGL((wino43r_kernel<true, 1>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 2) hipLaunchKernelGGL((wino43r_kernel<true, 2>), grid, dim3(R4_NT), 0, s, *a);
@@ -348,7 +349,9 @@ int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
     else if (fast && dbg == 4) hipLaunchKernelGGL((wino43r_kernel<true, 4>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 8) hipLaunchKernelGGL((wino43r_kernel<true, 0, 8>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 9) hipLaunchKernelGGL((wino43r_kernel<true, 0, 4>), grid, dim3(R4_NT), 0, s, *a);
-    else if (fast) hipLaunchKernelGGL((wino43r_kernel<true>), grid, dim3(R4_NT), 0, s, *a);
+    else
+#endif
+    if (fast) hipLaunchKernelGGL((wino43r_kernel<true>), grid, dim3(R4_NT), 0, s, *a);
     else      hipLaunchKernelGGL((wino43r_kernel<false>), grid, dim3(R4_NT), 0, s, *a);
     return check_launch("winograd43r");
 }

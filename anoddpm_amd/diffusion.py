@@ -158,7 +158,9 @@ class ReverseChain:
         self.t = torch.full((self.B,), t_distance - 1, device=x.device, dtype=torch.int64)
         self.step_idx = torch.zeros(1, device=x.device, dtype=torch.int32)
         self.remaining = int(t_distance)
-        self.hip_model = hasattr(model, "forward_hip")
+        # a train()-mode model with dropout draws a fresh mask per forward from the host generator (UNet.py:192): it goes
+        # through model.forward (eager), not through the captured inference plan
+        self.hip_model = hasattr(model, "forward_hip") and not (getattr(model, "training", False) and getattr(model, "dropout", 0) > 0)
         self.noise = None
         self.tables = None
         # Which noise sources may run inside a captured HIP graph: device-side philox draws ("gauss" / "random":
@@ -221,6 +223,8 @@ class ReverseChain:
     def _draw_tables(self, nsteps):
         """Every seed of the chain, drawn now in the order the per-step newSeed() calls would (numpy global stream), and the
         permutation tables uploaded in one copy."""
+        import time
+        t0 = time.perf_counter()
         fn = self.simplex_fn
         n = nsteps * fn.in_channels
         tabs = np.empty((n, 512), dtype=np.int16)
@@ -231,6 +235,10 @@ class ReverseChain:
             self._last_seed = seed
         if n:
             self.tables[:n].copy_(torch.from_numpy(tabs))
+        # host time of the whole chain's newSeed() work, paid before the first step (upstream pays one newSeed() per step):
+        # bench.py reports it beside the per-step time
+        self.table_setup_ms = 1000.0 * (time.perf_counter() - t0)
+        self.table_setup_steps = nsteps
 
     def reset(self, x, t_distance):
         """Start another chain of the same batch shape on this chain's device buffers: the captured HIP graph (and the plan behind
@@ -612,7 +620,29 @@ class GaussianDiffusionModel:
             if seq is not None:
                 seq.append(chain.x.cpu().detach())
         chain.finish()
-        return chain.x
+        # a kept chain's buffer is overwritten by the next reset(): hand the caller its own tensor (the reference returns a fresh
+        # one from every call, GaussianDiffusion.py:351-359); an un-kept chain's buffer dies with the chain, no copy needed
+        return chain.x.clone() if chain in self.__dict__.get("_chains", {}).values() else chain.x
+
+    def release_chains(self):
+        """Drop every kept ReverseChain (captured HIP graph + the device buffers and plan it holds: about 3.4 GB per chain at
+        config 2); the next forward_backward / detection call builds and captures a fresh one."""
+        self.__dict__.pop("_chains", None)
+
+    def __getstate__(self):
+        """Pickle / deepcopy without the device-side caches: kept chains hold CUDAGraph objects, `_dev` holds device tensors."""
+        d = dict(self.__dict__)
+        d.pop("_chains", None)
+        d["_dev"] = {}
+        return d
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     def reverse_chain(self, model, x_t, t_distance, denoise_fn="gauss"):
         """Stepping form of the reverse loop of forward_backward (:351-357): returns a ReverseChain whose

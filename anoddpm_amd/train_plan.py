@@ -768,10 +768,15 @@ class TrainPlan(_Plan):
         self.stem.x = x.data_ptr()
         self.posemb.t = t.data_ptr()
         if self._drop_ops:
-            # a fresh mask per forward and per layer: the seed mixes torch's seed, a per-plan call counter and the layer index
-            # (the forward launch and the backward launch of a layer get the same value)
-            self._drop_calls = getattr(self, "_drop_calls", 0) + 1
-            base = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._drop_calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+            # a fresh mask per forward and per layer: the seed is one draw from torch's CPU generator (so torch.manual_seed
+            # between steps matters, as it does for nn.Dropout, and the stream advances per forward) mixed with the
+            # data-parallel rank (replicas seeded alike must not drop the same units) and the layer index; the forward launch
+            # and the backward launch of a layer get the same value
+            draw = int(torch.randint(0, 2 ** 62, (1,)).item())
+            rank = 0
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                rank = torch.distributed.get_rank()
+            base = (draw * 0x9E3779B97F4A7C15 + (rank + 1) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
             for fwd, bwd, idx in self._drop_ops:
                 fwd.seed = (base + idx * 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
                 if bwd is not None:
@@ -792,7 +797,8 @@ class TrainPlan(_Plan):
         self.stem_bwd_args.x = x.data_ptr()
         from .training import reducer_of
         red = reducer_of(self.model)
-        if red is not None and fresh:
+        if red is not None and any(self.named[k].requires_grad for k in fresh):
+            # (frozen parameters never get a .grad and are not in the flat buffers: they do not count)
             # every rank must cut its backward at the same places (the collectives are issued in bucket order): with a reducer
             # attached the gradients are bound to the flat views before the forward (UNetModel._forward_autograd), so a
             # missing .grad here means they were dropped between forward and backward
@@ -869,8 +875,7 @@ class TrainPlanFunction(torch.autograd.Function):
         plan = ctx.plan
         if ctx.epoch != plan.fwd_epoch:
             raise _lib.AnoddpmError("UNetModel training plan: backward() of a forward whose activations were overwritten by a "
-                                    "later forward of the same (batch, size); run one forward/backward pair at a time or set "
-                                    "ANODDPM_TRAIN_PLAN=0")
+                                    "later forward of the same (batch, size); run one forward/backward pair at a time")
         if not plan.params_match():
             raise _lib.AnoddpmError("UNetModel training plan: parameters or their .grad tensors moved between forward and backward")
         dx = plan.run_backward(ctx.xin, dy.detach().float().contiguous())

@@ -119,8 +119,15 @@ class GradAllReducer:
     Backend "gloo" with device tensors (two test ranks sharing one GPU -- RCCL cannot do that) stages each bucket through
     host memory: correct, slow, test-only."""
 
-    def __init__(self, flat, process_group=None, bucket_bytes=64 << 20, force=False):
+    def __init__(self, flat, process_group=None, bucket_bytes=None, force=False):
+        import os
         import torch.distributed as dist
+        if bucket_bytes is None:
+            # 64 MiB unless ANODDPM_BUCKET_MB says otherwise (the first real 8-GPU runs tune it without a code change)
+            bucket_bytes = int(float(os.environ.get("ANODDPM_BUCKET_MB", "64")) * (1 << 20))
+        if bucket_bytes < 4:
+            raise ValueError(f"GradAllReducer: bucket_bytes must be >= 4, got {bucket_bytes}")
+        self.bucket_bytes = int(bucket_bytes)
         self.dist = dist
         self.flat = flat
         self.group = process_group

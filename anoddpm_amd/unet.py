@@ -260,7 +260,34 @@ class UNetModel(nn.Module):
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_grad:
             return self._forward_autograd(x, time)
+        if self.training and self.dropout > 0:
+            return self._forward_train_mode_no_grad(x, time)
         return self.forward_hip(x, time)
+
+    def _forward_train_mode_no_grad(self, x, time):
+        """train() mode with dropout > 0 called under no_grad (the sampling previews of the training script run the train-mode
+        model through forward_backward): nn.Dropout is active in train mode whatever the grad mode (UNet.py:192), so this runs the
+        training plan's forward list (the only one with the dropout launches) and drops its saved activations."""
+        _lib.require_cuda(x, "UNetModel.forward (train mode)")
+        if not (x.dim() == 4 and x.shape[2] == x.shape[3] and x.shape[1] == self.in_channels):
+            raise ValueError(f"expected [B,{self.in_channels},S,S] input, got {tuple(x.shape)}")
+        from . import train_plan
+        B, S = x.shape[0], x.shape[2]
+        if not train_plan.eligible(self, B, S):
+            raise NotImplementedError(f"UNetModel in train() mode with dropout at batch {B}, size {S}: outside the native training plan; "
+                                      "call .eval() for sampling")
+        plan = self._train_plan_for(B, S, x.device, False, float(self.dropout))
+        xin = x.detach()
+        if xin.dtype != torch.float32 or not xin.is_contiguous():
+            xin = xin.float().contiguous()
+        if xin.data_ptr() % 16:
+            xin = xin.clone()
+        t = time.detach()
+        if t.dtype != torch.int64 or t.device != x.device or not t.is_contiguous():
+            t = t.to(device=x.device, dtype=torch.int64).contiguous()
+        y = plan.run_forward(xin, t)
+        plan.fwd_epoch = getattr(plan, "fwd_epoch", 0) + 1          # a pending backward of an earlier forward is now stale
+        return y.clone().to(x.dtype)
 
     def forward_hip(self, x, time, out=None):
         """Inference forward on the HIP plan (no autograd).  Returns a fresh tensor like x."""

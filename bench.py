@@ -99,6 +99,39 @@ def host_threads():
     return max(1, min(avail, 64))
 
 
+def host_description():
+    """What the CPU baseline ran on: os.cpu_count() and the CPU model string, beside the thread count used."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return {"host_cpu_count": os.cpu_count() or 1, "host_cpus_available": avail, "cpu_model": model}
+
+
+def tree_hash():
+    """Short hash of the sources that decide which kernels a step launches and how (csrc/*, the plans): the committed PMC
+    traffic files carry the hash of the tree they were measured on, so that a line can say when its `traffic` is stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, "anoddpm_amd", "csrc", "*.h*"))) + \
+        [os.path.join(ROOT, "anoddpm_amd", f) for f in ("unet.py", "train_plan.py")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 # ------------------------------------------------------------------------------------------ CPU baselines (oracle/)
 def cpu_baseline_reverse(cfg, steps=5):
     """The reference's CPU path restated (oracle/unet_oracle.py + simplex oracle + diffusion oracle), one image:
@@ -278,12 +311,17 @@ def committed_traffic(config_name, batch, kernel_prefixes):
             w += v["write_bytes_per_launch"] * v["launches"]
     if n == 0:
         return None
+    now = tree_hash()
     return {"bytes_per_launch": (f + w) / n, "fetch_bytes_per_launch": f / n, "write_bytes_per_launch": w / n,
             "source": os.path.relpath(path, ROOT), "fetch_factor": d["calibration"]["fetch_factor"],
-            "write_factor": d["calibration"]["write_factor"], "tree": d.get("tree")}
+            "write_factor": d["calibration"]["write_factor"], "tree": d.get("tree"),
+            # measured on another tree than the one running now (kernels / plans changed since the PMC passes): byte counts are
+            # of that tree, the timings beside them of this one
+            "measured_on_sources": d.get("sources_hash"), "running_sources": now, "stale": d.get("sources_hash") != now}
 
 
 PEAK_HBM_GBPS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (about 6.3 TB/s achievable)
+ACHIEVABLE_HBM_GBPS = 6300.0          # MI355X_MICROARCH.md: 6.29 TB/s measured with a float4 copy (79 % of peak)
 
 
 def hbm_kernel_rows(plan, B, ms, cnt, steps, extra=()):
@@ -337,6 +375,7 @@ def run_reverse(c, args, cfg):
     t_T = torch.full((B,), T_STEPS - 1, device=c.dev, dtype=torch.int64)
     x_T = diff.sample_q(x0, t_T, diff.noise_fn(x0, t_T).float())
     chain = diff.reverse_chain(model, x_T, T_STEPS, noise_fn)
+    table_setup_ms = getattr(chain, "table_setup_ms", 0.0)             # all T steps' newSeed() tables, drawn before the timed region
     assert (args.warmup + args.steps) * 2 + 2 <= T_STEPS
     elapsed = timed(c, args, chain.step)
     if args.dump_plan and c.rank == 0:
@@ -351,6 +390,10 @@ def run_reverse(c, args, cfg):
     if not args.no_prof:
         L = _lib.lib()
         plan = next(iter(model._plans.values()))
+        # the update and the noise kernel are launched by the chain, not by the plan's executor: one HIP-event pair around each
+        # of their launches inside the same instrumented steps (in the stream of a running step, not as lone launches)
+        pu_t = _TimedEntry(L, "anoddpm_p_sample_update", lambda a: 0.0)
+        sx_t = _TimedEntry(L, "anoddpm_simplex3_octaves_f32", lambda a: 0.0)
         L.anoddpm_prof_enable(1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -362,6 +405,8 @@ def run_reverse(c, args, cfg):
         cnt = (ctypes.c_int64 * _lib.OP_MAX)()
         _lib.check(L.anoddpm_prof_collect(ms, cnt), "prof_collect")
         L.anoddpm_prof_enable(0)
+        pu_ms_tot, pu_n, _ = pu_t.finish()
+        sx_ms_tot, sx_n, _ = sx_t.finish()
         # contraction classes: profiler slot, launches of the plan, fraction of the direct-convolution FLOPs the matrix pipe executes
         classes = {
             "wino43_kernel (Winograd F(4x4,3x3) 3x3 convolutions on maps >= 64x64, v_mfma_f32_16x16x4_f32)":
@@ -427,27 +472,34 @@ def run_reverse(c, args, cfg):
             roofline["traffic_detail"] = dict(tr, algorithmic_bytes_per_launch=alg, ratio_to_algorithmic=tr["bytes_per_launch"] / alg,
                                               GBps_at_avg_launch=tr["bytes_per_launch"] / (roofline["avg_launch_ms"] / 1000.0) / 1e9)
         # the memory-bound kernels against the HBM roofline (HIP events of the same instrumented pass; p_update timed here)
-        ev = []
-        for _ in range(5):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            diff._reverse_update(chain.x, chain.t, chain.x, chain.noise, want_pred=False, out=torch.empty_like(chain.x))
-            e1.record()
-            ev.append((e0, e1))
-        torch.cuda.synchronize()
-        pu_ms = min(a.elapsed_time(b) for a, b in ev)
-        pu_bytes = 16.0 * chain.x.numel()
-        extra = [{"kernel": "p_update (fused reverse update: read x_t, eps, noise; write x_{t-1})", "launches_per_step": 1.0, "ms_per_step": pu_ms,
-                  "algorithmic_MB_per_step": pu_bytes / 1e6, "GBps": pu_bytes / (pu_ms / 1000.0) / 1e9,
-                  "frac_of_8TBps": pu_bytes / (pu_ms / 1000.0) / 1e9 / PEAK_HBM_GBPS,
-                  "note": "1 MB per launch: launch-latency bound, timed with a HIP-event pair around a lone launch"}]
+        extra = []
+        if pu_n:
+            pu_ms = pu_ms_tot / pu_n
+            pu_bytes = 16.0 * chain.x.numel()
+            extra.append({"kernel": "p_update (fused reverse update: read x_t, eps, noise; write x_{t-1})", "launches_per_step": pu_n / args.steps,
+                          "ms_per_step": pu_ms_tot / args.steps, "algorithmic_MB_per_step": pu_bytes / 1e6, "GBps": pu_bytes / (pu_ms / 1000.0) / 1e9,
+                          "frac_of_8TBps": pu_bytes / (pu_ms / 1000.0) / 1e9 / PEAK_HBM_GBPS,
+                          "note": "4 MB per launch at batch 4: a few microseconds of data behind a launch; HIP-event pair around the launch "
+                                  "inside the instrumented step (stream busy before and after)"})
         roofline["hbm_kernels"] = hbm_kernel_rows(plan, B, ms, cnt, args.steps, extra)
+        for r in roofline["hbm_kernels"]:
+            r["frac_of_6.3TBps_achievable"] = r["GBps"] / ACHIEVABLE_HBM_GBPS
+        if sx_n:
+            roofline["class_ms_per_step"]["simplex"] = sx_ms_tot / args.steps
+        if pu_n:
+            roofline["class_ms_per_step"]["p_update"] = pu_ms_tot / args.steps
+        # kernel launches of one step: the plan's ops, a tail launch per split-K contraction, noise + update + chain_advance
+        roofline["kernel_launches_per_step"] = (len(plan.ops) + sum(1 for code, st in plan.ops if code == _lib.OP_IGEMM and st.ksplit > 1)
+                                                + (pu_n + sx_n) / args.steps + 1)
     metric = ("reverse-diffusion images/sec @256x256 T=1000 simplex" if cfg["img"] == 256 else
               f"reverse-diffusion images/sec @{cfg['img']}x{cfg['img']} T=1000 simplex")
     out = {"metric": metric, "value": value, "unit": "images/s", "ms_per_step": ms_per_step, "scaling": "weak", "dtype": "f32",
            "config": {"workload": cfg["name"], "per_gpu_batch": B, "global_batch": B * c.world, "T": T_STEPS,
                       "timed_steps_scaled_to_T": True, "parallelism": f"batch-sharded x{c.world} (no data-path collective)",
-                      "output_finite": finite}}
+                      "output_finite": finite,
+                      # work outside the timed region: the permutation tables of ALL T steps are drawn (numpy stream order of the
+                      # per-step newSeed() calls) and uploaded when the chain is built; per step that is table_setup_ms / T
+                      "table_setup_ms": table_setup_ms, "table_setup_us_per_step": 1000.0 * table_setup_ms / T_STEPS}}
     return out, roofline, (lambda: cpu_baseline_reverse(cfg))
 
 
@@ -685,6 +737,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--dump-plan", default="", help="write the igemm launch list of the compiled plan (JSON) here")
+    ap.add_argument("--no-extra", action="store_true", help="c2 only: skip the config-3 training step measured after the timed region")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -706,12 +759,46 @@ def main():
     if c.rank == 0 and c.world == 1 and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_fn()
+            line["cpu_baseline"].update(host_description())
         except Exception as e:                                   # the baseline must never sink the GPU number
             line["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if args.config == "c2" and not args.no_extra and os.environ.get("ANODDPM_BENCH_NO_EXTRA", "0") != "1":
+        line["extra"] = extra_c3(c, args, line)
     if c.rank == 0:
         print(json.dumps(line), flush=True)
     if c.dist is not None:
         c.dist.destroy_process_group()
+
+
+def extra_c3(c, args, line):
+    """After the timed region of the headline (c2) run: BASELINE config 3's training step on the same ranks (batch 4 per GPU;
+    N > 1: the bucketed RCCL all-reduce of the 521 MB gradient, the one data-path collective of the repo), 2 warm-up + 3 timed
+    steps, as `extra.c3_ms_per_step` -- so that the driver's N = 1, 2, 4, 8 runs also carry the training step and the first
+    real multi-rank RCCL numbers.  It can never cost the headline: any exception is reported in the object, and a watchdog
+    thread prints the line without the extra and exits if the leg has not finished within its budget (a hung collective cannot
+    be interrupted from Python)."""
+    import threading
+    budget = float(os.environ.get("ANODDPM_BENCH_EXTRA_TIMEOUT", "300"))
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(budget):
+            if c.rank == 0:
+                line["extra"] = {"c3_ms_per_step": None, "error": f"config-3 leg did not finish within {budget:.0f} s (abandoned)"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+    th = threading.Thread(target=watchdog, daemon=True)
+    th.start()
+    try:
+        a3 = argparse.Namespace(**vars(args))
+        a3.steps, a3.warmup, a3.no_prof, a3.batch, a3.config = 3, 2, True, 0, "c3"
+        out, _, _ = run_train(c, a3, dict(CONFIGS["c3"]))
+        res = {"c3_ms_per_step": out["ms_per_step"], "c3_images_per_s": out["value"], "c3_steps": a3.steps, "c3_warmup": a3.warmup,
+               "c3_config": out["config"], "note": "measured after the timed region of this line's metric; not part of `value`"}
+    except Exception as e:                                         # noqa: BLE001 -- the extra must never sink the headline
+        res = {"c3_ms_per_step": None, "error": repr(e)}
+    done.set()
+    return res
 
 
 if __name__ == "__main__":

@@ -31,7 +31,6 @@ extern "C" {
 int anoddpm_abi_version(void);          /* bumps whenever a struct below changes */
 const char *anoddpm_last_error(void);   /* [host] text of the last failure on this thread */
 int anoddpm_device_count(void);
-int anoddpm_debug_set(int32_t key, int32_t value);   /* tuning experiments only; all keys default to 0 */
 int anoddpm_struct_size(int32_t which); /* sizeof of the n-th *_args struct, in declaration order */
 
 /* ------------------------------------------------------------------ simplex ------------ */

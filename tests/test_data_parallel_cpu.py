@@ -190,3 +190,62 @@ def test_flat_layout_puts_embedding_projections_in_the_last_bucket_and_module_pi
     torch.save(net, io.BytesIO())
     from anoddpm_amd.training import reducer_of
     assert reducer_of(net) is None                                           # inert reducers are not handed to the plan
+
+
+def _worker8(rank, world, port, out_dir):
+    """Eight ranks, batch 32 (config 3's global batch): bucket size from ANODDPM_BUCKET_MB, buckets must tile the flat buffer
+    identically on every rank, shards must tile the batch, the reduced gradient must be the large-batch one."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["ANODDPM_BUCKET_MB"] = str(192 / (1 << 20))           # 192 bytes: several buckets on the toy model
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(123)
+    x = torch.randn(32, 1, 12, 12)
+    tgt = torch.randn(32, 1, 12, 12)
+    model = _toy()
+    flat = FlatBuffers(model)
+    red = GradAllReducer(flat)
+    assert red.bucket_bytes == 192 and red.active and red.world == 8
+    lo, hi = shard_range(32, rank, world)
+    for _ in range(2):
+        flat.zero_grad()
+        # mean over the shard; the reducer's mean over ranks then equals the mean over the global batch (equal shards)
+        (model(x[lo:hi]) - tgt[lo:hi]).square().mean().backward()
+        red.finish()
+    torch.save({"grad": flat.flat_grad.clone(), "range": (lo, hi), "bounds": red.bounds, "launched": red.launched},
+               os.path.join(out_dir, f"e{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gradient_allreduce_bucket_tiling_and_shards(tmp_path):
+    """the first real 8-GPU run must not fail on plumbing -- 8 gloo ranks, B = 32."""
+    world = 8
+    mp.spawn(_worker8, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / f"e{r}.pt") for r in range(world)]
+    torch.manual_seed(123)
+    x = torch.randn(32, 1, 12, 12)
+    tgt = torch.randn(32, 1, 12, 12)
+    model = _toy()
+    flat = FlatBuffers(model)
+    (model(x) - tgt).square().mean().backward()
+    assert [o["range"] for o in outs] == [(4 * r, 4 * r + 4) for r in range(world)]
+    bounds = outs[0]["bounds"]
+    assert len(bounds) > 2 and bounds[0][1] == flat.numel and bounds[-1][0] == 0
+    assert all(a[0] == b[1] for a, b in zip(bounds, bounds[1:]))               # buckets tile the flat buffer, top down
+    for o in outs:
+        assert o["bounds"] == bounds and o["launched"] == len(bounds)
+        assert torch.allclose(o["grad"], flat.flat_grad, rtol=1e-5, atol=1e-7)
+        assert torch.equal(o["grad"], outs[0]["grad"])                          # identical everywhere -> one clip factor
+
+
+def test_bucket_size_env_and_validation(monkeypatch):
+    net = _Net()
+    flat = FlatBuffers(net)
+    monkeypatch.setenv("ANODDPM_BUCKET_MB", "0.5")
+    assert GradAllReducer(flat).bucket_bytes == 512 * 1024
+    monkeypatch.delenv("ANODDPM_BUCKET_MB")
+    assert GradAllReducer(flat).bucket_bytes == 64 << 20
+    with pytest.raises(ValueError):
+        GradAllReducer(flat, bucket_bytes=0)

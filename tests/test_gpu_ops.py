@@ -376,9 +376,9 @@ def f43_variant(request):
     """0: the launcher's choice (the 64-channel position-sliced kernel on these small grids); 3: force the channel-sliced
     kernel (csrc/winograd43r.hip, what the 128-channel grids of the real layers run) wherever N % 128 == 0."""
     from anoddpm_amd._lib import lib
-    lib().anoddpm_debug_set(5, request.param)
+    lib().anoddpm_internal_variant(5, request.param)
     yield request.param
-    lib().anoddpm_debug_set(5, 0)
+    lib().anoddpm_internal_variant(5, 0)
 
 
 @pytest.mark.parametrize("case", F43_CASES)

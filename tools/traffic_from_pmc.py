@@ -75,5 +75,9 @@ if __name__ == "__main__":
         d = traffic(sys.argv[2], sys.argv[3], sys.argv[4])
         d["per_gpu_batch"] = int(sys.argv[5]) if len(sys.argv) > 5 else None
         d["tree"] = sys.argv[6] if len(sys.argv) > 6 else None
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        d["sources_hash"] = bench.tree_hash()          # bench.py flags the file as stale when the kernels / plans change
         d["command"] = "ANODDPM_NO_GRAPH=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof"
         print(json.dumps(d, indent=1))
