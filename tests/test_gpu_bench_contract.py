@@ -39,6 +39,10 @@ def test_bench_line_small_config():
     names = " ".join(k["kernel"] for k in r["hbm_kernels"])
     assert all(n in names for n in ("conv_stem", "conv_head", "resample2x", "p_update"))
     assert all(0 < k["frac_of_8TBps"] < 1 and abs(k["frac_of_8TBps"] - k["GBps"] / 8000.0) < 1e-9 for k in r["hbm_kernels"])
+    assert all(abs(k["frac_of_6.3TBps_achievable"] - k["GBps"] / 6300.0) < 1e-9 for k in r["hbm_kernels"])
+    pu = [k for k in r["hbm_kernels"] if "p_update" in k["kernel"]][0]
+    assert pu["launches_per_step"] == 1.0                           # timed inside the instrumented steps, one launch per step
+    assert r["kernel_launches_per_step"] > 50 and r["class_ms_per_step"]["simplex"] > 0 and r["class_ms_per_step"]["p_update"] > 0
 
 
 def test_bench_cpu_baseline_object():
@@ -46,6 +50,10 @@ def test_bench_cpu_baseline_object():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "images/s" and c["value"] > 0 and "sample" in c
     assert d["value"] > c["value"]
+    # the host the baseline ran on
+    assert c["host_cpu_count"] >= c["cores"] and c["host_cpus_available"] >= 1 and isinstance(c["cpu_model"], (str, type(None)))
+    # work outside the timed region is reported: the chain's pre-drawn simplex tables
+    assert d["config"]["table_setup_ms"] > 0 and d["config"]["table_setup_us_per_step"] > 0
 
 
 def test_bench_line_simplex_and_training_configs():

@@ -134,3 +134,22 @@ def test_bench_gpus_flag_spawns_ranks_or_fails_loudly():
         assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and "cpu_baseline" not in d
         assert d["config"]["global_batch"] == 2 * d["config"]["per_gpu_batch"]
         assert d["config"].get("ranks_share_devices", False) == (ndev < 2)
+
+
+def test_bench_eight_ranks_on_shared_devices():
+    """the driver's first 8-GPU run must not fail on plumbing.  `bench.py --gpus 8` here: eight ranks over the
+    visible device(s) (rank r uses device r % ndev), gloo -- reverse-chain shards (c1) and the config-3 training step with its
+    bucketed gradient all-reduce at batch 1 per rank.  One line, n_gpus 8, global batch = 8 x per-GPU batch."""
+    ndev = torch.cuda.device_count()
+    env = {"ANODDPM_BENCH_SHARE_GPU": "1", "ANODDPM_BUCKET_MB": "128"} if ndev < 8 else {"ANODDPM_BUCKET_MB": "128"}
+    for cfg, extra in (("c1", []), ("c3", ["--batch", "1"])):
+        out = _bench("--gpus", "8", "--config", cfg, "--no-prof", *extra, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 8 and d["value"] > 0 and d["scaling"] == "weak" and "cpu_baseline" not in d
+        assert d["config"]["global_batch"] == 8 * d["config"]["per_gpu_batch"]
+        assert d["config"].get("ranks_share_devices", False) == (ndev < 8)
+        if cfg == "c3":
+            assert d["config"]["loss_finite"] is True and "data-parallel x8" in d["config"]["parallelism"]

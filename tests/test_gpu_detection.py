@@ -145,8 +145,42 @@ def test_detection_A_frequency_sweep(tmp_path, monkeypatch):
     recs = d.last_detection
     assert [r["freq"] for r in recs] == [7, 6, 5, 4, 3, 2, 1] and all(r["t_distance"] == 50 for r in recs)
     assert all(torch.isfinite(r["output"]).all() and r["output"].abs().max() <= 1.0 + 1e-6 for r in recs)
+    # every setting's chains are the caller's own tensor: the kept ReverseChain's buffer is reused, the records must not alias it
+    ptrs = [r["output"].data_ptr() for r in recs]
+    assert len(set(ptrs)) == len(ptrs)
+    assert all(not torch.equal(recs[0]["output"], r["output"]) for r in recs[1:])
     with pytest.raises(ValueError):
         d._avg_chains(m, x_0.repeat(2, 1, 1, 1), 5, 2)
+
+
+def test_forward_backward_results_are_independent_tensors_and_chains_can_be_released():
+    """the kept chain's buffer is overwritten by the next call -- a returned tensor must not change afterwards
+    (the reference returns a fresh tensor from every forward_backward, GaussianDiffusion.py:351-359)."""
+    import copy
+    import pickle
+    GD, m, d = tiny()
+    torch.manual_seed(11)
+    xa = torch.rand(2, 1, 32, 32, device=DEV) * 2 - 1
+    xb = torch.rand(2, 1, 32, 32, device=DEV) * 2 - 1
+    a = d.forward_backward(m, xa, see_whole_sequence=None, t_distance=6)
+    keep = a.clone()
+    b = d.forward_backward(m, xb, see_whole_sequence=None, t_distance=6)       # same (model, shape, noise): the chain is restarted
+    assert len(d._chains) == 1 and a.data_ptr() != b.data_ptr()
+    assert torch.equal(a, keep) and not torch.equal(a, b)
+    chain = next(iter(d._chains.values()))
+    assert a.data_ptr() != chain.x.data_ptr() and b.data_ptr() != chain.x.data_ptr()
+    # device-side caches do not travel: deepcopy works after sampling (CUDAGraph objects cannot be copied), and the copy samples
+    d2 = copy.deepcopy(d)
+    assert "_chains" not in d2.__dict__ and d2._dev == {} and len(d._chains) == 1
+    c = d2.forward_backward(m, xa, see_whole_sequence=None, t_distance=3)
+    assert torch.isfinite(c).all()
+    st = d.__getstate__()
+    assert "_chains" not in st and st["_dev"] == {}
+    pickle.dumps({k: v for k, v in st.items() if not callable(v)})            # everything but the (lambda) noise functions pickles
+    d.release_chains()
+    assert "_chains" not in d.__dict__
+    e = d.forward_backward(m, xa, see_whole_sequence=None, t_distance=6)        # builds and captures a fresh chain
+    assert len(d._chains) == 1 and torch.isfinite(e).all()
 
 
 def test_detection_A_fixedT_matches_reference_fixture():

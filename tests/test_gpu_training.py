@@ -383,3 +383,85 @@ def test_rccl_world_size_1_reducer_with_native_backward():
         assert torch.equal(results[0][2], results[1][2]) and torch.equal(results[0][1], results[1][1])
     finally:
         dist.destroy_process_group()
+
+
+def test_frozen_parameters_under_an_active_reducer():
+    """data-parallel fine-tuning with requires_grad=False parameters.  Frozen parameters are not in the flat buffers and
+    never get a .grad; with an active GradAllReducer (RCCL process group of one rank, force=True) the step must run -- every bucket
+    launched from the cut backward -- and equal the reducer-free step; frozen parameters stay untouched."""
+    import os
+    import torch.distributed as dist
+    import GaussianDiffusion as GD
+    from UNet import UNetModel
+    from anoddpm_amd.training import FlatBuffers, FusedAdamWEMA, GradAllReducer, train_step
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29537")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        torch.manual_seed(5)
+        base = UNetModel(32, 32, n_heads=2, attention_resolutions="16,8").to(DEV)
+        frozen = [k for k, _ in base.named_parameters() if k.startswith("down.1.") or k.startswith("middle.1.")]
+        assert len(frozen) > 8
+        diff = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(1000, "linear"), noise="gauss")
+        x = torch.rand(2, 1, 32, 32, device=DEV) * 2 - 1
+        noise = torch.randn(2, 1, 32, 32, device=DEV)
+        diff.noise_fn = lambda a, b: noise
+        results = []
+        for use_reducer in (False, True):
+            model = copy.deepcopy(base)
+            named = dict(model.named_parameters())
+            for k in frozen:
+                named[k].requires_grad_(False)
+            before = {k: named[k].detach().clone() for k in frozen}
+            flat = FlatBuffers(model)
+            assert not any(k in flat.names for k in frozen)
+            opt = FusedAdamWEMA(flat, None, lr=1e-3)
+            red = GradAllReducer(flat, bucket_bytes=1 << 20, force=True) if use_reducer else None
+            for _ in range(2):                                     # twice: the second step reuses the plan and its cut schedule
+                torch.manual_seed(77)
+                loss, _ = train_step(model, diff, x, {"train_start": False}, flat, red, opt)
+            if red is not None:
+                assert red.launched == len(red.buckets) and all(d is not None for _, d in red.last_launch_log)
+            assert all(named[k].grad is None and torch.equal(named[k], before[k]) for k in frozen)
+            results.append((loss.item(), flat.flat_param.clone(), flat.flat_grad.clone()))
+        assert results[0][0] == results[1][0]
+        assert torch.equal(results[0][2], results[1][2]) and torch.equal(results[0][1], results[1][1])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_mode_dropout_is_active_under_no_grad_and_absent_in_eval():
+    """nn.Dropout acts in train() mode whatever the grad mode (UNet.py:192) -- the sampling previews of the training
+    script run the train-mode model under no_grad.  Two no-grad forwards in train mode differ (fresh masks from torch's generator,
+    reproducible under manual_seed), eval mode is deterministic and equals the inference plan."""
+    from UNet import UNetModel
+    import GaussianDiffusion as GD
+    torch.manual_seed(3)
+    m = UNetModel(32, 32, n_heads=2, attention_resolutions="16,8", dropout=0.25).to(DEV)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith("out_layers.3.weight") or k.startswith("out.2."):
+                p.normal_(0, 0.05)                                  # the reference zero-initialises these: make dropout visible
+    x = torch.rand(2, 1, 32, 32, device=DEV) * 2 - 1
+    t = torch.tensor([10, 500], device=DEV)
+    m.train()
+    with torch.no_grad():
+        torch.manual_seed(1)
+        a = m(x, t)
+        b = m(x, t)
+        torch.manual_seed(1)
+        a2 = m(x, t)
+    assert not torch.equal(a, b) and torch.equal(a, a2)
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(x, t), m(x, t)
+    assert torch.equal(e1, e2) and not torch.equal(e1, a)
+    # the reverse chain takes the eager path for such a model (no captured graph with frozen masks)
+    d = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(100, "linear"), noise="gauss")
+    m.train()
+    ch = d.reverse_chain(m, x, 3, "gauss")
+    assert not ch.hip_model and not ch.use_graph
+    ch.step()
+    m.eval()
+    assert d.reverse_chain(m, x, 3, "gauss").hip_model
