@@ -47,7 +47,10 @@ class IgemmArgs(Structure):
                 ("ksplit", c_int32), ("cfg", c_int32), ("alpha", c_float), ("gn_ld", c_int32), ("stats", c_void_p), ("stats_rows", c_int32),
                 ("tail_csum", c_void_p), ("tail_other", c_void_p), ("tail_gamma", c_void_p), ("tail_beta", c_void_p),
                 ("tail_scale", c_void_p), ("tail_shift", c_void_p), ("tail_mean", c_void_p), ("tail_rstd", c_void_p),
-                ("tail_c1", c_int32), ("tail_groups", c_int32), ("tail_eps", c_float)]
+                ("tail_c1", c_int32), ("tail_groups", c_int32), ("tail_eps", c_float),
+                ("fold_stats0", c_void_p), ("fold_stats1", c_void_p), ("fold_gamma", c_void_p), ("fold_beta", c_void_p),
+                ("fold_rows0", c_int32), ("fold_rows1", c_int32), ("fold_fmt0", c_int32), ("fold_fmt1", c_int32),
+                ("fold_groups", c_int32), ("fold_eps", c_float)]
 
 
 class GnArgs(Structure):
@@ -253,7 +256,7 @@ SYMBOLS = [
     "anoddpm_simplex_perm_init", "anoddpm_simplex3_octaves_f64", "anoddpm_simplex3_octaves_f32",
     "anoddpm_simplex3_grid_f64", "anoddpm_simplex2_octaves_f64", "anoddpm_simplex2_grid_f64",
     "anoddpm_q_sample", "anoddpm_p_sample_update", "anoddpm_chain_advance",
-    "anoddpm_igemm", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
+    "anoddpm_igemm", "anoddpm_smallmap_tile", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
     "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_stem_stats_rows", "anoddpm_conv_head", "anoddpm_nhwc_to_nchw",
     "anoddpm_run_ops", "anoddpm_prof_enable", "anoddpm_prof_active", "anoddpm_prof_collect",
     "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map", "anoddpm_vlb_terms", "anoddpm_conv3x3_wgrad", "anoddpm_gn_silu_backward", "anoddpm_pack_conv3x3",

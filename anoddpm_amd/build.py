@@ -24,6 +24,7 @@ SOURCES = {
     "winograd43.hip": [],
     "winograd43r.hip": [],
     "pointwise.hip": [],
+    "smallmap.hip": [],
     "attention.hip": [],
     "executor.hip": [],
     "optim.hip": [],

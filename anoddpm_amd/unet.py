@@ -358,6 +358,11 @@ def _posemb_freqs(half):
 
 
 # ----------------------------------------------------------------------------- plan
+class _GnFold:
+    """A GroupNorm that is finished inside its consumer (anoddpm_igemm_args.fold_*): statistics sources (pointer, rows, format)
+    of the one or two concatenated tensors + the affine parameters."""
+
+
 def _use_winograd():
     import os
     return os.environ.get("ANODDPM_NO_WINOGRAD", "0") != "1"
@@ -369,7 +374,21 @@ def fused_attention_ok(L, ch):
             and os.environ.get("ANODDPM_NO_FUSED_ATTENTION", "0") != "1")
 
 
-def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None, c1=0, wino=True, f43=False, plain=False):
+def smallmap_ok(H, W, K, N, B, *, ks, a_mode=0, b_mode=0, heads=1, c0=None):
+    """cfg 5 (csrc/smallmap.hip: no split-K, batch folded into M, GroupNorm of the operand finished in the prologue) takes this
+    launch: every 1x1 / conv1d on maps of <= 256 pixels and the 3x3 convolutions on maps of <= ANODDPM_SMALLMAP_CONV_MAXP pixels
+    (default 64: at 16x16 the Winograd kernel's 2.25x fewer multiplies still win).  ANODDPM_NO_SMALLMAP=1 disables it."""
+    if os.environ.get("ANODDPM_NO_SMALLMAP", "0") == "1" or a_mode != 0 or b_mode != 0 or heads != 1:
+        return False
+    P = H * W
+    if ks == 3 and P > int(os.environ.get("ANODDPM_SMALLMAP_CONV_MAXP", 64)):
+        return False
+    if ks == 1 and P > int(os.environ.get("ANODDPM_SMALLMAP_GEMM_MAXP", 256)):
+        return False
+    return lib().anoddpm_smallmap_tile(ks, H, W, K, K if c0 is None else c0, N, B) != 0
+
+
+def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None, c1=0, wino=True, f43=False, plain=False, small=False):
     """Tile configuration (0: 128x128 direct, 1: 64x64 direct, 4: streaming 1x1 for large maps, 2: Winograd F(2x2,3x3),
     3: Winograd F(4x4,3x3) -- only when the
     caller can supply its weights, `f43`, and only on maps >= 64x64 with enough workgroups, where its 1.78x fewer MFMAs outweigh
@@ -379,6 +398,8 @@ def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None
     Winograd on small maps."""
     c0 = K if c0 is None else c0
     P = H * W
+    if small and smallmap_ok(H, W, K, N, Z, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads, c0=c0):
+        return 5, 1                                            # inference plan only (the training plan does not pass `small`)
     if (plain and ks == 1 and a_mode == 0 and b_mode == 0 and heads == 1 and K % 128 == 0 and K <= 512 and c0 % 32 == 0
             and P % 32 == 0 and N % 64 == 0 and os.environ.get("ANODDPM_NO_STREAM1X1", "0") != "1"):
         # cfg 4: streaming 1x1 (weights resident in LDS, one 32-pixel tile per wave pass) -- `plain` = no fused GroupNorm /
@@ -580,9 +601,10 @@ class _Plan:
             return scale, shift, mean, rstd
         return scale, shift
 
-    def gn(self, srcs, P, gamma_key, beta_key):
+    def gn(self, srcs, P, gamma_key, beta_key, fold=False):
         """GroupNorm(32) affine of one or two concatenated sources from their per-channel partial sums
-        (emitted by the producing igemm's epilogue).  Returns (scale, shift) [B][Ctot]."""
+        (emitted by the producing igemm's epilogue).  Returns (scale, shift) [B][Ctot] -- or, with `fold` (the only consumer is a
+        cfg 5 contraction, which finishes the GroupNorm in its own prologue), a _GnFold descriptor and NO launch."""
         B = self.B
         c0 = srcs[0][1]
         c1 = srcs[1][1] if len(srcs) > 1 else 0
@@ -594,6 +616,14 @@ class _Plan:
         job = self.gn_tail_job(srcs, gamma, beta)
         if job is not None:
             return job
+        if fold and C % 32 == 0:
+            d = _GnFold()
+            d.gamma, d.beta, d.groups, d.eps = gamma, beta, 32, 1e-5
+            d.src = []
+            for s in srcs:
+                kind, buf, extra = self.stats_of[s[0].data_ptr()]
+                d.src.append((buf.data_ptr(), extra if kind == "rows" else 1, 0 if kind == "rows" else 1))
+            return d
         st = GnFinalizeArgs()
         self.stats_source(st, 0, srcs[0][0], c0)
         if c1:
@@ -606,6 +636,10 @@ class _Plan:
         st.c0, st.c1, st.P, st.B, st.groups, st.eps = c0, c1, P, B, 32, 1e-5
         self.add(_lib.OP_GN_FINALIZE, st)
         return scale, shift
+
+    def small(self, H, W, K, N, *, ks, a_mode=0, c0=None):
+        """True when the contraction with these parameters will run on cfg 5 (so its GroupNorm can be folded into it)."""
+        return smallmap_ok(H, W, K, N, self.B, ks=ks, a_mode=a_mode, c0=c0)
 
     def attention(self, qkv, att, L, heads, ch, probs=None):
         """One fused launch for softmax(q^T k / sqrt(ch)) v (csrc/attention.hip) when the shape allows it; False otherwise (the
@@ -646,9 +680,16 @@ class _Plan:
         else:
             st.a0_bs, st.a0_hs = a_strides
             st.a1_bs = st.a1_hs = 0
-        st.gn_scale = gn[0].data_ptr() if gn else None
-        st.gn_shift = gn[1].data_ptr() if gn else None
+        fold = gn if isinstance(gn, _GnFold) else None
+        st.gn_scale = gn[0].data_ptr() if (gn and fold is None) else None
+        st.gn_shift = gn[1].data_ptr() if (gn and fold is None) else None
         st.gn_ld = K
+        st.fold_gamma = st.fold_beta = st.fold_stats0 = st.fold_stats1 = None
+        if fold is not None:
+            st.fold_gamma, st.fold_beta, st.fold_groups, st.fold_eps = fold.gamma, fold.beta, fold.groups, fold.eps
+            st.fold_stats0, st.fold_rows0, st.fold_fmt0 = fold.src[0]
+            if c1:
+                st.fold_stats1, st.fold_rows1, st.fold_fmt1 = fold.src[1]
         self._pending_bmat = (st, bmat, wino)
         st.b_bs, st.b_hs = b_strides
         st.bias = (bias if isinstance(bias, int) else bias.data_ptr()) if bias is not None else None
@@ -673,7 +714,9 @@ class _Plan:
         Z = B * heads
         cfg, ksplit = choose_conv_cfg(H, W, K, N, Z, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads, c0=c0, c1=c1,
                                       wino=bool(wino), f43=bool(wino43),
-                                      plain=(gn is None and act == 0 and not want_stats))
+                                      plain=(gn is None and act == 0 and not want_stats), small=True)
+        if fold is not None and cfg != 5:
+            raise _lib.AnoddpmError("plan: a folded GroupNorm needs a cfg 5 consumer")
         bm = 128 if cfg == 0 else 64
         st.cfg, st.ksplit = cfg, ksplit
         _st, _bmat, _wino = self._pending_bmat
@@ -688,7 +731,12 @@ class _Plan:
         if ksplit > 1:
             self._ws_need = max(self._ws_need, ksplit * Z * P * N)
         st.stats = None
-        if want_stats and ksplit == 1 and heads == 1:
+        if want_stats and cfg == 5:
+            rows = P // (16 * (lib().anoddpm_smallmap_tile(ks, H, W, K, c0, N, B) >> 4))     # one row per TM-pixel tile
+            stats = self.buf(B, rows, N, 2)
+            st.stats = stats.data_ptr()
+            self.stats_of[out.data_ptr()] = ("rows", stats, rows)
+        elif want_stats and ksplit == 1 and heads == 1:
             # the epilogue emits per-channel {sum, sumsq} per wave-row of every pixel tile
             if cfg in (2, 3):
                 tiles = (H // 16) * (W // 16)
@@ -777,7 +825,8 @@ class _Plan:
             cin = sum(s[1] for s in srcs)
             Hout = Hin * 2 if resample == "up" else (Hin // 2 if resample == "down" else Hin)
             Pin, Pout = Hin * Hin, Hout * Hout
-            g1 = self.gn(srcs, Pin, prefix + ".in_layers.0.weight", prefix + ".in_layers.0.bias")
+            g1 = self.gn(srcs, Pin, prefix + ".in_layers.0.weight", prefix + ".in_layers.0.bias",
+                         fold=(resample is None and self.small(Hout, Hout, cin, cout, ks=3, c0=srcs[0][1])))
             h1 = self.buf(B, Pout, cout)
             pooled = None
             if resample == "down" and len(srcs) == 1 and os.environ.get("ANODDPM_NO_POOL_ACT", "0") != "1":
@@ -798,7 +847,8 @@ class _Plan:
                        wino43=lambda p=prefix: self.packed(p + ".in_layers.2.weight", "wino43"),
                        bias=self.packed(prefix + ".in_layers.2.bias", "copy"),
                        temb=emb_all.data_ptr() + 4 * offs[prefix], temb_ld=tot, out=h1, want_stats=True)
-            g2 = self.gn([(h1, cout)], Pout, prefix + ".out_layers.0.weight", prefix + ".out_layers.0.bias")
+            g2 = self.gn([(h1, cout)], Pout, prefix + ".out_layers.0.weight", prefix + ".out_layers.0.bias",
+                         fold=self.small(Hout, Hout, cout, cout, ks=3))
             if cin != cout:
                 sk = self.buf(B, Pout, cout)
                 assert resample is None
@@ -833,7 +883,7 @@ class _Plan:
             ch = C // heads
             if ch % 4:
                 raise NotImplementedError(f"attention head width {ch} must be a multiple of 4")
-            g = self.gn([(x, C)], L, prefix + ".norm.weight", prefix + ".norm.bias")
+            g = self.gn([(x, C)], L, prefix + ".norm.weight", prefix + ".norm.bias", fold=self.small(Hc, Hc, C, 3 * C, ks=1))
             qkv = self.buf(B, L, 3 * C)
             self.igemm(srcs=[(x, C)], H=Hc, W=Hc, ks=1, N=3 * C, gn=g, act=0, kind="qkvproj",
                        bmat=self.packed(prefix + ".to_qkv.weight", "conv"),

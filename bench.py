@@ -413,8 +413,10 @@ def run_reverse(c, args, cfg):
                 (14, [e for e in plan.igemm_log if e.get("f43")], 36.0 / (16 * 9)),
             "wino_kernel (Winograd F(2x2,3x3) 3x3 convolutions, v_mfma_f32_32x32x2_f32)":
                 (12, [e for e in plan.igemm_log if e["wino"] and not e.get("f43")], 4.0 / 9.0),
-            "igemm_kernel / pointwise_stream_kernel (direct implicit GEMM: 1x1, 8x8 3x3, qkv/proj; v_mfma_f32_32x32x2_f32)":
-                (_lib.OP_IGEMM, [e for e in plan.igemm_log if not e["wino"]], 1.0),
+            "igemm_kernel / pointwise_stream_kernel (direct implicit GEMM with 64x64 / 128x128 tiles, streaming 1x1; v_mfma_f32_32x32x2_f32)":
+                (_lib.OP_IGEMM, [e for e in plan.igemm_log if not e["wino"] and e["cfg"] != 5], 1.0),
+            "smallmap_kernel (maps <= 16x16 without split-K: 8x8 3x3, 1x1, qkv / proj, GroupNorm finalize in the prologue; v_mfma_f32_16x16x4_f32)":
+                (13, [e for e in plan.igemm_log if e["cfg"] == 5], 1.0),
             "attention_kernel (fused QK^T - softmax - AV per attention block, v_mfma_f32_16x16x4_f32)":
                 (_lib.OP_ATTENTION, getattr(plan, "attention_log", []), 1.0),
         }
@@ -455,11 +457,11 @@ def run_reverse(c, args, cfg):
                                          "algorithmic_tflops": tf(flops_per_step, ig_ms),
                                          "ms_per_step": ig_ms / args.steps, "algorithmic_gflop_per_step": flops_per_step / 1e9},
                     "class_ms_per_step": {name: ms[code] / args.steps for name, code in
-                                          (("winograd_f43", 14), ("winograd_f23", 12), ("igemm_direct", 1), ("gn_stats", 2), ("softmax", 3), ("resample", 4),
+                                          (("winograd_f43", 14), ("winograd_f23", 12), ("igemm_direct", 1), ("smallmap", 13), ("gn_stats", 2), ("softmax", 3), ("resample", 4),
                                            ("linear", 5), ("posemb", 6), ("stem", 7), ("layout", 8), ("chan_stats", 9),
                                            ("gn_finalize", 10), ("head", 11), ("attention", 26))},
                     "instrumented_ms_per_step": prof_ms_per_step}
-        prefix = {14: ["wino43_kernel", "wino43r_kernel"], 12: ["wino_kernel"], _lib.OP_IGEMM: ["igemm_kernel", "pointwise_stream_kernel"],
+        prefix = {14: ["wino43_kernel", "wino43r_kernel"], 12: ["wino_kernel"], _lib.OP_IGEMM: ["igemm_kernel", "pointwise_stream_kernel"], 13: ["smallmap_kernel"],
                   _lib.OP_ATTENTION: ["attention_kernel"]}[classes[dom][0]]
         tr = committed_traffic(args.config, B, prefix)
         if tr is not None:

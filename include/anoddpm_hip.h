@@ -141,7 +141,7 @@ enum {
     ANODDPM_OP_CHAN_STATS = 9,   /* anoddpm_chan_stats_args  */
     ANODDPM_OP_GN_FINALIZE = 10, /* anoddpm_gn_finalize_args */
     ANODDPM_OP_HEAD = 11,        /* anoddpm_head_args        */
-    /* 12 is the profiler's slot for Winograd launches of ANODDPM_OP_IGEMM */
+    /* 12 / 14 are the profiler's slots for the Winograd F(2x2) / F(4x4) launches of ANODDPM_OP_IGEMM, 13 for its cfg 5 launches */
     /* training step (backward twins and per-step weight packing) */
     ANODDPM_OP_WGRAD3 = 16,      /* anoddpm_wgrad_args        */
     ANODDPM_OP_WGRAD1 = 17,      /* anoddpm_wgrad1_args       */
@@ -200,7 +200,8 @@ typedef struct {
                                        bmat = transformed weights [16][K/4][N][4] (G g G^T); 3: Winograd F(4x4,3x3): as 2 with
                                        N % 64 == 0, ksplit 1, bmat [36][K/4][N][4]; statistics: one row per 16x16 patch;
                                        4: streaming 1x1 for large maps (pointwise.hip): ks 1, a_mode 0, b_mode 0, heads 1, ksplit 1,
-                                       no gn / act / stats, K % 128 == 0, K <= 512, c0 % 32 == 0, H*W % 32 == 0, N % 64 == 0 */
+                                       no gn / act / stats, K % 128 == 0, K <= 512, c0 % 32 == 0, H*W % 32 == 0, N % 64 == 0;
+                                       5: small maps without split-K (smallmap.hip), see anoddpm_smallmap_tile */
     float alpha;
     int32_t gn_ld;                  /* row length of gn_scale/gn_shift (= K) */
     float *stats;                   /* or NULL: per-channel partial sums of the OUTPUT, [B][tiles*2][N][2]
@@ -222,9 +223,26 @@ typedef struct {
     float *tail_mean, *tail_rstd;   /* optional [B][tail_groups] (training) */
     int32_t tail_c1, tail_groups;
     float tail_eps;
+    /* cfg 5 only (smallmap.hip): the GroupNorm of the A operand FINISHED IN THE KERNEL'S PROLOGUE from its producers' statistics
+     * (UNet.py:409-411 over torch.cat([h, skip], 1)) -- the arguments of anoddpm_gn_finalize, consumed in place: no finalize
+     * launch between producer and consumer.  With fold_gamma set, gn_scale / gn_shift are ignored.  fp64 fold in a fixed order
+     * (rows ascending per channel, channels ascending per group), biased variance, fold_eps. */
+    const float *fold_stats0, *fold_stats1;   /* as anoddpm_gn_finalize_args.stats0 / stats1 */
+    const float *fold_gamma, *fold_beta;      /* [K], or NULL: no fold */
+    int32_t fold_rows0, fold_rows1, fold_fmt0, fold_fmt1;
+    int32_t fold_groups;
+    float fold_eps;
 } anoddpm_igemm_args;
 
 int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream);
+
+/* cfg 5 of anoddpm_igemm: contractions on maps of <= 256 pixels WITHOUT split-K (smallmap.hip) -- the batch is folded into the
+ * GEMM's M, a workgroup owns TM output rows x TN channels over all of K' = taps * K and its eight waves split K' (fold through
+ * LDS, fixed order): one launch per layer instead of main + split-K tail (+ GroupNorm finalize, see fold_*).  ks 1 or 3, a_mode 0,
+ * b_mode 0, heads 1, ksplit 1, H * W <= 256, W in {4, 8, 16}, K % 16 == 0, 16 <= K <= 1024, N % 32 == 0.  `stats` rows: one per
+ * TM-pixel tile, [B][P / TM][N][2].  Returns the tile the launch will use as (TM / 16) * 16 + TN / 16, or 0 when the shape is
+ * not taken (the caller then uses cfg 0 / 1 / 2). */
+int anoddpm_smallmap_tile(int32_t ks, int32_t H, int32_t W, int32_t K, int32_t c0, int32_t N, int32_t B);
 
 /* GroupNorm statistics -> per-sample per-channel affine (UNet.py:409-411 / nn.GroupNorm(32,C),
  * eps 1e-5, biased variance), over up to two concatenated NHWC sources:

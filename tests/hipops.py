@@ -108,7 +108,7 @@ _LAST_KEEP = None
 
 
 def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=None, res=None, cfg=0, ksplit=1,
-               stats_out=None, gn_tail=None):
+               stats_out=None, gn_tail=None, fold=None):
     """srcs: NHWC sources; w: OIHW weights.  Returns NHWC [B,Hout,Hout,N]."""
     dev = srcs[0].device
     B = srcs[0].shape[0]
@@ -138,7 +138,20 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
     st.cfg, st.ksplit = cfg, ksplit
     ws = torch.empty(max(1, ksplit * B * P * N), device=dev) if ksplit > 1 else None
     st.ws = ws.data_ptr() if ws is not None else None
-    if gn_tail is not None:
+    if fold is not None:
+        # cfg 5: the operand's GroupNorm finished in the kernel's prologue; fold = dict(stats=[(tensor, fmt)] per source, gamma, beta)
+        st.fold_gamma, st.fold_beta, st.fold_groups, st.fold_eps = fold["gamma"].data_ptr(), fold["beta"].data_ptr(), 32, 1e-5
+        (s0, f0) = fold["stats"][0]
+        st.fold_stats0, st.fold_rows0, st.fold_fmt0 = s0.data_ptr(), (1 if f0 else s0.shape[1]), f0
+        if c1:
+            (s1, f1) = fold["stats"][1]
+            st.fold_stats1, st.fold_rows1, st.fold_fmt1 = s1.data_ptr(), (1 if f1 else s1.shape[1]), f1
+    if cfg == 5 and stats_out is not None:
+        tm = 16 * (lib().anoddpm_smallmap_tile(ks, Hout, Hout, c0 + c1, c0, N, B) >> 4)
+        stats = torch.full((B, P // tm, N, 2), float("nan"), device=dev)
+        st.stats = stats.data_ptr()
+        stats_out.append(stats)
+    elif gn_tail is not None:
         # split-K tail with the consumer GroupNorm folded in: gn_tail = dict(gamma, beta[, other_csum], want_mean) -> filled with
         # csum / scale / shift / mean / rstd
         assert ksplit > 1
@@ -174,7 +187,7 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
     check(lib().anoddpm_igemm(ctypes.byref(st), current_stream()), "igemm")
     torch.cuda.synchronize()
     global LAST_IGEMM, _LAST_KEEP
-    LAST_IGEMM, _LAST_KEEP = st, (srcs, wp, out, gn, bias, temb, res, ws, gn_tail)        # tools/bench_conv.py re-launches the prepared call
+    LAST_IGEMM, _LAST_KEEP = st, (srcs, wp, out, gn, bias, temb, res, ws, gn_tail, fold)        # tools/bench_conv.py re-launches the prepared call
     return out
 
 

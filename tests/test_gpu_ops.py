@@ -714,3 +714,93 @@ def test_splitk_tail_with_fused_groupnorm(cfg, ks, H, K, N, c1, ksplit):
     check(lib().anoddpm_gn_finalize(ctypes.byref(st), current_stream()), "gn_finalize")
     assert (sc - tail["scale"]).abs().max().item() < 1e-6 * tail["scale"].abs().max().item()
     assert (sh - tail["shift"]).abs().max().item() < 1e-5 * max(tail["shift"].abs().max().item(), 1.0)
+
+
+# ---- cfg 5: small maps without split-K (csrc/smallmap.hip), GroupNorm of the operand finished in the prologue -----------------
+SMALL_CASES = [
+    # B, (c0, c1), N, H, ks, gn ("no" / "given" / "fold" / "fold64": folded from fp64 sums), act, temb, res
+    (4, (512, 0), 512, 8, 3, "fold", 1, True, False),        # 8x8 ResBlock conv1: 16 x 32 tiles, two K chunks
+    (4, (512, 0), 512, 8, 3, "fold", 1, False, True),        # conv2 + residual
+    (4, (512, 512), 512, 8, 3, "fold", 1, True, False),      # up path: virtual concat, four chunks
+    (4, (512, 512), 512, 8, 1, "no", 0, False, False),       # 1x1 skip over the concat
+    (4, (512, 0), 1536, 8, 1, "fold", 0, False, False),      # to_qkv: GroupNorm, no SiLU
+    (4, (512, 0), 512, 8, 1, "no", 0, False, True),          # proj_out + residual
+    (4, (512, 0), 1536, 16, 1, "given", 0, False, False),    # 16x16 to_qkv: 32 x 96 tiles, precomputed affine
+    (4, (512, 0), 512, 16, 1, "no", 0, False, True),         # 16x16 proj_out
+    (4, (768, 256), 512, 16, 1, "no", 0, False, False),      # 16x16 skip over a concat whose first source is not a chunk multiple
+    (2, (96, 32), 96, 8, 3, "fold", 1, True, True),          # narrow test-model widths: partial chunk, K tail inside a wave's slice
+    (3, (64, 0), 32, 4, 3, "fold64", 1, False, True),        # 4x4 level: one tile per image; statistics given as fp64 sums
+    (2, (128, 0), 384, 16, 1, "fold", 0, False, False),      # 16x16 qkv at test width
+    (1, (256, 0), 256, 16, 3, "given", 1, True, True),       # batch 1 (configuration 5): 16x16 3x3, 16-row tiles
+    (2, (32, 0), 64, 8, 3, "fold", 1, False, False),         # K = 32: seven of eight waves idle
+]
+
+
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_smallmap_contraction(case):
+    """anoddpm_igemm cfg 5 against torch on the same fused expression: GroupNorm (folded from statistics rows, from fp64 sums, or
+    given) -> SiLU -> conv / 1x1 over one or two sources -> + bias + temb + residual; and its output statistics rows."""
+    import hipops
+    from anoddpm_amd._lib import lib
+    B, (c0, c1), N, H, ks, gn_mode, act, use_temb, use_res = case
+    C = c0 + c1
+    x = rnd(B, C, H, H, seed=21) * 1.5 + 0.3
+    w = rnd(N, C, ks, ks, seed=22, scale=1.0 / math.sqrt(C * ks * ks))
+    b = rnd(N, seed=23, scale=0.1)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=24), 0.1 * rnd(C, seed=25)
+    temb = rnd(B, N, seed=26) if use_temb else None
+    res = rnd(B, N, H, H, seed=27) if use_res else None
+    h = x
+    if gn_mode != "no":
+        h = F.group_norm(h, 32, gamma, beta, eps=1e-5)
+    if act:
+        h = F.silu(h)
+    ref = F.conv2d(h, w, b, padding=ks // 2)
+    if temb is not None:
+        ref = ref + temb[:, :, None, None]
+    if res is not None:
+        ref = ref + res
+    xs = hipops.nhwc(x.to(dev()))
+    srcs = [xs[..., :c0].contiguous()] + ([xs[..., c0:].contiguous()] if c1 else [])
+    assert lib().anoddpm_smallmap_tile(ks, H, H, C, c0, N, B) != 0
+    gn = fold = None
+    if gn_mode == "given":
+        gn = hipops.gn_affine(srcs, gamma.to(dev()), beta.to(dev()))
+    elif gn_mode in ("fold", "fold64"):
+        stats = []
+        for i, s_ in enumerate(srcs):
+            rows = hipops.chan_stats(s_, nslab=(3 if H > 4 else 1) + i)          # different row counts per source
+            if gn_mode == "fold64":
+                stats.append((rows.double().sum(1).contiguous(), 1))                 # [B][c][2] fp64, as a split-K tail's tail_csum
+            else:
+                stats.append((rows, 0))
+        fold = dict(stats=stats, gamma=gamma.to(dev()), beta=beta.to(dev()))
+    st = []
+    got = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), Hout=H, ks=ks, gn=gn, act=act, fold=fold,
+                            temb=temb.to(dev()) if temb is not None else None,
+                            res=hipops.nhwc(res.to(dev())) if res is not None else None, cfg=5, stats_out=st)
+    assert relerr(hipops.nchw(got), ref) < TOL
+    # statistics rows of the output: their GroupNorm equals torch's on the result
+    g2, b2 = 1 + 0.1 * rnd(N, seed=28), 0.1 * rnd(N, seed=29)
+    sc, sh = hipops.gn_finalize(st, g2.to(dev()), b2.to(dev()), H * H)
+    assert relerr(hipops.nchw(got * sc[:, None, None, :] + sh[:, None, None, :]), F.group_norm(ref, 32, g2, b2, eps=1e-5)) < TOL
+    # deterministic: the cross-wave fold has a fixed order
+    got2 = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), Hout=H, ks=ks, gn=gn, act=act, fold=fold,
+                             temb=temb.to(dev()) if temb is not None else None,
+                             res=hipops.nhwc(res.to(dev())) if res is not None else None, cfg=5)
+    assert torch.equal(got, got2)
+
+
+def test_smallmap_rejects_what_it_does_not_take():
+    import hipops
+    from anoddpm_amd._lib import AnoddpmError, lib
+    assert lib().anoddpm_smallmap_tile(3, 32, 32, 256, 256, 256, 4) == 0          # > 256 pixels
+    assert lib().anoddpm_smallmap_tile(3, 8, 8, 512, 512, 500, 4) == 0            # N % 32
+    assert lib().anoddpm_smallmap_tile(1, 8, 8, 2048, 2048, 512, 4) == 0          # K > 1024
+    x = hipops.nhwc(rnd(1, 64, 32, 32, seed=1).to(dev()))
+    with pytest.raises(AnoddpmError):
+        hipops.conv_igemm([x], rnd(64, 64, 3, 3, seed=2).to(dev()), None, Hout=32, ks=3, cfg=5)
+    x8 = hipops.nhwc(rnd(1, 64, 8, 8, seed=1).to(dev()))
+    with pytest.raises(AnoddpmError):                                              # the fold is a cfg 5 feature
+        hipops.conv_igemm([x8], rnd(64, 64, 3, 3, seed=2).to(dev()), None, Hout=8, ks=3, cfg=1,
+                          fold=dict(stats=[(hipops.chan_stats(x8, 1), 0)], gamma=torch.ones(64, device=dev()), beta=torch.zeros(64, device=dev())))
