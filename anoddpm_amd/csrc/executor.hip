@@ -23,6 +23,8 @@ struct ProfState {
     bool on = false;
     std::vector<hipEvent_t> pool;       // pairs: start, stop
     std::vector<int> codes;
+    std::vector<float> last_ms;         // per recorded op of the last collect, in launch order
+    std::vector<int> last_codes;
     size_t used = 0;
     double ms[ANODDPM_OP_MAX] = {0};
     int64_t launches[ANODDPM_OP_MAX] = {0};
@@ -160,6 +162,8 @@ extern "C" int anoddpm_prof_active(void) { return g_prof.on ? 1 : 0; }
 extern "C" int anoddpm_prof_collect(double *ms_per_code, int64_t *launches_per_code)
 {
     ANODDPM_REQUIRE(ms_per_code && launches_per_code, "prof_collect: null pointer");
+    g_prof.last_ms.clear();
+    g_prof.last_codes.clear();
     for (size_t i = 0; i < g_prof.codes.size(); ++i) {
         hipEvent_t e0 = g_prof.pool[2 * i], e1 = g_prof.pool[2 * i + 1];
         if (hipEventSynchronize(e1) != hipSuccess) { set_error("prof_collect: event sync failed"); return ANODDPM_ELAUNCH; }
@@ -167,11 +171,25 @@ extern "C" int anoddpm_prof_collect(double *ms_per_code, int64_t *launches_per_c
         if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { set_error("prof_collect: elapsed failed"); return ANODDPM_ELAUNCH; }
         g_prof.ms[g_prof.codes[i]] += ms;
         g_prof.launches[g_prof.codes[i]] += 1;
+        g_prof.last_ms.push_back(ms);
+        g_prof.last_codes.push_back(g_prof.codes[i]);
     }
     g_prof.codes.clear();
     g_prof.used = 0;
     for (int c = 0; c < ANODDPM_OP_MAX; ++c) { ms_per_code[c] = g_prof.ms[c]; launches_per_code[c] = g_prof.launches[c]; }
     return ANODDPM_OK;
+}
+
+// The ops of the last anoddpm_prof_collect in launch order: their profiler code and HIP-event time.  Returns the count (at most cap
+// entries are written); with a plan's op list beside it this is a per-layer profile without an external tracer.
+extern "C" int anoddpm_prof_list(int32_t *codes, float *ms, int32_t cap)
+{
+    const int n = (int)g_prof.last_ms.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (codes) codes[i] = g_prof.last_codes[i];
+        if (ms) ms[i] = g_prof.last_ms[i];
+    }
+    return n;
 }
 
 // sizeof() of every ABI struct, so that the Python ctypes mirror can verify its layout at load time.

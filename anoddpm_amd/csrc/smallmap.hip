@@ -338,7 +338,9 @@ int smallmap_tile(int ks, int H, int W, int K, int c0, int N, int B)
     if (!(ks == 1 || ks == 3) || P > 256 || P < 16 || (W != 4 && W != 8 && W != 16) || H * W != P) return 0;
     if (K % 16 || c0 % 4 || K > 1024 || N % 32 || K < 16) return 0;
     const int M = B * P;
-    static const int cand[4][2] = {{2, 6}, {2, 2}, {1, 6}, {1, 2}};
+    // wide column tiles first: every workgroup of a row tile stages (and normalises) the same operand rows, so fewer, wider
+    // column tiles mean less redundant prologue work (to_qkv at 8x8: 16 x 96 tiles = 256 workgroups instead of 32 x 32 = 384)
+    static const int cand[4][2] = {{2, 6}, {1, 6}, {2, 2}, {1, 2}};
     int best = 0;
     for (int c = 0; c < 4; ++c) {
         const int rt = cand[c][0], ct = cand[c][1];

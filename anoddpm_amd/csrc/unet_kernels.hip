@@ -758,6 +758,116 @@ __global__ __launch_bounds__(256) void conv_head_mfma_kernel(anoddpm_head_args a
     }
 }
 
+// Round 4 form of the kernel above: the same contraction, issue-trimmed.  The inner loop of the round-3 kernel was a dependent
+// chain per value wrapped in an exec-mask branch (the `inside` test): saveexec / branch / restore around seven dependent
+// instructions, 129 SIMD cycles per 64 values against 32 (MFMA) + ~38 (affine + SiLU) of issue.  Here
+//   * the zero padding of the activated map moves to the tile's product rows: out-of-image pixels are zeroed when the wave writes
+//     its D rows to LDS (four selects per tile row instead of 32 masked SiLUs); their loads are clamped in-bounds, so what
+//     they compute is finite and discarded;
+//   * the four values of a float4 run as four independent chains in straight-line code;
+//   * the input tile is 16 x 28 (14 x 26 outputs): 1.23x halo instead of 1.31x;
+//   * the next tile row's channels are requested before the current row is computed (two rows in registers).
+constexpr int HT2R = 28;                                            // input tile rows; HT2R - 2 = 26 output rows: 256 rows = 10 strips, and
+                                                                    // 19 x 10 x 4 images = 760 workgroups = 2.97 per CU (30-row strips: 684 = 2.67
+                                                                    // per CU, i.e. a third of the CUs carry three workgroups and set the time)
+
+template <int COUT, int NJ>
+__global__ __launch_bounds__(256) void conv_head_mfma2_kernel(anoddpm_head_args a)
+{
+    constexpr int NT = (9 * COUT + 15) / 16;
+    constexpr int RPW = HT2R / 4;                                   // tile rows per wave
+    __shared__ float T[9 * COUT][HT2R * HT];
+    __shared__ hf32x4 aff[2][NJ * 4];
+    const int C = NJ * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int tiles_x = (a.W + HT - 3) / (HT - 2);
+    const int b = blockIdx.y;
+    const int oy0 = (blockIdx.x / tiles_x) * (HT2R - 2), ox0 = (blockIdx.x % tiles_x) * (HT - 2);
+    for (int i = tid; i < NJ * 4; i += 256) {
+        aff[0][i] = reinterpret_cast<const hf32x4 *>(a.gn_scale + (int64_t)b * C)[i];
+        aff[1][i] = reinterpret_cast<const hf32x4 *>(a.gn_shift + (int64_t)b * C)[i];
+    }
+    float bw[NT][NJ][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + m;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                bw[nt][j][s] = n < 9 * COUT ? a.w[((int64_t)(n / COUT) * C + 16 * j + 4 * q + s) * COUT + n % COUT] : 0.f;
+    }
+    // this lane's input column (clamped) and, for the D rows it will hold (pixels 4 q .. 4 q + 3 of a tile row), their validity
+    const int gx = ox0 + m - 1;
+    const int gxc = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
+    bool colok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int x = ox0 + 4 * q + r - 1; colok[r] = x >= 0 && x < a.W; }
+    auto row_ptr = [&](int mt) {
+        const int gy = oy0 + wave * RPW + mt - 1;
+        const int gyc = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+        return a.x + (((int64_t)b * a.H + gyc) * a.W + gxc) * C + 4 * q;
+    };
+    hf32x4 v[2][NJ];
+    {
+        const float *xp = row_ptr(0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) v[0][j] = *reinterpret_cast<const hf32x4 *>(xp + 16 * j);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < RPW; ++mt) {
+        const int cur = mt & 1;
+        if (mt + 1 < RPW) {
+            const float *xp = row_ptr(mt + 1);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) v[cur ^ 1][j] = *reinterpret_cast<const hf32x4 *>(xp + 16 * j);
+        }
+        hf32x4 accr[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accr[nt] = hf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const hf32x4 x4 = v[cur][j] * aff[0][4 * j + q] + aff[1][4 * j + q];
+            hf32x4 e;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) e[s] = __expf(-x4[s]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) e[s] = x4[s] * __builtin_amdgcn_rcpf(1.0f + e[s]);      // silu_f, four chains side by side
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) accr[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[s], bw[nt][j][s], accr[nt], 0, 0, 0);
+        }
+        // D[row = 4 q + r][col = m]: zero padding of the ACTIVATED map = zero product rows of out-of-image pixels
+        const int gy = oy0 + wave * RPW + mt - 1;
+        const bool rowok = gy >= 0 && gy < a.H;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            hf32x4 d = accr[nt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r] = (rowok && colok[r]) ? d[r] : 0.f;
+            const int n = nt * 16 + m;
+            if (n < 9 * COUT) *reinterpret_cast<hf32x4 *>(&T[n][(wave * RPW + mt) * HT + 4 * q]) = d;
+        }
+    }
+    __syncthreads();
+    for (int p = tid; p < (HT2R - 2) * (HT - 2); p += 256) {
+        const int ty = p / (HT - 2) + 1, tx = p % (HT - 2) + 1;       // tile coordinates of the output pixel, 1 .. edge - 2
+        const int oy = oy0 + ty - 1, ox = ox0 + tx - 1;
+        if (oy < a.H && ox < a.W) {
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                float r = a.bias ? a.bias[o] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) r += T[k * COUT + o][(ty + k / 3 - 1) * HT + tx + k % 3 - 1];
+                a.out[(((int64_t)b * COUT + o) * a.H + oy) * a.W + ox] = r;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(anoddpm_layout_args a)
 {
     const int64_t total = (int64_t)a.B * a.C * a.P;
@@ -955,6 +1065,14 @@ extern "C" int anoddpm_conv_head(const anoddpm_head_args *a, void *stream)
         hipStream_t s = anoddpm::as_stream(stream);
         // matrix-pipe form for the shipped widths (B operand in registers: NT * NJ <= 24); ANODDPM_DEBUG4=2: the VALU tap kernel
         const bool aligned = ((uintptr_t)a->x | (uintptr_t)a->gn_scale | (uintptr_t)a->gn_shift) % 16 == 0;
+        if (aligned && anoddpm::g_debug[4] == 0 && a->Cout == 1 && (a->C == 128 || a->C == 64)) {
+            // round 4: branch-free 16 x 32 tiles (ANODDPM_DEBUG4=3 keeps the round-3 kernel)
+            const int ty2 = (a->H + HT2R - 3) / (HT2R - 2);
+            dim3 grid2(tx * ty2, a->B);
+            if (a->C == 128) hipLaunchKernelGGL((conv_head_mfma2_kernel<1, 8>), grid2, dim3(256), 0, s, *a);
+            else             hipLaunchKernelGGL((conv_head_mfma2_kernel<1, 4>), grid2, dim3(256), 0, s, *a);
+            return anoddpm::check_launch("conv_head");
+        }
         if (aligned && anoddpm::g_debug[4] != 2) {
 #define HEAD_MFMA(CO, NJ_) { hipLaunchKernelGGL((conv_head_mfma_kernel<CO, NJ_>), grid, dim3(256), 0, s, *a); return anoddpm::check_launch("conv_head"); }
             if (a->C == 128) { if (a->Cout == 1) HEAD_MFMA(1, 8) if (a->Cout == 2) HEAD_MFMA(2, 8) if (a->Cout == 3) HEAD_MFMA(3, 8) if (a->Cout == 4) HEAD_MFMA(4, 8) }

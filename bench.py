@@ -320,6 +320,43 @@ def committed_traffic(config_name, batch, kernel_prefixes):
             "measured_on_sources": d.get("sources_hash"), "running_sources": now, "stale": d.get("sources_hash") != now}
 
 
+def per_op_profile(L, plan, steps):
+    """Average HIP-event microseconds of every op of the plan (launch order) over the instrumented steps, or None when the
+    recorded list does not tile into steps (other run_ops calls were recorded too)."""
+    n = L.anoddpm_prof_list(None, None, 0)
+    nops = len(plan.ops)
+    if n != nops * steps:
+        return None
+    codes = (ctypes.c_int32 * n)()
+    msv = (ctypes.c_float * n)()
+    L.anoddpm_prof_list(codes, msv, n)
+    return [1000.0 * sum(msv[s * nops + i] for s in range(steps)) / steps for i in range(nops)]
+
+
+def dump_layers(path, plan, per_op_us):
+    """Per-layer profile of the contraction launches (what tools/by_layer.py builds from a rocprofv3 trace), from the executor's own
+    HIP events: kind, shape, configuration, launches per step, average us, algorithmic / executed TFLOP/s."""
+    from collections import defaultdict
+    from anoddpm_amd import _lib
+    agg = defaultdict(lambda: [0, 0.0, 0.0])
+    it = iter(plan.igemm_log)
+    for (code, st), us in zip(plan.ops, per_op_us):
+        if code != _lib.OP_IGEMM:
+            continue
+        e = next(it)
+        key = (e["kind"], e["H"], e["K"], e["N"], e["ks"], e["a_mode"], e["cfg"], e["ksplit"])
+        a = agg[key]
+        a[0] += 1
+        a[1] += us
+        a[2] = e["gflop"]
+    with open(path, "w") as f:
+        f.write("kind,H,K,N,ks,a_mode,cfg,ksplit,launches_per_step,avg_us,algorithmic_TFLOPs,executed_TFLOPs,total_us_per_step\n")
+        for k, (n, us, gf) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            avg = us / n
+            ex = {2: 4.0 / 9.0, 3: 0.25}.get(k[6], 1.0)
+            f.write(",".join(str(v) for v in k) + f",{n},{avg:.1f},{gf / avg * 1e3:.1f},{gf * ex / avg * 1e3:.1f},{us:.0f}\n")
+
+
 PEAK_HBM_GBPS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (about 6.3 TB/s achievable)
 ACHIEVABLE_HBM_GBPS = 6300.0          # MI355X_MICROARCH.md: 6.29 TB/s measured with a float4 copy (79 % of peak)
 
@@ -405,6 +442,7 @@ def run_reverse(c, args, cfg):
         cnt = (ctypes.c_int64 * _lib.OP_MAX)()
         _lib.check(L.anoddpm_prof_collect(ms, cnt), "prof_collect")
         L.anoddpm_prof_enable(0)
+        per_op_us = per_op_profile(L, plan, args.steps)
         pu_ms_tot, pu_n, _ = pu_t.finish()
         sx_ms_tot, sx_n, _ = sx_t.finish()
         # contraction classes: profiler slot, launches of the plan, fraction of the direct-convolution FLOPs the matrix pipe executes
@@ -483,6 +521,20 @@ def run_reverse(c, args, cfg):
                           "frac_of_8TBps": pu_bytes / (pu_ms / 1000.0) / 1e9 / PEAK_HBM_GBPS,
                           "note": "4 MB per launch at batch 4: a few microseconds of data behind a launch; HIP-event pair around the launch "
                                   "inside the instrumented step (stream busy before and after)"})
+        if per_op_us is not None:
+            # the large resample launches one by one (the class row above averages them with five launch-latency-bound ones of < 10 MB)
+            for (code, st), us in zip(plan.ops, per_op_us):
+                if code == _lib.OP_RESAMPLE:
+                    pin = st.B * st.H * st.W * st.C
+                    pout = pin * 4 if st.mode == 1 else pin // 4
+                    nbytes = 4.0 * (pin + pout + (pout if st.out_act else 0))
+                    if nbytes >= 32e6:
+                        gbps = nbytes / (us * 1e-6) / 1e9
+                        extra.append({"kernel": f"resample2x {st.H}x{st.W}x{st.C} mode {st.mode}{' + activated operand' if st.out_act else ''} (one launch)",
+                                      "launches_per_step": 1.0, "ms_per_step": us / 1000.0, "algorithmic_MB_per_step": nbytes / 1e6,
+                                      "GBps": gbps, "frac_of_8TBps": gbps / PEAK_HBM_GBPS})
+            if args.dump_layers and c.rank == 0:
+                dump_layers(args.dump_layers, plan, per_op_us)
         roofline["hbm_kernels"] = hbm_kernel_rows(plan, B, ms, cnt, args.steps, extra)
         for r in roofline["hbm_kernels"]:
             r["frac_of_6.3TBps_achievable"] = r["GBps"] / ACHIEVABLE_HBM_GBPS
@@ -739,6 +791,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--dump-plan", default="", help="write the igemm launch list of the compiled plan (JSON) here")
+    ap.add_argument("--dump-layers", default="", help="write the per-layer profile of the instrumented pass (CSV, split-K tails included in their layer) here")
     ap.add_argument("--no-extra", action="store_true", help="c2 only: skip the config-3 training step measured after the timed region")
     args = ap.parse_args()
     if args.gpus < 1:

@@ -425,6 +425,8 @@ int anoddpm_run_ops(const anoddpm_op *ops, int32_t n, void *stream);
 int anoddpm_prof_enable(int32_t enable);
 int anoddpm_prof_active(void);             /* 1 while event recording is on (graph capture must be avoided) */
 int anoddpm_prof_collect(double *ms_per_code, int64_t *launches_per_code);
+/* the ops recorded up to the last anoddpm_prof_collect, in launch order: profiler slot + milliseconds each; returns their count */
+int anoddpm_prof_list(int32_t *codes, float *ms, int32_t cap);
 
 /* ------------------------------------------------------------------ training ----------- */
 

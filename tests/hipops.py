@@ -238,15 +238,20 @@ def attention_fused(qkv, heads, want_probs=False):
     return out, probs
 
 
-def resample(x, mode):
+def resample(x, mode, gn=None):
+    """x NHWC.  mode 1 nearest x2, 2 average 2x2; with gn = (scale, shift) [B][C] mode 2 also returns the pooled ACTIVATED tensor."""
     B, H, W, C = x.shape
     Ho = H * 2 if mode == 1 else H // 2
     out = torch.full((B, Ho, Ho, C), float("nan"), device=x.device)
     st = ResampleArgs()
     st.inp, st.out, st.B, st.H, st.W, st.C, st.mode = x.data_ptr(), out.data_ptr(), B, H, W, C, mode
+    act = None
+    if gn is not None:
+        act = torch.full((B, Ho, Ho, C), float("nan"), device=x.device)
+        st.gn_scale, st.gn_shift, st.out_act = gn[0].data_ptr(), gn[1].data_ptr(), act.data_ptr()
     check(lib().anoddpm_resample2x(ctypes.byref(st), current_stream()), "resample")
     torch.cuda.synchronize()
-    return out
+    return out if gn is None else (out, act)
 
 
 def linear(x, w, b, act_in=0, act_out=0):

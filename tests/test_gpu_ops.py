@@ -209,13 +209,32 @@ def test_softmax_spike_rows():
     assert relerr(d, torch.softmax(x, -1)) < TOL
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 16), (1, 128, 64), (3, 96, 8), (2, 512, 4), (1, 32, 34)])
 @pytest.mark.parametrize("mode", [1, 2])
-def test_resample(mode):
+def test_resample(mode, shape):
+    """nearest x2 / 2x2 average, bit-identical to ATen."""
     import hipops
-    x = rnd(2, 64, 16, 16, seed=31)
+    B, C, H = shape
+    x = rnd(B, C, H, H, seed=31)
     ref = F.interpolate(x, scale_factor=2, mode="nearest") if mode == 1 else F.avg_pool2d(x, 2, 2)
     got = hipops.resample(hipops.nhwc(x.to(dev())), mode)
     assert torch.equal(hipops.nchw(got).cpu(), ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16), (1, 128, 64), (3, 96, 8)])
+def test_resample_pooled_activated_operand(shape):
+    """Mode 2 with a GroupNorm affine also emits mean_2x2(silu(x * scale + shift)) -- the operand of a down block's first
+    convolution (UNet.py:175-178) -- in the same pass; row kernel == generic kernel bit for bit."""
+    import hipops
+    from anoddpm_amd._lib import lib
+    B, C, H = shape
+    x = rnd(B, C, H, H, seed=32)
+    sc, sh = 1 + 0.2 * rnd(B, C, seed=33), 0.3 * rnd(B, C, seed=34)
+    xs = hipops.nhwc(x.to(dev()))
+    out, act = hipops.resample(xs, 2, gn=(sc.to(dev()), sh.to(dev())))
+    assert torch.equal(hipops.nchw(out).cpu(), F.avg_pool2d(x, 2, 2))
+    ref = F.avg_pool2d(F.silu(x * sc[:, :, None, None] + sh[:, :, None, None]), 2, 2)
+    assert relerr(hipops.nchw(act), ref) < TOL
 
 
 @pytest.mark.parametrize("case", [(1, 128, 512, 0, 1), (4, 512, 512, 0, 0), (4, 512, 1000, 1, 0), (13, 64, 36, 1, 1)])
@@ -272,7 +291,8 @@ def test_stem_fused_groupnorm_sums(case):
 
 
 @pytest.mark.parametrize("case", [(2, 128, 32, 1), (1, 64, 64, 3), (1, 32, 8, 2), (1, 128, 256, 1),
-                                  (1, 256, 16, 1), (2, 128, 24, 4), (1, 64, 40, 2), (1, 96, 16, 1)])   # matrix-pipe widths, 96: tap kernel
+                                  (1, 256, 16, 1), (2, 128, 24, 4), (1, 64, 40, 2), (1, 96, 16, 1),    # matrix-pipe widths, 96: tap kernel
+                                  (1, 64, 40, 1), (3, 128, 24, 1), (1, 128, 72, 1)])                    # 16 x 28 tiles: ragged edges
 def test_head_conv(case):
     import hipops
     B, C, H, Cout = case
