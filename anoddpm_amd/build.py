@@ -25,6 +25,7 @@ SOURCES = {
     "winograd43r.hip": [],
     "pointwise.hip": [],
     "smallmap.hip": [],
+    "wino23s.hip": [],
     "attention.hip": [],
     "executor.hip": [],
     "optim.hip": [],

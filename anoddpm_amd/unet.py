@@ -388,6 +388,19 @@ def smallmap_ok(H, W, K, N, B, *, ks, a_mode=0, b_mode=0, heads=1, c0=None):
     return lib().anoddpm_smallmap_tile(ks, H, W, K, K if c0 is None else c0, N, B) != 0
 
 
+def wino23s_ok(H, W, K, N, B, *, ks, a_mode=0, b_mode=0, heads=1, c0=None):
+    """cfg 6 (csrc/wino23s.hip: Winograd F(2x2,3x3) on the 16x16 / 32x32 maps without split-K, GroupNorm of the operand finished
+    in the prologue) takes this launch.  ANODDPM_NO_WINO23S=1 disables it."""
+    if os.environ.get("ANODDPM_NO_WINO23S", "0") == "1" or ks != 3 or b_mode != 0 or heads != 1 or not _use_winograd():
+        return False
+    # Measured (config 2, gpurun_out/r4e): every 32- or 64-channel workgroup re-stages and re-transforms the input for its
+    # own channels, so the kernel wins where K is short -- 256 channels: 32x32 38.3 + 5 (finalize) -> 38.8 us, 16x16 35.6 -> 25.9 --
+    # and loses to split-K + tail on the deep layers (16x16 512 -> 512: 42.2 -> 45.6 us, 1024 -> 512: 59.9 -> 82.6)
+    if K > int(os.environ.get("ANODDPM_WINO23S_MAXK", 256)):
+        return False
+    return lib().anoddpm_wino23s_tile(H, W, K, K if c0 is None else c0, N, B, a_mode) != 0
+
+
 def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None, c1=0, wino=True, f43=False, plain=False, small=False):
     """Tile configuration (0: 128x128 direct, 1: 64x64 direct, 4: streaming 1x1 for large maps, 2: Winograd F(2x2,3x3),
     3: Winograd F(4x4,3x3) -- only when the
@@ -399,7 +412,9 @@ def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None
     c0 = K if c0 is None else c0
     P = H * W
     if small and smallmap_ok(H, W, K, N, Z, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads, c0=c0):
-        return 5, 1                                            # inference plan only (the training plan does not pass `small`)
+        return 5, 1
+    if small and wino and wino23s_ok(H, W, K, N, Z, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads, c0=c0):
+        return 6, 1
     if (plain and ks == 1 and a_mode == 0 and b_mode == 0 and heads == 1 and K % 128 == 0 and K <= 512 and c0 % 32 == 0
             and P % 32 == 0 and N % 64 == 0 and os.environ.get("ANODDPM_NO_STREAM1X1", "0") != "1"):
         # cfg 4: streaming 1x1 (weights resident in LDS, one 32-pixel tile per wave pass) -- `plain` = no fused GroupNorm /
@@ -638,8 +653,9 @@ class _Plan:
         return scale, shift
 
     def small(self, H, W, K, N, *, ks, a_mode=0, c0=None):
-        """True when the contraction with these parameters will run on cfg 5 (so its GroupNorm can be folded into it)."""
-        return smallmap_ok(H, W, K, N, self.B, ks=ks, a_mode=a_mode, c0=c0)
+        """True when the contraction with these parameters will run on cfg 5 / 6 (so its GroupNorm can be folded into it)."""
+        return (smallmap_ok(H, W, K, N, self.B, ks=ks, a_mode=a_mode, c0=c0) or
+                wino23s_ok(H, W, K, N, self.B, ks=ks, a_mode=a_mode, c0=c0))
 
     def attention(self, qkv, att, L, heads, ch, probs=None):
         """One fused launch for softmax(q^T k / sqrt(ch)) v (csrc/attention.hip) when the shape allows it; False otherwise (the
@@ -715,14 +731,14 @@ class _Plan:
         cfg, ksplit = choose_conv_cfg(H, W, K, N, Z, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads, c0=c0, c1=c1,
                                       wino=bool(wino), f43=bool(wino43),
                                       plain=(gn is None and act == 0 and not want_stats), small=True)
-        if fold is not None and cfg != 5:
-            raise _lib.AnoddpmError("plan: a folded GroupNorm needs a cfg 5 consumer")
+        if fold is not None and cfg not in (5, 6):
+            raise _lib.AnoddpmError("plan: a folded GroupNorm needs a cfg 5 / 6 consumer")
         bm = 128 if cfg == 0 else 64
         st.cfg, st.ksplit = cfg, ksplit
         _st, _bmat, _wino = self._pending_bmat
         if cfg == 3:
             _bmat = wino43()                                   # F(4x4,3x3) weights
-        elif cfg == 2:
+        elif cfg in (2, 6):
             _bmat = _wino()                                    # Winograd-domain weights for this layer
         elif callable(_bmat):
             _bmat = _bmat()                                    # packed lazily: only the layout this launch uses
@@ -731,8 +747,9 @@ class _Plan:
         if ksplit > 1:
             self._ws_need = max(self._ws_need, ksplit * Z * P * N)
         st.stats = None
-        if want_stats and cfg == 5:
-            rows = P // (16 * (lib().anoddpm_smallmap_tile(ks, H, W, K, c0, N, B) >> 4))     # one row per TM-pixel tile
+        if want_stats and cfg in (5, 6):
+            # one row per workgroup tile: TM pixels (cfg 5) / 8x8 pixels (cfg 6)
+            rows = P // 64 if cfg == 6 else P // (16 * (lib().anoddpm_smallmap_tile(ks, H, W, K, c0, N, B) >> 4))
             stats = self.buf(B, rows, N, 2)
             st.stats = stats.data_ptr()
             self.stats_of[out.data_ptr()] = ("rows", stats, rows)
@@ -766,7 +783,7 @@ class _Plan:
             st.stats, st.stats_rows = stats.data_ptr(), nslab
             self.stats_of[out.data_ptr()] = ("rows", stats, nslab)
         self.add(_lib.OP_IGEMM, st)
-        self.igemm_log.append(dict(wino=(cfg in (2, 3)), f43=(cfg == 3), kind=kind, H=H, W=W, K=K, N=N, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads,
+        self.igemm_log.append(dict(wino=(cfg in (2, 3, 6)), f43=(cfg == 3), kind=kind, H=H, W=W, K=K, N=N, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads,
                                    cfg=cfg, ksplit=ksplit, dual=bool(c1), gflop=2.0 * K * N * ks * ks * P * Z / 1e9))
         if want_stats and st.stats is None and not st.tail_csum:
             self.chan_stats(out, N, P)
@@ -826,7 +843,8 @@ class _Plan:
             Hout = Hin * 2 if resample == "up" else (Hin // 2 if resample == "down" else Hin)
             Pin, Pout = Hin * Hin, Hout * Hout
             g1 = self.gn(srcs, Pin, prefix + ".in_layers.0.weight", prefix + ".in_layers.0.bias",
-                         fold=(resample is None and self.small(Hout, Hout, cin, cout, ks=3, c0=srcs[0][1])))
+                         fold=(resample in (None, "up") and self.small(Hout, Hout, cin, cout, ks=3, c0=srcs[0][1],
+                                                                      a_mode=(1 if resample == "up" else 0))))
             h1 = self.buf(B, Pout, cout)
             pooled = None
             if resample == "down" and len(srcs) == 1 and os.environ.get("ANODDPM_NO_POOL_ACT", "0") != "1":

@@ -353,7 +353,7 @@ def dump_layers(path, plan, per_op_us):
         f.write("kind,H,K,N,ks,a_mode,cfg,ksplit,launches_per_step,avg_us,algorithmic_TFLOPs,executed_TFLOPs,total_us_per_step\n")
         for k, (n, us, gf) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             avg = us / n
-            ex = {2: 4.0 / 9.0, 3: 0.25}.get(k[6], 1.0)
+            ex = {2: 4.0 / 9.0, 6: 4.0 / 9.0, 3: 0.25}.get(k[6], 1.0)
             f.write(",".join(str(v) for v in k) + f",{n},{avg:.1f},{gf / avg * 1e3:.1f},{gf * ex / avg * 1e3:.1f},{us:.0f}\n")
 
 
@@ -627,7 +627,7 @@ def run_train(c, args, cfg):
             L.anoddpm_prof_enable(0)
             def conv_fl(st):
                 return 2.0 * (st.c0 + st.c1) * st.N * 9 * st.H * st.W * st.B
-            names = {1: "igemm_direct", 12: "winograd_f23", 14: "winograd_f43", 3: "softmax", 4: "resample", 5: "linear", 6: "posemb", 7: "stem", 9: "chan_stats",
+            names = {1: "igemm_direct", 12: "winograd_f23", 13: "smallmap", 14: "winograd_f43", 3: "softmax", 4: "resample", 5: "linear", 6: "posemb", 7: "stem", 9: "chan_stats",
                      10: "gn_finalize", 11: "head", 15: "wgrad3x3_winograd", 16: "wgrad3x3_direct", 17: "wgrad_pointwise", 18: "gn_silu_backward",
                      19: "pack_weights", 27: "pack_weights_batched", 28: "linear_backward_batched", 20: "softmax_backward", 21: "transpose", 22: "linear_backward", 23: "stem_backward", 24: "head_backward",
                      25: "colsum_fold", 26: "attention"}
@@ -644,10 +644,12 @@ def run_train(c, args, cfg):
                     (15, sum(conv_fl(st) for st in wgs if st.algo == 1), 0.25),
                 "wgrad_kernel (3x3 weight gradient, nine-tap MFMA tiles: small maps and pool-fused operands, v_mfma_f32_32x32x2_f32)":
                     (16, sum(conv_fl(st) for st in wgs if st.algo != 1), 1.0),
-                "wino_kernel (forward + data-gradient 3x3 convolutions in Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)":
-                    (12, ig_fl([st for st in igs if st.cfg == 2]), 4.0 / 9.0),
-                "igemm_kernel / pointwise_stream_kernel (1x1, 8x8 3x3, qkv / proj, attention backward GEMMs; v_mfma_f32_32x32x2_f32)":
-                    (1, ig_fl([st for st in igs if st.cfg not in (2, 3)]), 1.0),
+                "wino_kernel / wino23s_kernel (forward + data-gradient 3x3 convolutions in Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32 / 16x16x4)":
+                    (12, ig_fl([st for st in igs if st.cfg in (2, 6)]), 4.0 / 9.0),
+                "smallmap_kernel (maps <= 16x16 without split-K: 8x8 3x3, 1x1, qkv / proj, forward + data gradient; v_mfma_f32_16x16x4_f32)":
+                    (13, ig_fl([st for st in igs if st.cfg == 5]), 1.0),
+                "igemm_kernel / pointwise_stream_kernel (1x1 on large maps, attention backward GEMMs; v_mfma_f32_32x32x2_f32)":
+                    (1, ig_fl([st for st in igs if st.cfg not in (2, 3, 5, 6)]), 1.0),
             }
             rows = {k: dict(ms=ms[slot] / args.steps, n=cnt[slot] / args.steps, alg=fl, exe=fl * fr) for k, (slot, fl, fr) in classes.items()}
 

@@ -201,7 +201,9 @@ typedef struct {
                                        N % 64 == 0, ksplit 1, bmat [36][K/4][N][4]; statistics: one row per 16x16 patch;
                                        4: streaming 1x1 for large maps (pointwise.hip): ks 1, a_mode 0, b_mode 0, heads 1, ksplit 1,
                                        no gn / act / stats, K % 128 == 0, K <= 512, c0 % 32 == 0, H*W % 32 == 0, N % 64 == 0;
-                                       5: small maps without split-K (smallmap.hip), see anoddpm_smallmap_tile */
+                                       5: small maps without split-K (smallmap.hip), see anoddpm_smallmap_tile;
+                                       6: Winograd F(2x2,3x3) on 16x16 / 32x32 maps without split-K (wino23s.hip), see anoddpm_wino23s_tile;
+                                       bmat as cfg 2 */
     float alpha;
     int32_t gn_ld;                  /* row length of gn_scale/gn_shift (= K) */
     float *stats;                   /* or NULL: per-channel partial sums of the OUTPUT, [B][tiles*2][N][2]
@@ -223,7 +225,7 @@ typedef struct {
     float *tail_mean, *tail_rstd;   /* optional [B][tail_groups] (training) */
     int32_t tail_c1, tail_groups;
     float tail_eps;
-    /* cfg 5 only (smallmap.hip): the GroupNorm of the A operand FINISHED IN THE KERNEL'S PROLOGUE from its producers' statistics
+    /* cfg 5 / 6 only (smallmap.hip, wino23s.hip): the GroupNorm of the A operand FINISHED IN THE KERNEL'S PROLOGUE from its producers' statistics
      * (UNet.py:409-411 over torch.cat([h, skip], 1)) -- the arguments of anoddpm_gn_finalize, consumed in place: no finalize
      * launch between producer and consumer.  With fold_gamma set, gn_scale / gn_shift are ignored.  fp64 fold in a fixed order
      * (rows ascending per channel, channels ascending per group), biased variance, fold_eps. */
@@ -243,6 +245,13 @@ int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream);
  * TM-pixel tile, [B][P / TM][N][2].  Returns the tile the launch will use as (TM / 16) * 16 + TN / 16, or 0 when the shape is
  * not taken (the caller then uses cfg 0 / 1 / 2). */
 int anoddpm_smallmap_tile(int32_t ks, int32_t H, int32_t W, int32_t K, int32_t c0, int32_t N, int32_t B);
+
+/* cfg 6 of anoddpm_igemm: the 3x3 convolutions on 16x16 and 32x32 maps as Winograd F(2x2,3x3) WITHOUT split-K (wino23s.hip):
+ * a workgroup owns 8x8 output pixels of one image x 32 or 64 channels over all of K, its eight waves split the sixteen transform
+ * positions; one launch instead of main + split-K tail (+ GroupNorm finalize: fold_* as cfg 5).  a_mode 0 / 1, b_mode 0, heads 1,
+ * ksplit 1, K % 32 == 0, 64 <= K <= 1024, N % 32 == 0; bmat = the F(2x2,3x3) weights of cfg 2.  `stats` rows: one per workgroup
+ * tile, [B][(H / 8) * (W / 8)][N][2].  Returns the channel tiles per workgroup (2 or 4), or 0 when the shape is not taken. */
+int anoddpm_wino23s_tile(int32_t H, int32_t W, int32_t K, int32_t c0, int32_t N, int32_t B, int32_t a_mode);
 
 /* GroupNorm statistics -> per-sample per-channel affine (UNet.py:409-411 / nn.GroupNorm(32,C),
  * eps 1e-5, biased variance), over up to two concatenated NHWC sources:

@@ -118,7 +118,7 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
     P = Hout * Hout
     Pin = srcs[0].shape[1] * srcs[0].shape[2]
     st = IgemmArgs()
-    wp = _pack_wino43(w) if cfg == 3 else (_pack_wino(w) if cfg == 2 else _pack_conv(w))
+    wp = _pack_wino43(w) if cfg == 3 else (_pack_wino(w) if cfg in (2, 6) else _pack_conv(w))
     out = torch.full((B, Hout, Hout, N), float("nan"), device=dev)
     st.a0, st.a1 = srcs[0].data_ptr(), srcs[1].data_ptr() if c1 else None
     st.a0_ld, st.a1_ld, st.c0, st.c1 = c0, max(c1, 4), c0, c1
@@ -146,8 +146,8 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
         if c1:
             (s1, f1) = fold["stats"][1]
             st.fold_stats1, st.fold_rows1, st.fold_fmt1 = s1.data_ptr(), (1 if f1 else s1.shape[1]), f1
-    if cfg == 5 and stats_out is not None:
-        tm = 16 * (lib().anoddpm_smallmap_tile(ks, Hout, Hout, c0 + c1, c0, N, B) >> 4)
+    if cfg in (5, 6) and stats_out is not None:
+        tm = 64 if cfg == 6 else 16 * (lib().anoddpm_smallmap_tile(ks, Hout, Hout, c0 + c1, c0, N, B) >> 4)
         stats = torch.full((B, P // tm, N, 2), float("nan"), device=dev)
         st.stats = stats.data_ptr()
         stats_out.append(stats)

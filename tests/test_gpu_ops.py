@@ -824,3 +824,79 @@ def test_smallmap_rejects_what_it_does_not_take():
     with pytest.raises(AnoddpmError):                                              # the fold is a cfg 5 feature
         hipops.conv_igemm([x8], rnd(64, 64, 3, 3, seed=2).to(dev()), None, Hout=8, ks=3, cfg=1,
                           fold=dict(stats=[(hipops.chan_stats(x8, 1), 0)], gamma=torch.ones(64, device=dev()), beta=torch.zeros(64, device=dev())))
+
+
+# ---- cfg 6: Winograd F(2x2,3x3) on 16x16 / 32x32 maps without split-K (csrc/wino23s.hip) -------------------------------------
+WINO23S_CASES = [
+    # B, (c0, c1), N, H, a_mode, gn ("no" / "given" / "fold" / "fold64"), act, temb, res
+    (4, (512, 0), 512, 16, 0, "fold", 1, True, False),       # 16x16 ResBlock conv1: 32-channel workgroups, 16 chunks
+    (4, (512, 0), 512, 16, 0, "fold", 1, False, True),       # conv2 + residual
+    (4, (512, 512), 512, 16, 0, "fold64", 1, True, False),   # up path: virtual concat; statistics as fp64 sums (a split-K tail's)
+    (4, (256, 0), 256, 32, 0, "fold", 1, True, True),        # 32x32: 64-channel workgroups
+    (4, (512, 256), 256, 32, 0, "given", 1, True, False),    # 32x32 concat, precomputed affine
+    (4, (512, 0), 512, 16, 1, "fold", 1, True, False),       # up block: nearest x2 from 8x8 fused into the operand load
+    (12, (64, 32), 96, 16, 0, "fold", 1, False, True),       # narrow test-model widths: N = 96 -> 32-channel tiles, cpg = 3
+    (1, (128, 0), 128, 32, 0, "no", 0, False, False),        # plain operand (Upsample-style conv), batch 1
+    (2, (64, 0), 64, 32, 1, "given", 1, False, False),       # nearest x2 from 16x16, two chunks only
+]
+
+
+@pytest.mark.parametrize("case", WINO23S_CASES)
+def test_wino23s_conv(case):
+    """anoddpm_igemm cfg 6 against torch: GroupNorm (folded / given) -> SiLU -> [nearest x2] -> 3x3 conv over one or two sources
+    -> + bias + temb + residual, and its output statistics rows.  Winograd F(2x2,3x3) rounding: 1e-4 of the output's magnitude
+    (the bar of WINO_CASES)."""
+    import hipops
+    from anoddpm_amd._lib import lib
+    B, (c0, c1), N, H, a_mode, gn_mode, act, use_temb, use_res = case
+    C = c0 + c1
+    Hin = H // 2 if a_mode == 1 else H
+    x = rnd(B, C, Hin, Hin, seed=21) * 1.5 + 0.3
+    w = rnd(N, C, 3, 3, seed=22, scale=1.0 / math.sqrt(C * 9))
+    b = rnd(N, seed=23, scale=0.1)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=24), 0.1 * rnd(C, seed=25)
+    temb = rnd(B, N, seed=26) if use_temb else None
+    res = rnd(B, N, H, H, seed=27) if use_res else None
+    h = x
+    if gn_mode != "no":
+        h = F.group_norm(h, 32, gamma, beta, eps=1e-5)
+    if act:
+        h = F.silu(h)
+    if a_mode == 1:
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+    ref = F.conv2d(h, w, b, padding=1)
+    if temb is not None:
+        ref = ref + temb[:, :, None, None]
+    if res is not None:
+        ref = ref + res
+    xs = hipops.nhwc(x.to(dev()))
+    srcs = [xs[..., :c0].contiguous()] + ([xs[..., c0:].contiguous()] if c1 else [])
+    assert lib().anoddpm_wino23s_tile(H, H, C, c0, N, B, a_mode) != 0
+    gn = fold = None
+    if gn_mode == "given":
+        gn = hipops.gn_affine(srcs, gamma.to(dev()), beta.to(dev()))
+    elif gn_mode in ("fold", "fold64"):
+        stats = []
+        for i, s_ in enumerate(srcs):
+            rows = hipops.chan_stats(s_, nslab=3 + i)
+            stats.append((rows.double().sum(1).contiguous(), 1) if gn_mode == "fold64" else (rows, 0))
+        fold = dict(stats=stats, gamma=gamma.to(dev()), beta=beta.to(dev()))
+    st = []
+    kw = dict(Hout=H, ks=3, gn=gn, act=act, a_mode=a_mode, fold=fold, temb=temb.to(dev()) if temb is not None else None,
+              res=hipops.nhwc(res.to(dev())) if res is not None else None, cfg=6)
+    got = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), stats_out=st, **kw)
+    assert relerr(hipops.nchw(got), ref) < 1e-4
+    g2, b2 = 1 + 0.1 * rnd(N, seed=28), 0.1 * rnd(N, seed=29)
+    sc, sh = hipops.gn_finalize(st, g2.to(dev()), b2.to(dev()), H * H)
+    assert relerr(hipops.nchw(got * sc[:, None, None, :] + sh[:, None, None, :]), F.group_norm(ref, 32, g2, b2, eps=1e-5)) < 2e-4
+    got2 = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), **kw)
+    assert torch.equal(got, got2)
+
+
+def test_wino23s_rejects_what_it_does_not_take():
+    from anoddpm_amd._lib import lib
+    assert lib().anoddpm_wino23s_tile(64, 64, 256, 256, 256, 4, 0) == 0           # only 16x16 / 32x32 maps
+    assert lib().anoddpm_wino23s_tile(16, 16, 48, 48, 64, 4, 0) == 0              # K % 32
+    assert lib().anoddpm_wino23s_tile(16, 16, 512, 512, 512, 4, 2) == 0           # pooled operand
+    assert lib().anoddpm_wino23s_tile(16, 16, 512, 512, 512, 1, 0) == 0           # batch 1: 64 workgroups, the split-K kernel fills the chip
+    assert lib().anoddpm_wino23s_tile(32, 32, 256, 256, 256, 4, 0) == 4 and lib().anoddpm_wino23s_tile(16, 16, 512, 512, 512, 4, 0) == 2

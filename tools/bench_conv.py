@@ -107,3 +107,35 @@ if os.environ.get("WG"):                                 # WG=1: 3x3 weight grad
             gf = 2.0 * K * N * 9 * H * H * B / 1e9
             line += f"  algo{algo} {us:7.1f} us ({gf / us * 1e3:6.1f} alg TFLOP/s)"
         print(line, flush=True)
+
+if os.environ.get("SM"):                                 # SM=1: the small-map no-split kernel (cfg 5), where its time goes
+    def timeit(st, n=20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            lib().anoddpm_igemm(ctypes.byref(st), current_stream())
+        e0.record()
+        for _ in range(n):
+            lib().anoddpm_igemm(ctypes.byref(st), current_stream())
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1000 / n
+    for (B, (c0, c1), N, H, ks) in [(4, (512, 0), 512, 8, 3), (4, (512, 512), 512, 8, 3), (4, (512, 0), 1536, 8, 1), (4, (512, 0), 512, 8, 1),
+                                    (4, (512, 0), 1536, 16, 1), (4, (512, 0), 512, 16, 1), (4, (512, 0), 512, 16, 3)]:
+        C = c0 + c1
+        x = torch.randn(B, H, H, C, device=dev)
+        srcs = [x[..., :c0].contiguous()] + ([x[..., c0:].contiguous()] if c1 else [])
+        w = torch.randn(N, C, ks, ks, device=dev) * 0.02
+        b = torch.zeros(N, device=dev)
+        gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        gn = hipops.gn_affine(srcs, gamma, beta)
+        stats = [(hipops.chan_stats(s_, nslab=4), 0) for s_ in srcs]
+        line = f"{ks}x{ks} B{B} {c0}+{c1}->{N} @{H}:"
+        for name, kw in (("plain", dict()), ("given+silu", dict(gn=gn, act=1)), ("fold+silu", dict(fold=dict(stats=stats, gamma=gamma, beta=beta), act=1)),
+                         ("fold+silu+stats", dict(fold=dict(stats=stats, gamma=gamma, beta=beta), act=1, stats_out=[]))):
+            hipops.conv_igemm(srcs, w, b, Hout=H, ks=ks, cfg=5, **kw)
+            line += f"  {name} {timeit(hipops.LAST_IGEMM):6.1f}"
+        if ks == 3:
+            cfg, kspl = (2, 8) if H >= 16 else (1, 16)
+            hipops.conv_igemm(srcs, w, b, Hout=H, ks=ks, cfg=cfg, ksplit=kspl, gn=gn, act=1, stats_out=[])
+            line += f"  | cfg{cfg} ksplit{kspl} main+tail {timeit(hipops.LAST_IGEMM):6.1f}"
+        print(line + " us", flush=True)
