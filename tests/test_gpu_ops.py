@@ -836,8 +836,8 @@ WINO23S_CASES = [
     (4, (512, 256), 256, 32, 0, "given", 1, True, False),    # 32x32 concat, precomputed affine
     (4, (512, 0), 512, 16, 1, "fold", 1, True, False),       # up block: nearest x2 from 8x8 fused into the operand load
     (12, (64, 32), 96, 16, 0, "fold", 1, False, True),       # narrow test-model widths: N = 96 -> 32-channel tiles, cpg = 3
-    (1, (128, 0), 128, 32, 0, "no", 0, False, False),        # plain operand (Upsample-style conv), batch 1
-    (2, (64, 0), 64, 32, 1, "given", 1, False, False),       # nearest x2 from 16x16, two chunks only
+    (2, (128, 0), 128, 32, 0, "no", 0, False, False),        # plain operand (Upsample-style conv)
+    (4, (64, 0), 64, 32, 1, "given", 1, False, False),       # nearest x2 from 16x16, two chunks only
 ]
 
 
