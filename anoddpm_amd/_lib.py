@@ -256,7 +256,7 @@ SYMBOLS = [
     "anoddpm_simplex_perm_init", "anoddpm_simplex3_octaves_f64", "anoddpm_simplex3_octaves_f32",
     "anoddpm_simplex3_grid_f64", "anoddpm_simplex2_octaves_f64", "anoddpm_simplex2_grid_f64",
     "anoddpm_q_sample", "anoddpm_p_sample_update", "anoddpm_chain_advance",
-    "anoddpm_igemm", "anoddpm_smallmap_tile", "anoddpm_wino23s_tile", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
+    "anoddpm_igemm", "anoddpm_smallmap_tile", "anoddpm_wino23s_tile", "anoddpm_pack_wino43_bf16x3", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
     "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_stem_stats_rows", "anoddpm_conv_head", "anoddpm_nhwc_to_nchw",
     "anoddpm_run_ops", "anoddpm_prof_enable", "anoddpm_prof_active", "anoddpm_prof_collect", "anoddpm_prof_list",
     "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map", "anoddpm_vlb_terms", "anoddpm_conv3x3_wgrad", "anoddpm_gn_silu_backward", "anoddpm_pack_conv3x3",
@@ -339,6 +339,7 @@ def lib():
     L.anoddpm_prof_enable.argtypes = [c_int32]
     L.anoddpm_prof_collect.argtypes = [POINTER(c_double), POINTER(c_int64)]
     L.anoddpm_prof_list.argtypes = [POINTER(c_int32), POINTER(c_float), c_int32]
+    L.anoddpm_pack_wino43_bf16x3.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_void_p]
     L.anoddpm_adamw_ema.argtypes = [POINTER(AdamwArgs), c_void_p]
     L.anoddpm_sumsq.argtypes = [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p]
     L.anoddpm_anomaly_map.argtypes = [POINTER(AnomalyArgs), c_void_p]

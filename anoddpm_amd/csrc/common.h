@@ -35,6 +35,7 @@ int launch_pointwise_stream(const anoddpm_igemm_args *a, hipStream_t s); // poin
 int launch_smallmap(const anoddpm_igemm_args *a, hipStream_t s);         // smallmap.hip (cfg == 5)
 int smallmap_tile(int ks, int H, int W, int K, int c0, int N, int B);
 int launch_wino23s(const anoddpm_igemm_args *a, hipStream_t s);          // wino23s.hip (cfg == 6)
+int launch_winograd43b(const anoddpm_igemm_args *a, hipStream_t s);      // winograd43b.hip (cfg == 7: split-bf16 side configuration)
 int wino23s_tile(int H, int W, int K, int c0, int N, int B, int a_mode);
 int launch_wgrad43(const anoddpm_wgrad_args *a, hipStream_t s);      // wgrad43.hip (algo == 1 of anoddpm_conv3x3_wgrad)
 int wgrad43_groups(int K, int N, int B, int H, int W);

@@ -129,7 +129,7 @@ extern "C" int anoddpm_run_ops(const anoddpm_op *ops, int32_t n, void *stream)
             const int icfg = ops[i].code == ANODDPM_OP_IGEMM ? static_cast<const anoddpm_igemm_args *>(ops[i].args)->cfg : 0;
             const bool w43 = ops[i].code == ANODDPM_OP_WGRAD3 && static_cast<const anoddpm_wgrad_args *>(ops[i].args)->algo == 1;
             // ... the small-map no-split launches (cfg 5) under code 13
-            g_prof.codes.push_back((icfg == 2 || icfg == 6) ? 12 : (icfg == 3 ? 14 : (icfg == 5 ? 13 : (w43 ? 15 : ops[i].code))));
+            g_prof.codes.push_back((icfg == 2 || icfg == 6) ? 12 : ((icfg == 3 || icfg == 7) ? 14 : (icfg == 5 ? 13 : (w43 ? 15 : ops[i].code))));
             (void)hipEventRecord(e0, as_stream(stream));
         }
         const int rc = dispatch(ops[i], stream);

@@ -627,7 +627,7 @@ extern "C" int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream)
 {
     ANODDPM_REQUIRE(a && a->a0 && a->bmat && a->out, "igemm: null pointer");
     ANODDPM_REQUIRE(a->ks == 1 || a->ks == 3, "igemm: ks must be 1 or 3");
-    ANODDPM_REQUIRE(a->cfg >= 0 && a->cfg <= 6, "igemm: cfg must be 0 (128x128), 1 (64x64), 2 (Winograd F(2x2,3x3)), 3 (Winograd F(4x4,3x3)), 4 (streaming 1x1), 5 (small maps, no split-K) or 6 (F(2x2,3x3) on 16x16 / 32x32 maps, no split-K)");
+    ANODDPM_REQUIRE(a->cfg >= 0 && a->cfg <= 7, "igemm: cfg must be 0 (128x128), 1 (64x64), 2 (Winograd F(2x2,3x3)), 3 (Winograd F(4x4,3x3)), 4 (streaming 1x1), 5 (small maps, no split-K), 6 (F(2x2,3x3) on 16x16 / 32x32 maps, no split-K) or 7 (F(4x4,3x3) with split-bf16 products)");
     ANODDPM_REQUIRE(a->cfg == 5 || a->cfg == 6 || !a->fold_gamma, "igemm: the GroupNorm fold of the operand (fold_*) is a cfg 5 / 6 feature");
     const int BM = a->cfg == 0 ? 128 : 64, BN = BM;
     ANODDPM_REQUIRE(a->c0 > 0 && a->c0 % 4 == 0 && a->c1 >= 0 && a->c1 % 4 == 0, "igemm: channel counts must be multiples of 4");
@@ -670,6 +670,7 @@ extern "C" int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream)
     if (a->cfg == 4) return anoddpm::launch_pointwise_stream(a, anoddpm::as_stream(stream));
     if (a->cfg == 5) return anoddpm::launch_smallmap(a, anoddpm::as_stream(stream));
     if (a->cfg == 6) return anoddpm::launch_wino23s(a, anoddpm::as_stream(stream));
+    if (a->cfg == 7) return anoddpm::launch_winograd43b(a, anoddpm::as_stream(stream));
     if (a->cfg == 2) {
         const int rc = anoddpm::launch_winograd(a, anoddpm::as_stream(stream));
         if (rc != ANODDPM_OK) return rc;

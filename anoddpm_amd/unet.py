@@ -311,7 +311,7 @@ class UNetModel(nn.Module):
         return y.clone().to(x.dtype)
 
     def _plan_for(self, B, S, device):
-        key = (B, S, device)
+        key = (B, S, device, os.environ.get("ANODDPM_ARITH", "fp32"))
         plan = self._plans.get(key)
         if plan is None:
             plan = _Plan(self, B, S, device)
@@ -477,7 +477,13 @@ class _Plan:
         self.keep = []          # tensors / ctypes structs that must outlive the op list
         self.ops = []           # (code, struct)
         self._pack_jobs = []    # (parameter name, PackArgs): one device-side packing job per packed buffer
+        self._bf16_jobs = []    # (parameter name, destination): F(4x4,3x3) weights as three bf16 planes (side configuration)
         self._packed = {}
+        # ANODDPM_ARITH=bf16split3: the OPT-IN side configuration of the large 3x3 layers (csrc/winograd43b.hip: split-bf16 products,
+        # not the reference's arithmetic class); inference plan only, never the default
+        self.arith = os.environ.get("ANODDPM_ARITH", "fp32") if type(self) is _Plan else "fp32"
+        if self.arith not in ("fp32", "bf16split3"):
+            raise ValueError(f"ANODDPM_ARITH={self.arith}: expected fp32 or bf16split3")
         self.token = None
         self.flops = {"conv3": 0.0, "conv1": 0.0, "attn": 0.0, "qkvproj": 0.0}
         self.igemm_flops = 0.0
@@ -512,6 +518,13 @@ class _Plan:
             return hit
         p = dict(self.model.named_parameters())[key]
         shape = tuple(p.shape)
+        if kind == "wino43b":
+            N, K = shape[0], shape[1]
+            dst = torch.empty(54 * N * K, dtype=torch.float32, device=self.device)       # 3 planes x 36 x N x K bf16
+            self.keep.append(dst)
+            self._bf16_jobs.append((key, dst, N, K))
+            self._packed[ck] = dst
+            return dst
         k = self._PACK_KINDS[kind]
         if kind == "conv":
             k = 0 if (len(shape) == 4 and shape[2] == 3) else 2
@@ -560,6 +573,8 @@ class _Plan:
         pb = PackBatchArgs()
         pb.jobs, pb.block0, pb.njobs, pb.nblocks = raw.data_ptr(), b0.data_ptr(), len(self._pack_jobs), block0[-1]
         check(lib().anoddpm_pack_batch(ctypes.byref(pb), _lib.current_stream()), "weight packing")
+        for key, dst, N, K in self._bf16_jobs:
+            check(lib().anoddpm_pack_wino43_bf16x3(named[key].data_ptr(), dst.data_ptr(), N, K, _lib.current_stream()), "bf16 weight planes")
         self._pack_table = (raw, b0, pb)             # alive until the next refresh (the launch is asynchronous)
         self.token = token
         self.pack_count = getattr(self, "pack_count", 0) + 1
@@ -733,10 +748,15 @@ class _Plan:
                                       plain=(gn is None and act == 0 and not want_stats), small=True)
         if fold is not None and cfg not in (5, 6):
             raise _lib.AnoddpmError("plan: a folded GroupNorm needs a cfg 5 / 6 consumer")
+        if (cfg == 3 and self.arith == "bf16split3" and ksplit == 1 and N % 128 == 0 and K % 32 == 0 and (c1 == 0 or c0 % 32 == 0)
+                and (H // 16) * (W // 16) * (N // 128) * Z >= 200):
+            cfg = 7                                             # the 128-channel grids (what winograd43r.hip runs) on split-bf16 products
         bm = 128 if cfg == 0 else 64
         st.cfg, st.ksplit = cfg, ksplit
         _st, _bmat, _wino = self._pending_bmat
-        if cfg == 3:
+        if cfg == 7:
+            _bmat = wino43("wino43b")                          # F(4x4,3x3) weights as three bf16 planes
+        elif cfg == 3:
             _bmat = wino43()                                   # F(4x4,3x3) weights
         elif cfg in (2, 6):
             _bmat = _wino()                                    # Winograd-domain weights for this layer
@@ -755,14 +775,14 @@ class _Plan:
             self.stats_of[out.data_ptr()] = ("rows", stats, rows)
         elif want_stats and ksplit == 1 and heads == 1:
             # the epilogue emits per-channel {sum, sumsq} per wave-row of every pixel tile
-            if cfg in (2, 3):
+            if cfg in (2, 3, 7):
                 tiles = (H // 16) * (W // 16)
             elif ks == 1:
                 tiles = -(-P // bm)
             else:
                 tw = min(W, 32)
                 tiles = (W // tw) * -(-H // (bm // tw))
-            rows = tiles * {2: 4, 3: 1}.get(cfg, 2)            # partial rows per pixel tile (F(4x4,3x3): one per workgroup)
+            rows = tiles * {2: 4, 3: 1, 7: 1}.get(cfg, 2)      # partial rows per pixel tile (F(4x4,3x3): one per workgroup)
             stats = self.buf(B, rows, N, 2)
             st.stats = stats.data_ptr()
             self.stats_of[out.data_ptr()] = ("rows", stats, rows)
@@ -783,7 +803,7 @@ class _Plan:
             st.stats, st.stats_rows = stats.data_ptr(), nslab
             self.stats_of[out.data_ptr()] = ("rows", stats, nslab)
         self.add(_lib.OP_IGEMM, st)
-        self.igemm_log.append(dict(wino=(cfg in (2, 3, 6)), f43=(cfg == 3), kind=kind, H=H, W=W, K=K, N=N, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads,
+        self.igemm_log.append(dict(wino=(cfg in (2, 3, 6, 7)), f43=(cfg in (3, 7)), kind=kind, H=H, W=W, K=K, N=N, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads,
                                    cfg=cfg, ksplit=ksplit, dual=bool(c1), gflop=2.0 * K * N * ks * ks * P * Z / 1e9))
         if want_stats and st.stats is None and not st.tail_csum:
             self.chan_stats(out, N, P)
@@ -862,7 +882,7 @@ class _Plan:
                        a_mode=(0 if pooled is not None else {None: 0, "up": 1, "down": 2}[resample]),
                        bmat=lambda p=prefix: self.packed(p + ".in_layers.2.weight", "conv"),
                        wino=lambda p=prefix: self.packed(p + ".in_layers.2.weight", "wino"),
-                       wino43=lambda p=prefix: self.packed(p + ".in_layers.2.weight", "wino43"),
+                       wino43=lambda kind="wino43", p=prefix: self.packed(p + ".in_layers.2.weight", kind),
                        bias=self.packed(prefix + ".in_layers.2.bias", "copy"),
                        temb=emb_all.data_ptr() + 4 * offs[prefix], temb_ld=tot, out=h1, want_stats=True)
             g2 = self.gn([(h1, cout)], Pout, prefix + ".out_layers.0.weight", prefix + ".out_layers.0.bias",
@@ -890,7 +910,7 @@ class _Plan:
             self.igemm(srcs=[(h1, cout)], H=Hout, W=Hout, ks=3, N=cout, gn=g2, act=1,
                        bmat=lambda p=prefix: self.packed(p + ".out_layers.3.weight", "conv"),
                        wino=lambda p=prefix: self.packed(p + ".out_layers.3.weight", "wino"),
-                       wino43=lambda p=prefix: self.packed(p + ".out_layers.3.weight", "wino43"),
+                       wino43=lambda kind="wino43", p=prefix: self.packed(p + ".out_layers.3.weight", kind),
                        bias=self.packed(prefix + ".out_layers.3.bias", "copy"),
                        res=sk, out=h2, want_stats=True)
             return h2, Hout
@@ -949,7 +969,7 @@ class _Plan:
                 self.igemm(srcs=[(x, C)], H=Hc, W=Hc, ks=3, N=C, act=0,
                            bmat=lambda p=prefix: self.packed(p + ".downsample.weight", "conv"),
                            wino=lambda p=prefix: self.packed(p + ".downsample.weight", "wino"),
-                           wino43=lambda p=prefix: self.packed(p + ".downsample.weight", "wino43"),
+                           wino43=lambda kind="wino43", p=prefix: self.packed(p + ".downsample.weight", kind),
                            bias=self.packed(prefix + ".downsample.bias", "copy"), out=full)
                 rs(full, Hc, 3, out)
                 return out, Ho
@@ -961,7 +981,7 @@ class _Plan:
             self.igemm(srcs=[(x, C)], H=Ho, W=Ho, ks=3, N=C, act=0, a_mode=1,      # nearest x2 fused into the operand load
                        bmat=lambda p=prefix: self.packed(p + ".conv.weight", "conv"),
                        wino=lambda p=prefix: self.packed(p + ".conv.weight", "wino"),
-                       wino43=lambda p=prefix: self.packed(p + ".conv.weight", "wino43"),
+                       wino43=lambda kind="wino43", p=prefix: self.packed(p + ".conv.weight", kind),
                        bias=self.packed(prefix + ".conv.bias", "copy"), out=out, want_stats=True)
             return out, Ho
 

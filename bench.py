@@ -794,10 +794,15 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--dump-plan", default="", help="write the igemm launch list of the compiled plan (JSON) here")
     ap.add_argument("--dump-layers", default="", help="write the per-layer profile of the instrumented pass (CSV, split-K tails included in their layer) here")
+    ap.add_argument("--arith", default="fp32", choices=["fp32", "bf16split3"],
+                    help="bf16split3: OPT-IN side line -- the large F(4x4,3x3) layers on split-bf16 products (csrc/winograd43b.hip); "
+                         "not the reference's arithmetic class, never the default, reported with its own dtype / arith fields")
     ap.add_argument("--no-extra", action="store_true", help="c2 only: skip the config-3 training step measured after the timed region")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.arith != "fp32":
+        os.environ["ANODDPM_ARITH"] = args.arith              # read by the inference plan when it is built
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
     c = setup_dist(args)
@@ -808,6 +813,11 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": out.pop("ms_per_step"), "higher_is_better": True,
             "scaling": out.pop("scaling"), "vs_baseline": None, "dtype": out.pop("dtype"), "data": "synthetic",
             "config": out.pop("config")}
+    if args.arith != "fp32":
+        line["dtype"] = "f32 with bf16x3-split products on the 128-channel F(4x4,3x3) layers (fp32 accumulate)"
+        line["arith"] = args.arith
+        line["config"]["side_line"] = ("opt-in arithmetic, NOT the headline: products formed from three bf16 pieces per operand; "
+                                       "error table profiles/r4_bf16split3_errors.csv")
     if c.shared:
         # test-only layout (ANODDPM_BENCH_SHARE_GPU=1): the ranks do NOT each own a GPU, so this is not a scaling point
         line["config"]["ranks_share_devices"] = True
@@ -819,7 +829,7 @@ def main():
             line["cpu_baseline"].update(host_description())
         except Exception as e:                                   # the baseline must never sink the GPU number
             line["cpu_baseline"] = {"value": None, "error": repr(e)}
-    if args.config == "c2" and not args.no_extra and os.environ.get("ANODDPM_BENCH_NO_EXTRA", "0") != "1":
+    if args.config == "c2" and args.arith == "fp32" and not args.no_extra and os.environ.get("ANODDPM_BENCH_NO_EXTRA", "0") != "1":
         line["extra"] = extra_c3(c, args, line)
     if c.rank == 0:
         print(json.dumps(line), flush=True)

@@ -203,7 +203,10 @@ typedef struct {
                                        no gn / act / stats, K % 128 == 0, K <= 512, c0 % 32 == 0, H*W % 32 == 0, N % 64 == 0;
                                        5: small maps without split-K (smallmap.hip), see anoddpm_smallmap_tile;
                                        6: Winograd F(2x2,3x3) on 16x16 / 32x32 maps without split-K (wino23s.hip), see anoddpm_wino23s_tile;
-                                       bmat as cfg 2 */
+                                       bmat as cfg 2;
+                                       7: OPT-IN side configuration, never chosen by default: cfg 3's layer with every fp32 operand split into
+                                       three bf16 pieces and six products on v_mfma_f32_16x16x32_bf16 (winograd43b.hip): NOT the reference's
+                                       arithmetic class.  N % 128 == 0, K % 32 == 0 per source, ksplit 1; bmat = anoddpm_pack_wino43_bf16x3 */
     float alpha;
     int32_t gn_ld;                  /* row length of gn_scale/gn_shift (= K) */
     float *stats;                   /* or NULL: per-channel partial sums of the OUTPUT, [B][tiles*2][N][2]
@@ -245,6 +248,10 @@ int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream);
  * TM-pixel tile, [B][P / TM][N][2].  Returns the tile the launch will use as (TM / 16) * 16 + TN / 16, or 0 when the shape is
  * not taken (the caller then uses cfg 0 / 1 / 2). */
 int anoddpm_smallmap_tile(int32_t ks, int32_t H, int32_t W, int32_t K, int32_t c0, int32_t N, int32_t B);
+
+/* Weights of cfg 7: OIHW [N][K][3][3] fp32 -> U = G g G^T of F(4x4,3x3) (fp64 transform, rounded once to fp32) split into three bf16
+ * planes, out = [3 pieces][36][K/8][N][8] bf16 (3 * 36 * N * K * 2 bytes).  K % 8 == 0. */
+int anoddpm_pack_wino43_bf16x3(const float *w, void *out, int32_t N, int32_t K, void *stream);
 
 /* cfg 6 of anoddpm_igemm: the 3x3 convolutions on 16x16 and 32x32 maps as Winograd F(2x2,3x3) WITHOUT split-K (wino23s.hip):
  * a workgroup owns 8x8 output pixels of one image x 32 or 64 channels over all of K, its eight waves split the sixteen transform

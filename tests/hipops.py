@@ -118,7 +118,12 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
     P = Hout * Hout
     Pin = srcs[0].shape[1] * srcs[0].shape[2]
     st = IgemmArgs()
-    wp = _pack_wino43(w) if cfg == 3 else (_pack_wino(w) if cfg in (2, 6) else _pack_conv(w))
+    if cfg == 7:                                          # F(4x4,3x3) weights as three bf16 planes (the device packer is the only one)
+        wp = torch.empty(54 * N * (c0 + c1), device=dev)
+        wc = w.detach().float().contiguous()
+        check(lib().anoddpm_pack_wino43_bf16x3(wc.data_ptr(), wp.data_ptr(), N, c0 + c1, current_stream()), "pack_wino43_bf16x3")
+    else:
+        wp = _pack_wino43(w) if cfg == 3 else (_pack_wino(w) if cfg in (2, 6) else _pack_conv(w))
     out = torch.full((B, Hout, Hout, N), float("nan"), device=dev)
     st.a0, st.a1 = srcs[0].data_ptr(), srcs[1].data_ptr() if c1 else None
     st.a0_ld, st.a1_ld, st.c0, st.c1 = c0, max(c1, 4), c0, c1
@@ -177,11 +182,11 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
         stats_out.append(stats)
     elif stats_out is not None:
         bm = 128 if cfg == 0 else 64
-        if cfg in (2, 3):
+        if cfg in (2, 3, 7):
             tiles = (Hout // 16) ** 2
         else:
             tiles = -(-P // bm) if ks == 1 else (Hout // min(Hout, 32)) * -(-Hout // (bm // min(Hout, 32)))
-        stats = torch.full((B, tiles * {2: 4, 3: 1}.get(cfg, 2), N, 2), float("nan"), device=dev)
+        stats = torch.full((B, tiles * {2: 4, 3: 1, 7: 1}.get(cfg, 2), N, 2), float("nan"), device=dev)
         st.stats = stats.data_ptr()
         stats_out.append(stats)
     check(lib().anoddpm_igemm(ctypes.byref(st), current_stream()), "igemm")

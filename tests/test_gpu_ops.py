@@ -900,3 +900,62 @@ def test_wino23s_rejects_what_it_does_not_take():
     assert lib().anoddpm_wino23s_tile(16, 16, 512, 512, 512, 4, 2) == 0           # pooled operand
     assert lib().anoddpm_wino23s_tile(16, 16, 512, 512, 512, 1, 0) == 0           # batch 1: 64 workgroups, the split-K kernel fills the chip
     assert lib().anoddpm_wino23s_tile(32, 32, 256, 256, 256, 4, 0) == 4 and lib().anoddpm_wino23s_tile(16, 16, 512, 512, 512, 4, 0) == 2
+
+
+# ---- cfg 7: F(4x4,3x3) with split-bf16 products (csrc/winograd43b.hip) -- the opt-in side configuration ------------------------
+BF3_CASES = [
+    # B, (c0, c1), Cout, Hout, a_mode, gn, act, temb, res
+    (1, (32, 0), 128, 16, 0, False, 0, False, False),      # one workgroup, one K iteration
+    (2, (64, 0), 128, 32, 0, True, 1, True, True),         # full ResBlock conv: GN + SiLU + temb + residual
+    (1, (128, 0), 256, 64, 0, True, 1, False, False),      # two channel blocks
+    (2, (64, 64), 128, 32, 0, True, 1, True, True),        # virtual concat
+    (1, (64, 0), 128, 32, 1, True, 1, False, False),       # fused nearest x2
+    (1, (96, 0), 128, 48, 0, True, 1, False, True),        # non power-of-two image, three K iterations
+    (1, (128, 0), 128, 32, 0, False, 0, False, False),     # no GroupNorm / activation
+]
+
+
+@pytest.mark.parametrize("case", BF3_CASES)
+def test_winograd_f43_bf16split3(case):
+    """The split-bf16 side configuration against fp64 on the fused layer: it must stay in the accuracy class of the fp32 F(4x4,3x3)
+    kernel (three bf16 pieces = 24 bits; the products dropped are below 2^-24) -- asserted at 2x the fp32 kernel's own error, and
+    bit-reproducible."""
+    import hipops
+    B, (c0, c1), N, Hout, a_mode, use_gn, act, use_temb, use_res = case
+    C = c0 + c1
+    Hin = Hout if a_mode == 0 else Hout // 2
+    x = rnd(B, C, Hin, Hin, seed=11)
+    w = rnd(N, C, 3, 3, seed=12, scale=1.0 / math.sqrt(C * 9))
+    b = rnd(N, seed=13, scale=0.1)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=14), 0.1 * rnd(C, seed=15)
+    temb = rnd(B, N, seed=16) if use_temb else None
+    res = rnd(B, N, Hout, Hout, seed=17) if use_res else None
+    h = x.double()
+    if use_gn:
+        h = F.group_norm(h, 32, gamma.double(), beta.double(), eps=1e-5)
+    if act:
+        h = F.silu(h)
+    if a_mode == 1:
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+    ref = F.conv2d(h, w.double(), b.double(), padding=1)
+    if temb is not None:
+        ref = ref + temb.double()[:, :, None, None]
+    if res is not None:
+        ref = ref + res.double()
+    xs = hipops.nhwc(x.to(dev()))
+    srcs = [xs[..., :c0].contiguous()] + ([xs[..., c0:].contiguous()] if c1 else [])
+    gn = hipops.gn_affine(srcs, gamma.to(dev()), beta.to(dev())) if use_gn else None
+    kw = dict(Hout=Hout, ks=3, gn=gn, act=act, a_mode=a_mode, temb=temb.to(dev()) if temb is not None else None,
+              res=hipops.nhwc(res.to(dev())) if res is not None else None)
+    st = []
+    got = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), cfg=7, stats_out=st, **kw)
+    f32 = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), cfg=3, **kw)
+
+    def err(t):
+        return ((hipops.nchw(t).double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    e7, e3 = err(got), err(f32)
+    assert e7 < max(2 * e3, 2e-5), (e7, e3)
+    g2, b2 = 1 + 0.1 * rnd(N, seed=28), 0.1 * rnd(N, seed=29)
+    sc, sh = hipops.gn_finalize(st, g2.to(dev()), b2.to(dev()), Hout * Hout)
+    assert relerr(hipops.nchw(got * sc[:, None, None, :] + sh[:, None, None, :]), F.group_norm(ref.float(), 32, g2, b2, eps=1e-5)) < 2e-4
+    assert torch.equal(got, hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), cfg=7, **kw))
