@@ -178,17 +178,29 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
     const double X[2] = {dx0, dx0 - 1.0}, Y[2] = {dy0, dy0 - 1.0}, Z[2] = {dz0, dz0 - 1.0};
     const double SQ[4] = {0.0, 1.0 * SQUISH3, 2.0 * SQUISH3, 3.0 * SQUISH3};
     const unsigned xb2 = ((unsigned)xsb & 0xFFu) * 8u, yb2 = ((unsigned)ysb & 0xFFu) * 8u, zb2 = ((unsigned)zsb & 0xFFu) * 8u;
-    const unsigned yo[2] = {yb2, (yb2 + 8u) & 0x7F8u}, zo[2] = {zb2, (zb2 + 8u) & 0x7F8u};
-    unsigned h0[2], h1[2][2];
+    // Round 4: the hash rows of a lattice-corner PAIR are neighbours in the table -- coordinate c and c + 1 of the same chain
+    // level are entries m and m + 1, and m + 1 <= 511 never wraps (PG holds 512 entries: 255 (hash) + 256 (coordinate + 1)) -- so
+    // every pair is ONE ds_read2_b64 instead of two masked reads: 1 + 2 + 4 pair reads for the cube's 2 + 4 + 8 entries.
+    unsigned h0[2], h1[2][2], gz[2][2][2];
     h0[0] = lds_pg(T, xb2).x;
-    h0[1] = lds_pg(T, (xb2 + 8u) & 0x7F8u).x;
+    h0[1] = lds_pg(T, xb2 + 8u).x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const unsigned base = h0[i] + yb2;
+        h1[i][0] = lds_pg(T, base).x;
+        h1[i][1] = lds_pg(T, base + 8u).x;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) h1[i][j] = lds_pg(T, h0[i] + yo[j]).x;
+        for (int j = 0; j < 2; ++j) {
+            const unsigned base = h1[i][j] + zb2;
+            gz[i][j][0] = lds_pg(T, base).y;
+            gz[i][j][1] = lds_pg(T, base + 8u).y;
+        }
     // shared slot: corner 0 (region A) or corner 7 (otherwise)
     const double sx = regA ? X[0] : X[1] - SQ[3], sy = regA ? Y[0] : Y[1] - SQ[3], sz = regA ? Z[0] : Z[1] - SQ[3];
-    const double slot = kernel_term(T, two07, sx, sy, sz, lds_pg(T, regA ? h1[0][0] + zo[0] : h1[1][1] + zo[1]).y);
+    const double slot = kernel_term(T, two07, sx, sy, sz, regA ? gz[0][0][0] : gz[1][1][1]);
     double value = regA ? 0.0 + slot : 0.0;                         // tetra0: corner 0 is the first term (0.0 + t: a -0.0 term gives +0.0)
     constexpr int ORDER[6] = {1, 2, 4, 3, 5, 6};
 #pragma unroll
@@ -196,7 +208,7 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
         const int code = ORDER[s];
         const int i = code & 1, j = (code >> 1) & 1, k = (code >> 2) & 1, n = i + j + k;
         const double dx = X[i] - SQ[n], dy = Y[j] - SQ[n], dz = Z[k] - SQ[n];
-        value += kernel_term(T, n == 1 ? two1 : two2, dx, dy, dz, lds_pg(T, h1[i][j] + zo[k]).y);
+        value += kernel_term(T, n == 1 ? two1 : two2, dx, dy, dz, gz[i][j][k]);
     }
     value += regA ? 0.0 : slot;                                     // tetra1: corner 7 is the last cube term; octahedron: +0.0
     // ---- the two extra vertices: displacement recipe and hash offsets from the vertex table (simplex_tables.h)

@@ -5,7 +5,7 @@ set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof"
+B="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof --no-extra"
 export ANODDPM_NO_GRAPH=1            # eager launches so that every kernel is attributed by name
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2_stats -o c2 -- $B > $OUT/c2_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/c2_fetch -o c2 -- $B > $OUT/c2_fetch.log 2>&1
@@ -16,8 +16,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stats -o c4 -- $
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY --output-format csv -d $OUT/c4_sq -o c4 -- $B --config c4 > $OUT/c4_sq.log 2>&1
 unset ANODDPM_NO_GRAPH
 cd $GRAFT_REPO_ROOT
-python bench.py --dump-plan $OUT/plan_c2.json --steps 2 --warmup 1 --no-cpu-baseline --no-prof > /dev/null 2>&1
-python tools/by_layer.py $OUT/plan_c2.json $(find $OUT/c2_stats -name "*kernel_trace.csv" | head -1) 2 > $OUT/c2_igemm_by_layer.csv 2> $OUT/by_layer.err
+# per-layer profile from the executor's own HIP events (round 4: bench.py --dump-layers; split-K tails are inside their layer's time)
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra --dump-layers $OUT/c2_igemm_by_layer.csv > /dev/null 2> $OUT/by_layer.err
+# one step as a timeline (kernel, start, duration) from the eager trace
+python tools/timeline.py $(find $OUT/c2_stats -name "*kernel_trace.csv" | head -1) -2 $OUT/c2_step_timeline.csv > $OUT/c2_step_timeline_summary.txt 2>> $OUT/by_layer.err
 # keep what is small: summaries only (the raw traces can be hundreds of MB)
 for d in c2_stats c2_fetch c2_write c2_sq c3_stats c4_stats c4_sq; do
   for f in $(find $OUT/$d -name "*kernel_trace.csv" -o -name "*counter_collection.csv" 2>/dev/null); do

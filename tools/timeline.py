@@ -12,7 +12,7 @@ from collections import defaultdict
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
-    return name.split("(")[0][:48]
+    return name.split("(")[0][:48].replace(", ", ";")
 
 
 rows = list(csv.DictReader(open(sys.argv[1])))
