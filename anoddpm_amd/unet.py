@@ -289,8 +289,9 @@ class UNetModel(nn.Module):
         plan.fwd_epoch = getattr(plan, "fwd_epoch", 0) + 1          # a pending backward of an earlier forward is now stale
         return y.clone().to(x.dtype)
 
-    def forward_hip(self, x, time, out=None):
-        """Inference forward on the HIP plan (no autograd).  Returns a fresh tensor like x."""
+    def forward_hip(self, x, time, out=None, borrow=False):
+        """Inference forward on the HIP plan (no autograd).  Returns a fresh tensor like x; `borrow=True` returns the plan's own
+        output buffer instead (valid until the plan runs again: the reverse chain consumes it in its next launch)."""
         _lib.require_cuda(x, "UNetModel.forward")
         B, C, H, W = x.shape
         if C != self.in_channels or H != W:
@@ -308,6 +309,8 @@ class UNetModel(nn.Module):
         if out is not None:
             out.copy_(y.view_as(out))
             return out
+        if borrow and x.dtype == torch.float32:
+            return y.view_as(x)
         return y.clone().to(x.dtype)
 
     def _plan_for(self, B, S, device):
