@@ -380,11 +380,14 @@ def fused_attention_ok(L, ch):
 def smallmap_ok(H, W, K, N, B, *, ks, a_mode=0, b_mode=0, heads=1, c0=None):
     """cfg 5 (csrc/smallmap.hip: no split-K, batch folded into M, GroupNorm of the operand finished in the prologue) takes this
     launch: every 1x1 / conv1d on maps of <= 256 pixels and the 3x3 convolutions on maps of <= ANODDPM_SMALLMAP_CONV_MAXP pixels
-    (default 64: at 16x16 the Winograd kernel's 2.25x fewer multiplies still win).  ANODDPM_NO_SMALLMAP=1 disables it."""
+    (default 64) or of <= ANODDPM_SMALLMAP_CONV_MAXM rows over the whole batch (default 256: the 16x16 maps of a batch of ONE --
+    config 5 -- are the same 256-row problem as the 8x8 maps of a batch of four: 34.0 -> 21 us per 512 -> 512 layer against the
+    direct kernel with split-K 16; with more rows the Winograd kernel's 2.25x fewer multiplies win).  ANODDPM_NO_SMALLMAP=1
+    disables it."""
     if os.environ.get("ANODDPM_NO_SMALLMAP", "0") == "1" or a_mode != 0 or b_mode != 0 or heads != 1:
         return False
     P = H * W
-    if ks == 3 and P > int(os.environ.get("ANODDPM_SMALLMAP_CONV_MAXP", 64)):
+    if ks == 3 and P > int(os.environ.get("ANODDPM_SMALLMAP_CONV_MAXP", 64)) and P * B > int(os.environ.get("ANODDPM_SMALLMAP_CONV_MAXM", 256)):
         return False
     if ks == 1 and P > int(os.environ.get("ANODDPM_SMALLMAP_GEMM_MAXP", 256)):
         return False

@@ -137,7 +137,9 @@ def test_batch_invariance_and_training_path_agree():
         y = m(x, t)
         y0 = m(x[:1], t[:1])
         y1 = m(x[1:], t[1:])
-    assert torch.allclose(torch.cat([y0, y1]), y, rtol=1e-5, atol=1e-6)
+    # not bitwise: the batch size may change a layer's kernel (split-K factors; since round 4 the 3x3 layers of <= 256 rows over
+    # the batch run the direct no-split-K kernel where larger batches run Winograd F(2x2,3x3)) -- same bound as the config-2 test
+    assert ((torch.cat([y0, y1]) - y).abs().max() / y.abs().max()).item() < 2e-5
     yt = m(x, t)                                       # autograd recording -> differentiable path
     assert yt.requires_grad
     assert ((yt.detach() - y).abs().max() / y.abs().max()) < REL
