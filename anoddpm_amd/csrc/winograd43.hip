@@ -398,9 +398,12 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
     ANODDPM_REQUIRE((int64_t)36 * K * a->N * 4 < ((int64_t)1 << 31), "winograd43: transformed weights exceed 32-bit buffer offsets");
     ANODDPM_REQUIRE((int64_t)a->H * a->W * (a->a0_ld > a->a1_ld ? a->a0_ld : a->a1_ld) * 4 < ((int64_t)1 << 31),
                     "winograd43: operand slice exceeds 32-bit buffer offsets");
-    // 64-channel workgroups when 128-channel ones would leave CUs idle (or N is not a multiple of 128)
+    // 64-channel workgroups when 128-channel ones would leave CUs idle (or N is not a multiple of 128): rounds over the 256 CUs x
+    // the cost of a workgroup -- a 64-channel one takes 0.71 of a 128-channel one (it transforms the same patch for half the
+    // outputs: 68 against 96 us on the 64x64 256 -> 256 layer).  128 workgroups (batch 4): one round of 256 halves, 0.71; 160
+    // (batch 5, the detection loop's five chains): one round of 128-channel workgroups, 1.0, against two rounds of halves, 1.42
     const int64_t wg128 = (int64_t)(a->H / 16) * (a->W / 16) * (a->N / 128) * a->B;
-    const bool half = (a->N % 128 != 0) || wg128 < 200;
+    const bool half = (a->N % 128 != 0) || ((2 * wg128 + 255) / 256) * 71 < ((wg128 + 255) / 256) * 100;
     const int nblk = half ? 64 : 128;
     dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / nblk), (unsigned)a->B);
     ANODDPM_REQUIRE(a->B <= 65535, "winograd43: batch too large");
