@@ -424,9 +424,10 @@ def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None
     if (plain and ks == 1 and a_mode == 0 and b_mode == 0 and heads == 1 and K % 128 == 0 and K <= 512 and c0 % 32 == 0
             and P % 32 == 0 and N % 64 == 0 and os.environ.get("ANODDPM_NO_STREAM1X1", "0") != "1"):
         # cfg 4: streaming 1x1 (weights resident in LDS, one 32-pixel tile per wave pass) -- `plain` = no fused GroupNorm /
-        # activation / statistics; needs enough 32-pixel tiles x channel blocks for the 2048 waves of the chip
+        # activation / statistics; needs enough 32-pixel tiles x channel blocks for the 2048 waves of the chip -- half of them
+        # still beats the direct kernel + split-K tail (config 2, 64x64 128 -> 256: step 9.381 -> 9.362 ms; a quarter: 9.394)
         nb = 128 if (N % 128 == 0 and K <= 256) else 64
-        if (Z * P // 32) * (N // nb) >= 2048:
+        if (Z * P // 32) * (N // nb) >= int(os.environ.get("ANODDPM_STREAM1X1_MIN_TILES", 1024)):
             return 4, 1
 
     def ok128():
