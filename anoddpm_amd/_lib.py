@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 (OP_WGRAD3, OP_WGRAD1, OP_GN_BWD, OP_PACK, OP_SOFTMAX_BWD, OP_TRANSPOSE, OP_LINEAR_BWD, OP_STEM_BWD, OP_HEAD_BWD,
@@ -50,7 +50,7 @@ class IgemmArgs(Structure):
                 ("tail_c1", c_int32), ("tail_groups", c_int32), ("tail_eps", c_float),
                 ("fold_stats0", c_void_p), ("fold_stats1", c_void_p), ("fold_gamma", c_void_p), ("fold_beta", c_void_p),
                 ("fold_rows0", c_int32), ("fold_rows1", c_int32), ("fold_fmt0", c_int32), ("fold_fmt1", c_int32),
-                ("fold_groups", c_int32), ("fold_eps", c_float)]
+                ("fold_groups", c_int32), ("fold_eps", c_float), ("res_mode", c_int32)]
 
 
 class GnArgs(Structure):

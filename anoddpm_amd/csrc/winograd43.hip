@@ -273,6 +273,8 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
     constexpr int ROUNDS = NTL == 8 ? 3 : 2;                        // 8 tiles: 3 + 3 + 2; 4 tiles: 2 + 2
     constexpr int RT = NTL == 8 ? 3 : 2;
     // Item geometry of a round: tile = tid / nch, channel = tid % nch (nch = 48, 48, 32 resp. 32, 32).
+    const bool res_up = a.res_mode == 1;                            // residual at half resolution, nearest x2 on the read
+    const unsigned hW = uW >> 1;
     struct Item { int tile, ch, n; bool active; unsigned vo, vr; };
     auto item_of = [&](int round) {
         const int nch = ((NTL == 8 && round == 2) ? 2 : RT) * 16;
@@ -283,7 +285,8 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
         it.n = n0 + round * RT * 16 + it.ch;
         const unsigned pix0 = (unsigned)(y0 + (it.tile >> 2) * 4) * uW + (unsigned)(x0 + (it.tile & 3) * 4);
         it.vo = (pix0 * o_ld + (unsigned)it.n) * 4u;
-        it.vr = (pix0 * r_ld + (unsigned)it.n) * 4u;
+        it.vr = res_up ? (((((unsigned)(y0 + (it.tile >> 2) * 4) >> 1) * hW + ((unsigned)(x0 + (it.tile & 3) * 4) >> 1)) * r_ld + (unsigned)it.n) * 4u)
+                       : ((pix0 * r_ld + (unsigned)it.n) * 4u);
         return it;
     };
     // The residual pixels and the per-channel addend of a round are requested one round AHEAD (round 0: before the accumulators
@@ -294,7 +297,17 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
 #pragma unroll
         for (int i = 0; i < 16; ++i) rv[i] = 0.f;
         if (it.active) {
-            if (has_res) {
+            if (has_res && res_up) {
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                    for (int j2 = 0; j2 < 2; ++j2) {
+                        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rR, (int)it.vr, (int)((((unsigned)i2 * hW + (unsigned)j2) * 4u) * r_ld), 0));
+                        rv[(2 * i2) * 4 + 2 * j2] = v; rv[(2 * i2) * 4 + 2 * j2 + 1] = v;
+                        rv[(2 * i2 + 1) * 4 + 2 * j2] = v; rv[(2 * i2 + 1) * 4 + 2 * j2 + 1] = v;
+                    }
+            } else if (has_res) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -408,6 +421,7 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
     dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / nblk), (unsigned)a->B);
     ANODDPM_REQUIRE(a->B <= 65535, "winograd43: batch too large");
     const bool fast = a->gn_scale && a->act;
+    ANODDPM_REQUIRE(a->res_mode == 0 || (a->res_mode == 1 && a->res && a->ksplit == 1), "winograd43: res_mode 1 needs a residual and ksplit 1");
 #ifdef ANODDPM_ABLATE
     const int dbg = anoddpm::g_debug[2];
 #else

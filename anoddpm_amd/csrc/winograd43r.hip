@@ -275,10 +275,24 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     // per-lane byte offset of tile (kq, 0)'s first pixel; tile r and pixel (i, j) add the wave-uniform (r*4 + i*W + j) pixels
     const unsigned pix0 = (unsigned)(y0 + kq * 4) * uW + (unsigned)x0;
     const unsigned vo = (pix0 * o_ld + (unsigned)nw) * 4u, vr = (pix0 * r_ld + (unsigned)nw) * 4u;
+    // res_mode 1: the residual lives at half resolution (nearest x2 on the read): a 4 x 4 output tile reads its 2 x 2 source pixels
+    const bool res_up = a.res_mode == 1;
+    const unsigned hW = uW >> 1;
+    const unsigned vrh = ((((unsigned)(y0 + kq * 4) >> 1) * hW + ((unsigned)x0 >> 1)) * r_ld + (unsigned)nw) * 4u;
     auto load_res = [&](int r, float (&rv)[16]) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) rv[i] = 0.f;
-        if (has_res) {
+        if (has_res && res_up) {
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2) {
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rR, (int)vrh, (int)((((unsigned)(r * 2) + (unsigned)i2 * hW + (unsigned)j2) * 4u) * r_ld), 0));
+                    rv[(2 * i2) * 4 + 2 * j2] = v; rv[(2 * i2) * 4 + 2 * j2 + 1] = v;
+                    rv[(2 * i2 + 1) * 4 + 2 * j2] = v; rv[(2 * i2 + 1) * 4 + 2 * j2 + 1] = v;
+                }
+        } else if (has_res) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -700,7 +700,7 @@ class _Plan:
     def igemm(self, *, srcs, H, W, ks, N, bmat, out, out_ld=None, gn=None, act=0, a_mode=0, bias=None,
               temb=None, temb_ld=0, res=None, res_ld=0, b_mode=0, ldb=0, heads=1, alpha=1.0,
               a_strides=None, b_strides=(0, 0), o_strides=None, r_strides=None, kind="conv3", want_stats=False,
-              wino=None, wino43=None):
+              wino=None, wino43=None, res_up=None):
         B = self.B
         P = H * W
         c0 = srcs[0][1]
@@ -760,6 +760,21 @@ class _Plan:
             cfg = 7                                             # the 128-channel grids (what winograd43r.hip runs) on split-bf16 products
         bm = 128 if cfg == 0 else 64
         st.cfg, st.ksplit = cfg, ksplit
+        st.res_mode = 0
+        if res_up is not None:
+            # residual = nearest x2 of the half-resolution tensor `res_up` (the x_upd path of an up-sampling ResBlock, UNet.py:196-198):
+            # the F(4x4,3x3) kernels repeat the source pixels on the read (res_mode 1: no resample launch, a quarter of the residual
+            # bytes); every other kernel gets the materialised tensor
+            if cfg == 3 and ksplit == 1 and os.environ.get("ANODDPM_NO_RES_UP", "0") != "1":
+                st.res, st.res_mode = res_up.data_ptr(), 1
+                st.res_ld, st.r_bs, st.r_hs = N, (P // 4) * N, 0
+            else:
+                sk = self.buf(B, P, N)
+                rs = ResampleArgs()
+                rs.inp, rs.out = res_up.data_ptr(), sk.data_ptr()
+                rs.B, rs.H, rs.W, rs.C, rs.mode = B, H // 2, W // 2, N, 1
+                self.add(_lib.OP_RESAMPLE, rs)
+                st.res = sk.data_ptr()
         _st, _bmat, _wino = self._pending_bmat
         if cfg == 7:
             _bmat = wino43("wino43b")                          # F(4x4,3x3) weights as three bf16 planes
@@ -902,12 +917,15 @@ class _Plan:
                            bias=self.packed(prefix + ".skip_connection.bias", "copy"), out=sk)
             elif resample is not None and pooled is not None:
                 sk = sk_pool
+            elif resample == "up":
+                assert len(srcs) == 1
+                sk = None                                          # igemm(res_up=...) below: fused into the F(4x4) epilogue, else materialised there
             elif resample is not None:
                 assert len(srcs) == 1
                 sk = self.buf(B, Pout, cout)
                 st = ResampleArgs()
                 st.inp, st.out = srcs[0][0].data_ptr(), sk.data_ptr()
-                st.B, st.H, st.W, st.C, st.mode = B, Hin, Hin, cin, 1 if resample == "up" else 2
+                st.B, st.H, st.W, st.C, st.mode = B, Hin, Hin, cin, 2
                 self.add(_lib.OP_RESAMPLE, st)
             else:
                 if len(srcs) != 1:
@@ -919,7 +937,7 @@ class _Plan:
                        wino=lambda p=prefix: self.packed(p + ".out_layers.3.weight", "wino"),
                        wino43=lambda kind="wino43", p=prefix: self.packed(p + ".out_layers.3.weight", kind),
                        bias=self.packed(prefix + ".out_layers.3.bias", "copy"),
-                       res=sk, out=h2, want_stats=True)
+                       res=sk, res_up=(srcs[0][0] if (resample == "up" and sk is None) else None), out=h2, want_stats=True)
             return h2, Hout
 
         def attn_block(prefix, x, Hc, C):

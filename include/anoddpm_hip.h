@@ -237,6 +237,10 @@ typedef struct {
     int32_t fold_rows0, fold_rows1, fold_fmt0, fold_fmt1;
     int32_t fold_groups;
     float fold_eps;
+    /* cfg 3 only: res_mode 1 = the residual is the block input at HALF resolution and is repeated 2x2 on the read (the
+     * `x_upd = Upsample(x)` skip path of an up-sampling ResBlock, UNet.py:196-198, 89: F.interpolate(scale_factor=2, mode="nearest")
+     * is never materialised); res: [B][(H/2)*(W/2)][res_ld], r_bs its batch stride.  0: res has the output's resolution. */
+    int32_t res_mode;
 } anoddpm_igemm_args;
 
 int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream);

@@ -108,8 +108,9 @@ _LAST_KEEP = None
 
 
 def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=None, res=None, cfg=0, ksplit=1,
-               stats_out=None, gn_tail=None, fold=None):
-    """srcs: NHWC sources; w: OIHW weights.  Returns NHWC [B,Hout,Hout,N]."""
+               stats_out=None, gn_tail=None, fold=None, res_up=False):
+    """srcs: NHWC sources; w: OIHW weights.  Returns NHWC [B,Hout,Hout,N].  res_up: `res` is [B,Hout/2,Hout/2,N] and is repeated
+    2x2 on the read (cfg 3, res_mode 1)."""
     dev = srcs[0].device
     B = srcs[0].shape[0]
     c0 = srcs[0].shape[3]
@@ -138,6 +139,8 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
     st.res = res.data_ptr() if res is not None else None
     st.out, st.out_ld, st.res_ld = out.data_ptr(), N, N
     st.o_bs = st.r_bs = P * N
+    if res_up:
+        st.res_mode, st.r_bs = 1, (P // 4) * N
     st.H, st.W, st.ks, st.a_mode, st.act = Hout, Hout, ks, a_mode, act
     st.b_mode, st.ldb, st.N, st.B, st.heads, st.alpha = 0, 0, N, B, 1, 1.0
     st.cfg, st.ksplit = cfg, ksplit

@@ -401,6 +401,30 @@ def f43_variant(request):
     lib().anoddpm_internal_variant(5, 0)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 128, 32), (1, 128, 128, 64), (4, 64, 256, 64), (3, 96, 128, 48)])
+def test_winograd_f43_half_resolution_residual(case, f43_variant):
+    """cfg 3 with res_mode 1: the residual is the block input at half resolution, repeated 2x2 on the read (the x_upd path of an
+    up-sampling ResBlock, UNet.py:196-198) -- must equal the same launch on the materialised nearest-x2 tensor bit for bit."""
+    import hipops
+    B, C, N, Hout = case
+    x = rnd(B, C, Hout, Hout, seed=41)
+    w = rnd(N, C, 3, 3, seed=42, scale=1.0 / math.sqrt(C * 9))
+    b = rnd(N, seed=43, scale=0.1)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=44), 0.1 * rnd(C, seed=45)
+    half = rnd(B, N, Hout // 2, Hout // 2, seed=46)
+    full = F.interpolate(half, scale_factor=2, mode="nearest")
+    srcs = [hipops.nhwc(x.to(dev()))]
+    gn = hipops.gn_affine(srcs, gamma.to(dev()), beta.to(dev()))
+    kw = dict(Hout=Hout, ks=3, gn=gn, act=1, cfg=3)
+    st0, st1 = [], []
+    want = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), res=hipops.nhwc(full.to(dev())).contiguous(), stats_out=st0, **kw)
+    got = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), res=hipops.nhwc(half.to(dev())).contiguous(), res_up=True, stats_out=st1, **kw)
+    assert torch.equal(got, want)
+    assert torch.equal(st0[0], st1[0])
+    with pytest.raises(Exception, match="res_mode"):
+        hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), res=hipops.nhwc(half.to(dev())).contiguous(), res_up=True, Hout=Hout, ks=3, gn=gn, act=1, cfg=2)
+
+
 @pytest.mark.parametrize("case", F43_CASES)
 def test_winograd_f43_conv(case, f43_variant):
     """cfg = 3: Winograd F(4x4,3x3) (csrc/winograd43.hip) against the direct 3x3 convolution.  fp32 with wider transforms:
