@@ -391,11 +391,11 @@ class TrainPlan(_Plan):
             self.linear_bwd(pe, "time_embedding.1.weight", "time_embedding.1.bias", g_z1, base, ted, 0, None)
         self._bw.append(time_bwd)
 
-        def conv3(srcs, Hout, N, gnp, a_mode, wkey, bkey, out, temb_ptr=None, temb_ld=0, res=None):
+        def conv3(srcs, Hout, N, gnp, a_mode, wkey, bkey, out, temb_ptr=None, temb_ld=0, res=None, res_up=None):
             self.igemm(srcs=srcs, H=Hout, W=Hout, ks=3, N=N, gn=(gnp[0], gnp[1]), act=1, a_mode=a_mode,
                        bmat=lambda: self.pack(wkey, 0), wino=lambda: self.pack(wkey, 1), wino43=lambda: self.pack(wkey, 5),
                        bias=bias(bkey),
-                       temb=temb_ptr, temb_ld=temb_ld, res=res, out=out, want_stats=True)
+                       temb=temb_ptr, temb_ld=temb_ld, res=res, res_up=res_up, out=out, want_stats=True)
 
         def dgrad3(dy, Hout, Kc, N, wkey):
             """da [B][Hout^2][Kc] = conv3x3(dy, flipped / transposed weights): the forward kernels on the packed twin."""
@@ -442,6 +442,12 @@ class TrainPlan(_Plan):
             elif resample is not None and sk_pool is not None:
                 skip_kind = "resample"
                 sk = sk_pool
+            elif resample == "up" and self.p_drop == 0:
+                # nearest x2 of the block input as the residual: read at half resolution by the F(4x4) epilogue (igemm(res_up=...)
+                # materialises it for every other kernel); the backward of this path is the pooling of gh2 below, unchanged
+                assert len(srcs) == 1
+                skip_kind = "resample"
+                sk = None
             elif resample is not None:
                 assert len(srcs) == 1
                 skip_kind = "resample"
@@ -470,7 +476,8 @@ class TrainPlan(_Plan):
                 self.igemm(srcs=[(a2, cout)], H=Hout, W=Hout, ks=3, N=cout, bmat=lambda: self.pack(wk, 0),
                            wino=lambda: self.pack(wk, 1), wino43=lambda: self.pack(wk, 5), bias=bias(bk), res=sk, out=h2, want_stats=True)
             else:
-                conv3([(h1, cout)], Hout, cout, g2, 0, prefix + ".out_layers.3.weight", prefix + ".out_layers.3.bias", h2, res=sk)
+                conv3([(h1, cout)], Hout, cout, g2, 0, prefix + ".out_layers.3.weight", prefix + ".out_layers.3.bias", h2, res=sk,
+                      res_up=(srcs[0][0] if (resample == "up" and sk is None) else None))
 
             def bwd():
                 gh2 = self.G(h2)
