@@ -181,6 +181,23 @@ def test_conv_launch_policy_on_config2_shapes():
     assert cfg == 2 and (768 // 16) % 1 == 0 and (ks - 1) * -(-(768 // 16) // ks) < 768 // 16      # no empty K slice
 
 
+def test_small_map_launch_policy_round4():
+    """The inference plan's choices for the <= 32x32 maps (small=True): no-split-K small-map kernel (cfg 5) by rows over the batch,
+    F(2x2,3x3) without split-K (cfg 6) for K <= 256, split-K + tail otherwise; streaming 1x1 from 1024 tile x block items."""
+    from anoddpm_amd.unet import choose_conv_cfg as pick
+    assert pick(8, 8, 512, 512, 4, small=True) == (5, 1)                       # 8x8 at batch 4: 256 rows
+    assert pick(8, 8, 1024, 512, 4, c0=512, c1=512, small=True) == (5, 1)      # up path: virtual concat
+    assert pick(16, 16, 512, 512, 1, small=True) == (5, 1)                     # 16x16 at batch 1 (config 5): the same 256 rows
+    assert pick(16, 16, 512, 512, 4, small=True) == (2, 8)                     # 1024 rows: Winograd + split-K + tail
+    assert pick(8, 8, 512, 512, 5, small=True) == (5, 1)                       # the detection loop's batch: map of <= 64 pixels
+    assert pick(16, 16, 512, 1536, 4, ks=1, small=True) == (5, 1)              # qkv projection
+    assert pick(16, 16, 256, 256, 4, small=True) == (6, 1) and pick(32, 32, 256, 256, 4, small=True) == (6, 1)
+    assert pick(32, 32, 512, 256, 4, small=True)[0] == 2                       # K > 256: split-K
+    assert pick(8, 8, 512, 512, 4) == (1, 16)                                  # the training plan does not ask for the small-map kernels here
+    assert pick(64, 64, 128, 256, 4, ks=1, plain=True, small=True) == (4, 1)   # 1024 items: streaming 1x1, no split-K tail
+    assert pick(32, 32, 512, 256, 4, ks=1, plain=True, small=True)[0] != 4     # 512 items: direct kernel
+
+
 def test_host_side_shape_helpers_of_the_library():
     """Pure host functions of the C ABI (no device needed): statistics rows of the fused stem sums, patch / group counts of
     the Winograd-domain weight gradient -- the values the plans size their buffers with."""
