@@ -17,7 +17,7 @@ from . import _lib
 from ._lib import AnomalyArgs, check, current_stream, lib
 
 __all__ = ["anomaly_maps", "anomaly_metrics", "heatmap", "dice_coeff", "PSNR", "SSIM", "IoU", "precision", "recall",
-           "FPR", "ROC_AUC", "AUC_score"]
+           "FPR", "ROC_AUC", "AUC_score", "testing"]
 
 NC = _lib.ANOMALY_NCOUNTS
 
@@ -173,3 +173,63 @@ def AUC_score(fpr, tpr):
     """evaluation.py:85-86."""
     from sklearn.metrics import auc
     return auc(fpr, tpr)
+
+
+def testing(testing_dataset_loader, diffusion, args, ema, model, test_iters=40, sequences=True):
+    """evaluation.py:90-186: the test-set pass `diffusion_training.train` ends with (diffusion_training.py:153).
+
+    Compute kept, in upstream's order and with its draw counts: (1) for `i in range(100, sample_distance, 100)` one
+    `forward_backward(ema, x, "half", t_distance=i)` (upstream turns the returned sequence into an mp4 -- the video
+    dump is plot I/O and is skipped, the chain itself runs so the loader and the RNG streams advance as upstream;
+    `sequences=False`, an extension, skips these chains); (2) `test_iters // Batch_Size + 5` batches of
+    `calc_total_vlb(x, model, args)`; (3) as many batches of `PSNR(forward_backward(ema, x, None, T // 2), x)`.
+    Prints upstream's six summary lines and (extension) returns them as a dict of (mean, std) pairs.
+
+    Upstream reads the module globals `device`, `np` and `animation`, which only exist when evaluation.py runs as
+    `__main__` (evaluation.py:222-232), so its call from diffusion_training.py:153 ends in NameError; here the
+    device is the model's."""
+    import numpy as np
+
+    device = next(model.parameters()).device
+    ema.eval()
+    model.eval()
+
+    def batch():
+        data = next(testing_dataset_loader)
+        if args["dataset"] == "cifar" or args["dataset"] == "carpet":
+            return data[0].to(device)                      # [data, class] pairs (evaluation.py:118-120)
+        return data["image"].to(device)
+
+    seq_lens = []
+    if sequences:
+        for i in range(100, args['sample_distance'], 100):
+            out = diffusion.forward_backward(ema, batch(), see_whole_sequence="half", t_distance=i)
+            seq_lens.append(len(out))
+    rounds = test_iters // args["Batch_Size"] + 5
+    vlb = [diffusion.calc_total_vlb(batch(), model, args) for _ in range(rounds)]
+    psnr = []
+    for _ in range(rounds):
+        x = batch()
+        out = diffusion.forward_backward(ema, x, see_whole_sequence=None, t_distance=args["T"] // 2)
+        psnr.append(PSNR(out, x))
+
+    def ms(vals):
+        return float(np.mean(vals)), float(np.std(vals))
+
+    k = min(199, diffusion.num_timesteps - 1)              # upstream indexes [0][199] (T >= 200 in every config)
+    res = {
+        "total_vlb": ms([v['total_vlb'].mean(dim=-1).cpu().item() for v in vlb]),
+        "prior_vlb": ms([v['prior_vlb'].mean(dim=-1).cpu().item() for v in vlb]),
+        "vb@200": ms([v['vb'][0][k].cpu().item() for v in vlb]),
+        "x_0_mse@200": ms([v['x_0_mse'][0][k].cpu().item() for v in vlb]),
+        "mse@200": ms([v['mse'][0][k].cpu().item() for v in vlb]),
+        "PSNR": ms(psnr),
+        "sequence_lengths": seq_lens,
+    }
+    print(f"Test set total VLB: {res['total_vlb'][0]} +- {res['total_vlb'][1]}")
+    print(f"Test set prior VLB: {res['prior_vlb'][0]} +- {res['prior_vlb'][1]}")
+    print(f"Test set vb @ t=200: {res['vb@200'][0]} +- {res['vb@200'][1]}")
+    print(f"Test set x_0_mse @ t=200: {res['x_0_mse@200'][0]} +- {res['x_0_mse@200'][1]}")
+    print(f"Test set mse @ t=200: {res['mse@200'][0]} +- {res['mse@200'][1]}")
+    print(f"Test set PSNR: {res['PSNR'][0]} +- {res['PSNR'][1]}")
+    return res

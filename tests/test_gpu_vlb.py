@@ -91,3 +91,43 @@ def test_calc_total_vlb_structure_and_consistency():
         np.testing.assert_allclose(out["vb"][:, col].cpu().numpy(), ov.numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(out["x_0_mse"][:, col].cpu().numpy(), om0.numpy(), rtol=1e-4, atol=1e-7)
         np.testing.assert_allclose(out["mse"][:, col].cpu().numpy(), ome.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_evaluation_testing_runs_the_reference_loop_on_device(capsys):
+    """evaluation.testing (evaluation.py:90-186; called by diffusion_training.py:153): draw counts from the loader, the
+    chains / VLB / PSNR passes in upstream's order, the six printed lines -- video dump skipped.  Real `UNetModel`s."""
+    import GaussianDiffusion as GD
+    import UNet as UN
+    import evaluation as EV
+    T, B = 200, 2
+    d = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(T, "linear"), noise="gauss")
+    torch.manual_seed(11)
+    model = UN.UNetModel(32, 32, attention_resolutions="16").to(DEV)
+    with torch.no_grad():
+        for n, p in model.named_parameters():                     # zero-init output conv would make every eps 0
+            if n.startswith("out.2"):
+                p.normal_(0, 0.05)
+    ema = UN.UNetModel(32, 32, attention_resolutions="16").to(DEV)
+    ema.load_state_dict(model.state_dict())
+    drawn = []
+
+    def loader():
+        g = torch.Generator().manual_seed(1)
+        while True:
+            drawn.append(1)
+            yield {"image": (torch.rand(B, 1, 32, 32, generator=g) * 2 - 1)}
+
+    args = {"arg_num": "t", "sample_distance": 250, "dataset": "mri", "Batch_Size": B, "T": T}
+    res = EV.testing(loader(), d, args, ema, model, test_iters=0)
+    rounds = 0 // B + 5
+    assert len(drawn) == 2 + 2 * rounds                            # i in {100, 200}, then VLB and PSNR batches
+    assert res["sequence_lengths"] == [102, 202]                  # "half": t_distance + 2 (GaussianDiffusion.py:320-359)
+    out = capsys.readouterr().out
+    for key in ("total VLB", "prior VLB", "vb @ t=200", "x_0_mse @ t=200", "mse @ t=200", "PSNR"):
+        assert f"Test set {key}:" in out
+    for k in ("total_vlb", "prior_vlb", "vb@200", "x_0_mse@200", "mse@200", "PSNR"):
+        assert np.isfinite(res[k]).all(), k
+    assert not model.training and not ema.training
+    # keyword form of diffusion_training.py:153
+    res2 = EV.testing(loader(), d, ema=ema, args=args, model=model, test_iters=0, sequences=False)
+    assert res2["sequence_lengths"] == []

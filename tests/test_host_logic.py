@@ -3,6 +3,7 @@ RNG consumption, error behaviour, config helpers, refusal of CPU tensors.  CPU o
 import copy
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -148,7 +149,34 @@ def test_helpers_surface(tmp_path):
     for n in (26, 28, 1001, 1002, 1003, 1005):
         args = HP.defaultdict_from_json(json.load(open(os.path.join(ROOT, "test_args", f"args{n}.json"))))
         assert args["T"] == 1000 and args["channels"] == "" and args["noise_fn"] in ("gauss", "simplex")
-    assert not hasattr(HP, "load_parameters") and not hasattr(HP, "load_checkpoint")     # control plane: not built
+    # helpers.py:26-93: checkpoint discovery + argv resolution, the checkpoint dict of diffusion_training.py:169-189 untouched
+    cwd, argv = os.getcwd(), sys.argv
+    try:
+        os.chdir(tmp_path)
+        os.makedirs("model/diff-params-ARGS=28/checkpoint")
+        ck = {"n_epoch": 3, "model_state_dict": {"w": torch.ones(2)}, "optimizer_state_dict": {}, "ema": {"w": torch.zeros(2)},
+              "args": HP.defaultdict_from_json({"arg_num": "28", "T": 1000})}
+        torch.save(ck, "model/diff-params-ARGS=28/params-final.pt")
+        torch.save(dict(ck, n_epoch=1000), "model/diff-params-ARGS=28/checkpoint/diff_epoch=1000.pt")
+        torch.save(dict(ck, n_epoch=2000), "model/diff-params-ARGS=28/checkpoint/diff_epoch=2000.pt")
+        open("model/diff-params-ARGS=28/checkpoint/diff_epoch=3000.pt", "wb").write(b"PK\x03\x04 truncated")   # corrupt: skipped
+        assert HP.load_checkpoint("28", False, "cpu")["n_epoch"] == 3
+        assert HP.load_checkpoint("28", True, "cpu")["n_epoch"] == 2000             # newest readable one
+        for spec in (["28"], ["args28"], ["args28.json"]):
+            sys.argv = ["detection.py"] + spec
+            args, out = HP.load_parameters("cpu")
+            assert out["n_epoch"] == 3 and args["noise_fn"] == "gauss" and args["missing"] == ""
+        sys.argv = ["detection.py", "CHECKPOINT", "28"]
+        assert HP.load_parameters("cpu")[1]["n_epoch"] == 2000
+        sys.argv = ["detection.py"]                                             # no argv: the entries of ./model
+        with pytest.raises(ValueError):
+            HP.load_parameters("cpu")                                           # "diff-params-ARGS=28" is not a valid spec upstream either
+        sys.argv = ["detection.py", "bogus"]
+        with pytest.raises(ValueError):
+            HP.load_parameters("cpu")
+    finally:
+        os.chdir(cwd)
+        sys.argv = argv
 
 
 def test_conv_launch_policy_on_config2_shapes():
