@@ -55,9 +55,10 @@ def build(force=False, verbose=False):
     stamp = os.path.join(OBJDIR, "flags.txt")
     if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
         force = True
-        with open(stamp, "w") as f:
-            f.write(" ".join(flags))
-    deps = [HEADER, os.path.join(CSRC, "common.h"), os.path.abspath(__file__)]
+        if os.path.exists(stamp):
+            os.remove(stamp)                     # re-written only after EVERY object compiled with the new flags
+    # every header under csrc/ is a dependency of every object (simplex_tables.h and pack_items.h carry bit-exact tables)
+    deps = [HEADER, os.path.abspath(__file__)] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     dep_m = max(os.path.getmtime(d) for d in deps)
     objs, rebuilt = [], False
     procs = []
@@ -71,12 +72,20 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
             rebuilt = True
+    failed = []
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
-        if verbose and out.strip():
+            failed.append(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
+            o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+            if os.path.exists(o):
+                os.remove(o)                     # never leave an object of the previous flag set behind a failure
+        elif verbose and out.strip():
             print(out.decode(errors="replace"))
+    if failed:
+        raise RuntimeError("\n".join(failed))
+    with open(stamp, "w") as f:
+        f.write(" ".join(flags))
     if rebuilt or not os.path.exists(SO):
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs]
         subprocess.check_call(cmd)

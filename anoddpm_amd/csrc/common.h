@@ -28,6 +28,24 @@ inline int check_launch(const char *what)
     return ANODDPM_OK;
 }
 
+// Kernels that ask for more than 64 KB of dynamic LDS: the limit is a per-DEVICE function attribute.  `done` is the call site's
+// own `static bool[ANODDPM_MAX_DEV]`; the flag of a device is set only after the call succeeded there (a repeated call from a
+// second thread is harmless: the attribute is idempotent).
+constexpr int ANODDPM_MAX_DEV = 64;
+inline int allow_big_lds(const void *fn, bool *done, const char *what)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ANODDPM_MAX_DEV) dev = -1;
+    if (dev >= 0 && done[dev]) return ANODDPM_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", what, hipGetErrorString(e));
+        return ANODDPM_ELAUNCH;
+    }
+    if (dev >= 0) done[dev] = true;
+    return ANODDPM_OK;
+}
+
 int launch_winograd(const anoddpm_igemm_args *a, hipStream_t s);   // winograd.hip (cfg == 2 of anoddpm_igemm)
 int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s); // winograd43.hip (cfg == 3)
 int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s); // winograd43r.hip (cfg == 3, 128-channel workgroups)

@@ -359,7 +359,7 @@ int launch_smallmap(const anoddpm_igemm_args *a, hipStream_t s)
     const int K = a->c0 + a->c1;
     ANODDPM_REQUIRE(a->b_mode == 0 && a->heads == 1 && a->a_mode == 0 && a->ksplit == 1, "smallmap: needs packed weights, heads 1, a_mode 0, ksplit 1");
     const int tile = smallmap_tile(a->ks, a->H, a->W, K, a->c0, a->N, a->B);
-    ANODDPM_REQUIRE(tile != 0, "smallmap: shape not supported (H*W <= 256, W in {4, 8, 16}, K %% 4 == 0, K <= 1024, N %% 32 == 0)");
+    ANODDPM_REQUIRE(tile != 0, "smallmap: shape not supported (H*W <= 256, W in {4, 8, 16}, K %% 16 == 0, 16 <= K <= 1024, N %% 32 == 0)");
     ANODDPM_REQUIRE(a->c1 == 0 || a->a1, "smallmap: dual source needs a1");
     ANODDPM_REQUIRE(a->out_ld % 4 == 0 && (!a->res || a->res_ld % 4 == 0) && a->a0_ld % 4 == 0 && (a->c1 == 0 || a->a1_ld % 4 == 0),
                     "smallmap: pixel strides must be multiples of 4 floats");
@@ -387,12 +387,10 @@ int launch_smallmap(const anoddpm_igemm_args *a, hipStream_t s)
     dim3 grid((unsigned)(a->N / TN), (unsigned)((int64_t)a->B * P / TM));
 #define SM_LAUNCH(KS_, RT_, CT_, LW_)                                                                                     \
     do {                                                                                                                  \
-        static bool attr_done = false;                                                                                    \
-        if (!attr_done) {                                                                                                 \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&smallmap_kernel<KS_, RT_, CT_, LW_>),                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                  \
-            attr_done = true;                                                                                             \
-        }                                                                                                                 \
+        static bool attr_done[ANODDPM_MAX_DEV];                                                                           \
+        if (int rc_ = allow_big_lds(reinterpret_cast<const void *>(&smallmap_kernel<KS_, RT_, CT_, LW_>), attr_done,      \
+                                    "igemm(smallmap)"))                                                                   \
+            return rc_;                                                                                                   \
         hipLaunchKernelGGL((smallmap_kernel<KS_, RT_, CT_, LW_>), grid, dim3(SM_NT), lds, s, *a);                         \
         return check_launch("igemm(smallmap)");                                                                           \
     } while (0)

@@ -366,12 +366,9 @@ int launch_wino23s(const anoddpm_igemm_args *a, hipStream_t s)
     const size_t lds = (size_t)(2 * K + 2 * WS_VBUF + 2 * WS_PBUF) * sizeof(float);
     ANODDPM_REQUIRE(lds <= 160 * 1024, "wino23s: LDS budget exceeded");
     dim3 grid((unsigned)(a->N / (16 * ct)), (unsigned)(a->B * (a->H / 8) * (a->W / 8)));
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino23s_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino23s_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static bool attr_done2[ANODDPM_MAX_DEV], attr_done4[ANODDPM_MAX_DEV];
+    if (int rc = allow_big_lds(reinterpret_cast<const void *>(&wino23s_kernel<2>), attr_done2, "igemm(wino23s)")) return rc;
+    if (int rc = allow_big_lds(reinterpret_cast<const void *>(&wino23s_kernel<4>), attr_done4, "igemm(wino23s)")) return rc;
     if (ct == 2) hipLaunchKernelGGL((wino23s_kernel<2>), grid, dim3(WS_NT), lds, s, *a);
     else         hipLaunchKernelGGL((wino23s_kernel<4>), grid, dim3(WS_NT), lds, s, *a);
     return check_launch("igemm(wino23s)");

@@ -361,11 +361,8 @@ int launch_winograd43b(const anoddpm_igemm_args *a, hipStream_t s)
     ANODDPM_REQUIRE((int64_t)a->H * a->W * (a->a0_ld > a->a1_ld ? a->a0_ld : a->a1_ld) * 4 < ((int64_t)1 << 31), "winograd43b: operand slice exceeds 32-bit buffer offsets");
     ANODDPM_REQUIRE(!a->tail_csum && !a->fold_gamma, "winograd43b: no split-K tail, no GroupNorm fold");
     ANODDPM_REQUIRE(a->B <= 65535, "winograd43b: batch too large");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino43b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static bool attr_done[ANODDPM_MAX_DEV];
+    if (int rc = allow_big_lds(reinterpret_cast<const void *>(&wino43b_kernel), attr_done, "igemm(winograd43b)")) return rc;
     dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / 128), (unsigned)a->B);
     hipLaunchKernelGGL(wino43b_kernel, grid, dim3(B4_NT), B4_LDS_BYTES, s, *a);
     return check_launch("igemm(winograd43b)");

@@ -160,7 +160,8 @@ class ReverseChain:
         self.remaining = int(t_distance)
         # a train()-mode model with dropout draws a fresh mask per forward from the host generator (UNet.py:192): it goes
         # through model.forward (eager), not through the captured inference plan
-        self.hip_model = hasattr(model, "forward_hip") and not (getattr(model, "training", False) and getattr(model, "dropout", 0) > 0)
+        self.hip_model = hasattr(model, "forward_hip") and not self._draws_dropout(model)
+        self._plan = None              # the inference plan a captured graph points into (set at capture)
         self.noise = None
         self.tables = None
         # Which noise sources may run inside a captured HIP graph: device-side philox draws ("gauss" / "random":
@@ -188,7 +189,16 @@ class ReverseChain:
         elif use_graph and not capture_safe:
             raise ValueError("ReverseChain(use_graph=True): this denoise_fn draws host-side random numbers every step "
                              "and cannot be replayed from a captured graph; pass a SimplexNoiseFn or 'gauss'")
+        elif use_graph and not self.hip_model:
+            # a train()-mode dropout model seeds its masks on the host per forward: captured once, every replay would repeat
+            # the first step's mask; a foreign callable's launches are not known to be capture-safe at all
+            raise ValueError("ReverseChain(use_graph=True): the model is not the built-in UNetModel in a dropout-free "
+                             "mode (model.eval(), or dropout == 0); its forward cannot be replayed from a captured graph")
         self.use_graph = bool(use_graph)
+
+    @staticmethod
+    def _draws_dropout(model):
+        return bool(getattr(model, "training", False) and getattr(model, "dropout", 0) > 0)
 
     @staticmethod
     def _resolve_noise(owner, denoise_fn):
@@ -254,8 +264,9 @@ class ReverseChain:
         if self.tables is not None:
             self._draw_tables(self.remaining)
         if self.hip_model and self._graph_state == 2:
-            # the replayed graph reads the plan's packed weights: let the plan re-pack them if the parameters moved since
-            self.model._plan_for(self.B, self.x.shape[2], self.x.device)
+            # the replayed graph reads the packed weights of the plan it was captured with (NOT whatever _plan_for would pick
+            # now -- ANODDPM_ARITH may have changed since): let THAT plan re-pack them if the parameters moved since
+            self._plan.refresh_weights()
         return self
 
     def step(self):
@@ -267,6 +278,8 @@ class ReverseChain:
             if self._graph_state == 1:
                 # everything a step touches is static (x, t, step counter, noise, tables, plan buffers)
                 torch.cuda.synchronize()
+                if self.hip_model:
+                    self._plan = self.model._plan_for(self.B, self.x.shape[2], self.x.device)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._step_body()
@@ -607,7 +620,9 @@ class GaussianDiffusionModel:
         if want is not None:
             key = (id(model), tuple(x.shape), str(x.device), want)
             chain = cache.get(key)
-            if chain is not None and chain.model is model:
+            # a kept chain replays the dropout-free inference graph: not for a model that has since been put in train() mode
+            # with dropout > 0 (it gets a fresh eager chain below, which is not kept)
+            if chain is not None and chain.model is model and not ReverseChain._draws_dropout(model):
                 return chain.reset(x, t_distance)
         chain = ReverseChain(self, model, x, t_distance, denoise_fn)
         if chain.use_graph and chain.reuse_key is not None:
