@@ -140,6 +140,31 @@ class SimplexNoiseFn:
                                       self.in_channels)
 
 
+def plan_chain_slots(lengths, slots):
+    """Longest-first list schedule of reverse chains on `slots` chain slots (host logic of `_run_chains`).
+
+    lengths[i] > 0: steps of chain i.  Returns (makespan, [(slot, first_step), ...] per chain): a chain occupies one slot for
+    `lengths[i]` consecutive global steps; a freed slot takes the longest pending chain.  makespan <= ceil(sum / slots) + max - 1
+    (Graham's bound for list scheduling), and with the detection sweeps' lengths the slots end within one short chain of each other."""
+    import heapq
+    if slots < 1:
+        raise ValueError("plan_chain_slots: slots must be >= 1")
+    if any(int(l) <= 0 for l in lengths):
+        raise ValueError("plan_chain_slots: chain lengths must be positive")
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    free = [(0, s) for s in range(slots)]
+    heapq.heapify(free)
+    place = [None] * len(lengths)
+    makespan = 0
+    for i in order:
+        t0, slot = heapq.heappop(free)
+        place[i] = (slot, t0)
+        t1 = t0 + int(lengths[i])
+        makespan = max(makespan, t1)
+        heapq.heappush(free, (t1, slot))
+    return makespan, place
+
+
 class ReverseChain:
     """Device-resident state of the reverse loop (GaussianDiffusion.py:351-357): x, t and a step counter
     live in HBM; one step = model forward + noise + ONE fused update launch + t -= 1."""
@@ -801,13 +826,18 @@ class GaussianDiffusionModel:
             output[(i - 1) * 6:i * 6, ...] = torch.cat((x_0, x_noised, x, mse, mse_threshold, mask))
         return output
 
-    # The (t_distance, avg) loops of detection_A / detection_B.  Upstream runs `total_avg` chains of one image
-    # one after the other (:499-514, :554-569); the chains are independent, so they are stacked as ONE batch:
-    # total_avg x fewer UNet launches at a batch size that fills the GPU, the mean / mse / threshold images and
-    # the segmentation counts come from one fused pass (metrics.anomaly_maps).  RNG: the same generators are
-    # consumed (np.random for simplex seeds, torch's for randn) but the draws of different chains interleave
-    # differently from the serial loop, so outputs are equal in distribution, not sample-for-sample.
+    # The (t_distance, avg) loops of detection_A / detection_B.  Upstream runs every chain of one image one after the other
+    # (:499-514, :554-569).  The chains are independent of each other -- every (t_distance, avg) pair, and in detection_A every
+    # frequency too -- so ALL chains of a call share one batched reverse loop: `slots` device-resident chain slots
+    # with a per-slot timestep (the UNet and the fused update take per-sample `t`), stepped together by ONE captured graph; a slot
+    # whose chain reaches t = 0 hands its image over and starts the next pending chain (longest first, so the slots drain together).
+    # The batch size is therefore constant (the quantisation-free sizes of DESIGN 10-6: 16 by default) whatever `total_avg` and the
+    # t_distance sweep are.  The mean / mse / threshold images and the segmentation counts of a setting come from one fused pass
+    # (metrics.anomaly_maps).  RNG: the same generators are consumed (np.random for simplex seeds, torch's for randn), the forward
+    # noise in upstream's order, but the reverse-step draws of different chains interleave differently from the serial loop, so
+    # outputs are equal in distribution, not sample-for-sample.
     def _avg_chains(self, model, x_0, t_distance, total_avg):
+        """One setting: `total_avg` chains of the same length as one batch (all slots start and end together)."""
         _lib.require_cuda(x_0, "GaussianDiffusionModel.detection")
         if x_0.shape[0] != 1:
             raise ValueError("detection loops take one image (upstream stores each chain into output[avg], :514)")
@@ -816,6 +846,74 @@ class GaussianDiffusionModel:
         x = self.sample_q(x_0.repeat(total_avg, 1, 1, 1), t_tensor.repeat(total_avg), noise)
         with torch.no_grad():
             return self._reverse_chain(model, x, int(t_distance), "gauss", None)      # sample_p default noise, :508
+
+    def _forward_noise(self, x_0, t_distance, n):
+        """`n` draws of the forward noise of one setting, in upstream's order (:501-505, :556-560)."""
+        t_tensor = torch.full((1,), int(t_distance), device=x_0.device, dtype=torch.int64)
+        return [self.noise_fn(x_0, t_tensor).float() for _ in range(n)]
+
+    def _run_chains(self, model, x_0, t_distances, noise, slots=None):
+        """Reverse chains of ONE image with individual lengths, batched over `slots` chain slots.
+
+        t_distances[c] / noise[c]: chain c is `sample_q(x_0, t_distances[c], noise[c])` followed by t_distances[c] steps of
+        `sample_p(model, x, t)` with the default gaussian step noise (GaussianDiffusion.py:501-512, 556-567).  Returns the final
+        images, [len(t_distances), C, H, W].  The schedule (which slot, which global step) is kept in `self.last_chain_schedule`."""
+        import os
+        _lib.require_cuda(x_0, "GaussianDiffusionModel.detection")
+        if x_0.shape[0] != 1:
+            raise ValueError("detection loops take one image (upstream stores each chain into output[avg], :514)")
+        n = len(t_distances)
+        lens = [int(d) for d in t_distances]
+        out = torch.empty((n,) + tuple(x_0.shape[1:]), device=x_0.device, dtype=torch.float32)
+        if n == 0:
+            return out
+        if min(lens) < 0 or max(lens) > self.num_timesteps - 1:
+            # sample_q at t = t_distance reads the T-entry tables: upstream's extract() raises for t_distance >= T
+            raise IndexError(f"t_distance {max(lens)} is out of range for a {self.num_timesteps}-step schedule")
+        if slots is None and os.environ.get("ANODDPM_DET_SLOTS"):
+            slots = int(os.environ["ANODDPM_DET_SLOTS"])
+        if slots is None:
+            # a batched step costs about (2 + G) image-units (DESIGN 8b: a batch-independent floor worth two images): take the
+            # slot count among the quantisation-free sizes whose longest-first schedule is cheapest
+            pos = [l for l in lens if l > 0] or [1]
+            slots = min((g for g in (16, 12, 8) if g <= max(n, 8)), key=lambda g: plan_chain_slots(pos, min(g, len(pos)))[0] * (2 + min(g, len(pos))))
+        G = max(1, min(int(slots), n))
+        t_all = torch.tensor(lens, device=x_0.device, dtype=torch.int64)
+        x_start = self.sample_q(x_0.repeat(n, 1, 1, 1), t_all, noise)
+        live = [c for c in range(n) if lens[c] > 0]
+        for c in range(n):
+            if lens[c] == 0:
+                out[c].copy_(x_start[c])                               # no reverse step: the noised image itself
+        makespan, place = plan_chain_slots([lens[c] for c in live], G)
+        self.last_chain_schedule = {"slots": G, "steps": makespan, "chain_steps": sum(lens),
+                                    "place": {live[i]: place[i] for i in range(len(live))}}
+        if makespan == 0:
+            return out
+        refill, harvest = {}, {}
+        last_busy = [0] * G                                            # first global step at which a slot has nothing left to do
+        for i, (slot, start) in enumerate(place):
+            c = live[i]
+            refill.setdefault(start, []).append((slot, c))
+            harvest.setdefault(start + lens[c] - 1, []).append((slot, c))
+            last_busy[slot] = max(last_busy[slot], start + lens[c])
+        with torch.no_grad():
+            chain = self._chain_for(model, x_start[:1].expand(G, -1, -1, -1).contiguous(), 1, "gauss")
+            chain.remaining = makespan
+            for slot in range(G):
+                if last_busy[slot] == 0:                                # fewer chains than slots cannot happen (G <= n); kept for safety
+                    chain.t[slot:slot + 1].fill_(makespan - 1)
+            for k in range(makespan):
+                for slot, c in refill.get(k, ()):
+                    chain.x[slot].copy_(x_start[c])
+                    chain.t[slot:slot + 1].fill_(lens[c] - 1)
+                chain.step()
+                for slot, c in harvest.get(k, ()):
+                    out[c].copy_(chain.x[slot])
+                    if last_busy[slot] == k + 1 and k + 1 < makespan:
+                        # nothing left for this slot: it idles on its last image with a timestep that stays >= 0 to the end
+                        chain.t[slot:slot + 1].fill_(makespan - k - 2)
+            chain.finish()
+        return out
 
     def _detection_record(self, x_0, output, mask, extra):
         from . import metrics
@@ -826,22 +924,29 @@ class GaussianDiffusionModel:
         return rec, maps
 
     def detection_A(self, model, x_0, args, file, mask, total_avg=2):
-        """GaussianDiffusion.py:480-529: simplex frequencies 2^7..2^1 x t_distance 50..0.6T step 50, `total_avg` chains each
-        (batched here).  Returns None as upstream; the per-setting results upstream only plots (the figure files are file / plot
-        I/O, out of scope) are kept in `self.last_detection`: mean / mse / threshold images and the segmentation counts, on the device."""
-        self.last_detection = []
+        """GaussianDiffusion.py:480-529: simplex frequencies 2^7..2^1 x t_distance 50..0.6T step 50, `total_avg` chains each -- all
+        of them one batched reverse loop (`_run_chains`).  Returns None as upstream; the per-setting results upstream only plots
+        (the figure files are file / plot I/O, out of scope) are kept in `self.last_detection`, in upstream's loop order: mean /
+        mse / threshold images and the segmentation counts, on the device."""
+        settings, dists, noise = [], [], []
         for i in range(7, 0, -1):
             freq = 2 ** i
             self.noise_fn = SimplexNoiseFn(self.simplex, frequency=freq, in_channels=self.img_channels)     # :491-494
             for t_distance in range(50, int(args["T"] * 0.6), 50):
-                output = self._avg_chains(model, x_0, t_distance, total_avg)
-                rec, _ = self._detection_record(x_0, output, mask, {"freq": i, "t_distance": t_distance})
-                self.last_detection.append(rec)
+                settings.append({"freq": i, "t_distance": t_distance})
+                dists += [t_distance] * total_avg
+                noise += self._forward_noise(x_0, t_distance, total_avg)
+        outputs = self._run_chains(model, x_0, dists, torch.cat(noise) if noise else None)
+        self.last_detection = []
+        for j, extra in enumerate(settings):
+            rec, _ = self._detection_record(x_0, outputs[j * total_avg:(j + 1) * total_avg].clone(), mask, extra)
+            self.last_detection.append(rec)
 
     def detection_B(self, model, x_0, args, file, mask, denoise_fn="gauss", total_avg=5):
         """GaussianDiffusion.py:531-594: t_distance 50..end step 50 with gaussian or 6-octave simplex forward noise,
-        `total_avg` chains each (batched here).  Returns the list upstream returns -- the values of `evaluation.heatmap(...)`,
-        which are None -- and keeps the device-side results in `self.last_detection` (the figures upstream writes are out of scope)."""
+        `total_avg` chains each -- all (t_distance, avg) chains one batched reverse loop (`_run_chains`).  Returns the list upstream
+        returns -- the values of `evaluation.heatmap(...)`, which are None -- and keeps the device-side results in
+        `self.last_detection` (the figures upstream writes are out of scope)."""
         assert type(file) == tuple
         if denoise_fn == "octave":
             end = int(args["T"] * 0.6)
@@ -849,11 +954,16 @@ class GaussianDiffusionModel:
         else:
             end = int(args["T"] * 0.8)
             self.noise_fn = lambda x, t: torch.randn_like(x)
+        settings = list(range(50, end, 50))
+        dists, noise = [], []
+        for t_distance in settings:
+            dists += [t_distance] * total_avg
+            noise += self._forward_noise(x_0, t_distance, total_avg)
+        outputs = self._run_chains(model, x_0, dists, torch.cat(noise) if noise else None)
         dice_coeff = []
         self.last_detection = []
-        for t_distance in range(50, end, 50):
-            output = self._avg_chains(model, x_0, t_distance, total_avg)
-            rec, _ = self._detection_record(x_0, output, mask, {"t_distance": t_distance})
+        for j, t_distance in enumerate(settings):
+            rec, _ = self._detection_record(x_0, outputs[j * total_avg:(j + 1) * total_avg].clone(), mask, {"t_distance": t_distance})
             self.last_detection.append(rec)
             dice_coeff.append(None)                                 # evaluation.heatmap() returns None (evaluation.py:12-22)
         return dice_coeff

@@ -52,9 +52,10 @@ CONFIGS = {
     "c4": dict(kind="simplex", img=256, slices=1000, octaves=8, batch=1,
                name="simplex rand_3d_octaves volume 1000x256x256, 8 octaves, persistence 0.8, frequency 64, fp64 "
                     "(BASELINE config 4)"),
-    "det": dict(kind="detect", img=256, base=128, mults="", attn="16,8", heads=2, batch=5, t_distance=50,
-                name="detection_B setting @256x256 (GaussianDiffusion.py:531-594): 5 averaged chains x 50 reverse steps from "
-                     "octave-simplex-noised x_0 + anomaly maps, base128 attn16,8, one image per GPU (SURVEY 8f row 1)"),
+    "det": dict(kind="detect", img=256, base=128, mults="", attn="16,8", heads=2, batch=5,
+                name="detection_B sweep @256x256 (GaussianDiffusion.py:531-594): every (t_distance, avg) chain of range(50, 600, 50) x 5 "
+                     "from octave-simplex-noised x_0, slot-batched, + anomaly maps per setting, base128 attn16,8, one image per GPU "
+                     "(SURVEY 8f row 1)"),
 }
 T_STEPS = 1000
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -751,45 +752,55 @@ def run_simplex(c, args, cfg):
 
 
 def run_detect(c, args, cfg):
-    """The product loop around the hot path: one (t_distance) setting of detection_B for one image per GPU =
-    forward-noise `total_avg` copies, run them as ONE batched reverse chain (graph replay), reduce to the mean / mse / threshold
-    maps and the segmentation counts on the device.  A step is one whole setting; value = reverse chain-steps per second."""
+    """The product loop around the hot path: the WHOLE detection_B sweep of one image per GPU -- every
+    (t_distance, avg) chain of `range(50, end, 50)` x `total_avg` (GaussianDiffusion.py:531-594, "octave" variant: 6-octave simplex
+    forward noise, end = 0.6 T) in one slot-batched reverse loop (graph replay, per-slot timesteps, longest chain first), then the
+    mean / mse / threshold maps and segmentation counts of every setting on the device.  A step is one whole image; value =
+    reverse chain-steps per second.  `--det-end` shortens the sweep (tests); `--batch` is total_avg."""
     import GaussianDiffusion as GD
     from UNet import UNetModel
-    navg, td = args.batch or cfg["batch"], cfg["t_distance"]
+    navg = args.batch or cfg["batch"]
+    end = args.det_end or int(T_STEPS * 0.6)
     torch.manual_seed(1234)
     np.random.seed(1234 + c.rank)
     model = UNetModel(cfg["img"], cfg["base"], channel_mults=cfg["mults"], n_heads=cfg["heads"], attention_resolutions=cfg["attn"])
     fill_weights(model)
     model.to(c.dev).eval()
     diff = GD.GaussianDiffusionModel([cfg["img"]] * 2, GD.get_beta_schedule(T_STEPS, "linear"), noise="simplex")
-    diff.noise_fn = GD.SimplexNoiseFn(diff.simplex, octave=6, persistence=0.8, frequency=64)          # detection_B "octave", :547-550
     x0 = mri_like(1, cfg["img"], c.dev, seed=1234 + c.rank)
     mask = (mri_like(1, cfg["img"], c.dev, seed=99 + c.rank) > 0.2).float()
-    last = {}
+    dargs = {"arg_num": "bench", "T": int(round(end / 0.6)), "img_size": [cfg["img"]] * 2}      # detection_B: end = int(T * 0.6)
 
     def step():
-        output = diff._avg_chains(model, x0, td, navg)
-        last["rec"], _ = diff._detection_record(x0, output, mask, {"t_distance": td})
+        diff.detection_B(model, x0, dargs, ("bench", "image"), mask, denoise_fn="octave", total_avg=navg)
     elapsed = timed(c, args, step)
     ms_per_step = 1000.0 * elapsed / args.steps
-    value = navg * td * c.world / (ms_per_step / 1000.0)
-    out = {"metric": f"detection_B reverse chain-steps/sec @{cfg['img']}x{cfg['img']} ({navg} averaged chains x {td} steps + anomaly maps per setting)",
+    sched = diff.last_chain_schedule
+    settings = [r["t_distance"] for r in diff.last_detection]
+    chain_steps = sched["chain_steps"]
+    value = chain_steps * c.world / (ms_per_step / 1000.0)
+    out = {"metric": f"detection_B reverse chain-steps/sec @{cfg['img']}x{cfg['img']} (whole sweep of one image: t_distance "
+                     f"{settings[0]}..{settings[-1]} step 50 x {navg} averaged chains + anomaly maps per setting)",
            "value": value, "unit": "chain-steps/s", "ms_per_step": ms_per_step, "scaling": "weak", "dtype": "f32",
-           "config": {"workload": cfg["name"], "chains_per_setting": navg, "t_distance": td,
-                      "ms_per_chain_step_batched": ms_per_step / td,
-                      "parallelism": f"images x{c.world} (one image's settings per rank, no collective)",
-                      "output_finite": bool(torch.isfinite(last["rec"]["mse"]).all().item())}}
+           "config": {"workload": cfg["name"], "chains_per_setting": navg, "settings": settings, "chains": len(settings) * navg,
+                      "chain_steps_per_image": chain_steps, "slots": sched["slots"], "batched_steps_per_image": sched["steps"],
+                      "slot_utilisation": chain_steps / (sched["slots"] * sched["steps"]),
+                      "ms_per_image": ms_per_step, "ms_per_chain_step": ms_per_step / chain_steps,
+                      "ms_per_batched_step": ms_per_step / sched["steps"],
+                      "round4_ms_per_chain_step": 13.36 / 5,
+                      "parallelism": f"images x{c.world} (one image's sweep per rank, no collective)",
+                      "output_finite": bool(all(torch.isfinite(r["mse"]).all().item() for r in diff.last_detection))}}
     return out, None, (lambda: {"value": None, "note": "see config c2: the per-step CPU baseline is the same reverse step"})
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; config det, whose step is a whole image's sweep: 2)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; config det: 1)")
     ap.add_argument("--config", default="c2", choices=list(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--det-end", type=int, default=0, help="config det: end of the t_distance sweep range(50, end, 50) (default 0.6 T = 600)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--dump-plan", default="", help="write the igemm launch list of the compiled plan (JSON) here")
@@ -801,6 +812,10 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.steps is None:
+        args.steps = 2 if args.config == "det" else 20
+    if args.warmup is None:
+        args.warmup = 1 if args.config == "det" else 3
     if args.arith != "fp32":
         os.environ["ANODDPM_ARITH"] = args.arith              # read by the inference plan when it is built
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

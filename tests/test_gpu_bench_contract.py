@@ -72,12 +72,15 @@ def test_bench_line_simplex_and_training_configs():
     assert any("wgrad43_kernel" in k for k in kernels) and all(0 < k["achieved"] <= r["peak"] for k in r["other_contraction_kernels"])
 
 
-def test_bench_line_detection_setting():
-    """`--config det`: one detection_B setting end to end (batched chains + on-device anomaly maps), a side line."""
-    d = run_bench("--config", "det", "--no-cpu-baseline")
+def test_bench_line_detection_sweep():
+    """`--config det`: one image's detection_B sweep end to end (every (t_distance, avg) chain slot-batched + on-device anomaly
+    maps), a side line.  Shortened sweep here: range(50, 150, 50) x 5 chains."""
+    d = run_bench("--config", "det", "--no-cpu-baseline", "--det-end", "150")
     assert d["unit"] == "chain-steps/s" and d["value"] > 0 and d["config"]["output_finite"] is True
-    assert d["config"]["chains_per_setting"] == 5 and d["config"]["t_distance"] == 50
-    assert abs(d["value"] - 250 / (d["ms_per_step"] / 1000.0)) < 1e-6 * d["value"]
+    cf = d["config"]
+    assert cf["chains_per_setting"] == 5 and cf["settings"] == [50, 100] and cf["chains"] == 10 and cf["chain_steps_per_image"] == 750
+    assert cf["slots"] * cf["batched_steps_per_image"] >= 750 and 0 < cf["slot_utilisation"] <= 1
+    assert abs(d["value"] - 750 / (d["ms_per_step"] / 1000.0)) < 1e-6 * d["value"]
 
 
 def test_bench_under_torchrun_one_rank_uses_rccl():

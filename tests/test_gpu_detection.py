@@ -47,6 +47,42 @@ def test_batched_chains_equal_serial_chains():
         assert torch.allclose(batched[b:b + 1], x, atol=1e-4, rtol=0), float((batched[b:b + 1] - x).abs().max())
 
 
+def test_mixed_length_chains_on_slots_equal_serial_chains():
+    """All (t_distance, avg) chains of one image in ONE batched loop: chains of different lengths share `slots`
+    chain slots, a finished slot starts the next pending chain.  Every chain equals the same chain run alone with the draws its
+    slot saw (global step k of the batched loop, row `slot`)."""
+    GD, m, d = tiny()
+    torch.manual_seed(3)
+    x_0 = torch.rand(1, 1, 32, 32, device=DEV) * 2 - 1
+    dists = [9, 9, 6, 6, 3, 3, 1, 0, 12]                       # incl. a chain without reverse steps and one longer than the rest
+    n, G = len(dists), 4
+    fwd = torch.randn(n, 1, 32, 32, device=DEV)
+    torch.manual_seed(17)
+    out = d._run_chains(m, x_0, dists, fwd, slots=G)
+    sched = d.last_chain_schedule
+    assert out.shape == (n, 1, 32, 32) and torch.isfinite(out).all()
+    assert sched["slots"] == G and sched["chain_steps"] == sum(dists) and sched["steps"] >= -(-sum(dists) // G)
+    torch.manual_seed(17)
+    draws = [torch.randn(G, 1, 32, 32, device=DEV) for _ in range(sched["steps"])]
+    for c, dist in enumerate(dists):
+        x = d.sample_q(x_0, torch.full((1,), dist, device=DEV, dtype=torch.int64), fwd[c:c + 1])
+        if dist == 0:
+            assert torch.equal(out[c:c + 1], x)
+            continue
+        slot, start = sched["place"][c]
+        for i, t in enumerate(range(dist - 1, -1, -1)):
+            tb = torch.full((1,), t, device=DEV, dtype=torch.int64)
+            with torch.no_grad():
+                x = d.sample_p(m, x, tb, denoise_fn=lambda xx, tt, k=start + i, s=slot: draws[k][s:s + 1])["sample"]
+        assert torch.allclose(out[c:c + 1], x, atol=1e-4, rtol=0), (c, float((out[c:c + 1] - x).abs().max()))
+    # a second sweep on the kept chain (graph replay from the first step on), other slot count chosen by the cost rule
+    out2 = d._run_chains(m, x_0, [5, 4, 3], fwd[:3])
+    assert out2.shape == (3, 1, 32, 32) and torch.isfinite(out2).all() and d.last_chain_schedule["slots"] == 3
+    with pytest.raises(IndexError):
+        d._run_chains(m, x_0, [100], fwd[:1])                     # sample_q at t = T: upstream's extract() raises too
+    assert d._run_chains(m, x_0, [], None).shape == (0, 1, 32, 32)
+
+
 def test_reverse_chain_is_reused_across_settings_and_matches_a_fresh_chain():
     """The detection loops run many chains of one batch shape: after the first, a chain is restarted on the same device buffers
     and the same captured graph (ReverseChain.reset).  Restarted chains give bit-identical results to freshly built ones -- other
@@ -100,6 +136,7 @@ def test_detection_B_records_and_return(tmp_path, monkeypatch):
     args = {"arg_num": 9, "T": 100, "img_size": [32, 32]}
     out = d.detection_B(m, x_0, args, ("vol", "slice"), mask, denoise_fn="gauss", total_avg=2)
     assert out == [None]                                     # range(50, 80, 50): upstream appends heatmap()'s None
+    assert d.last_chain_schedule["chain_steps"] == 100 and d.last_chain_schedule["slots"] == 2
     assert not os.path.exists(tmp_path / "diffusion-videos")
     rec = d.last_detection[0]
     assert rec["t_distance"] == 50 and rec["output"].shape == (2, 1, 32, 32)

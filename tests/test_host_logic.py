@@ -261,3 +261,30 @@ def test_reverse_chain_reuse_keys():
     assert key(d, lambda x, t: x) is None
     d.noise_fn = lambda x, t: x                                                                   # user-replaced noise_fn: host side, eager
     assert key(d, "noise_fn") is None
+
+
+def test_chain_slot_schedule():
+    """diffusion.plan_chain_slots: the host-side schedule behind the batched detection loops."""
+    from anoddpm_amd.diffusion import plan_chain_slots
+    for lengths, slots in (([d for d in range(50, 800, 50) for _ in range(5)], 16), ([d for d in range(50, 600, 50) for _ in range(2)] * 7, 16),
+                           ([7, 3, 3, 1], 2), ([5], 4), ([], 3)):
+        makespan, place = plan_chain_slots(lengths, slots)
+        assert len(place) == len(lengths)
+        busy = {}
+        for L, (slot, start) in zip(lengths, place):
+            assert 0 <= slot < slots and start >= 0 and start + L <= makespan
+            for k in range(start, start + L):
+                assert (slot, k) not in busy                      # one chain per slot and step
+                busy[(slot, k)] = 1
+        total = sum(lengths)
+        assert len(busy) == total
+        if lengths:
+            assert makespan >= -(-total // slots) and makespan <= -(-total // slots) + max(lengths) - 1 + (1 if total % slots else 0)
+            assert makespan >= max(lengths)
+    # the detection_B gaussian sweep (15 settings x 5 chains) keeps 16 slots 96 % busy
+    m, _ = plan_chain_slots([d for d in range(50, 800, 50) for _ in range(5)], 16)
+    assert m == 1950
+    with pytest.raises(ValueError):
+        plan_chain_slots([3, 0], 2)
+    with pytest.raises(ValueError):
+        plan_chain_slots([3], 0)
