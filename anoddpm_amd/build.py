@@ -23,7 +23,6 @@ SOURCES = {
     "winograd.hip": [],
     "winograd43.hip": [],
     "winograd43r.hip": [],
-    "winograd43p.hip": [],
     "winograd43b.hip": [],
     "pointwise.hip": [],
     "smallmap.hip": [],

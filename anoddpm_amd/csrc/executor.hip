@@ -69,14 +69,13 @@ using namespace anoddpm;
 
 // Kernel-variant selector for tests and measurements; NOT part of the public ABI (include/anoddpm_hip.h does not declare it).
 // In a product build only the keys whose every value still computes the right result are accepted (0: F(2x2) workgroup
-// shape, 4: head kernel form, 5: F(4x4) position- vs channel-sliced, 8: weight-gradient fold form, 9-12: persistent F(4x4)
-// form, winograd43p.hip); the timing ablations
+// shape, 4: head kernel form, 5: F(4x4) position- vs channel-sliced, 8: weight-gradient fold form); the timing ablations
 // that skip work (keys 1, 2, 3, 6, 7) exist only in a -DANODDPM_ABLATE build (ANODDPM_ABLATE=1 python -m anoddpm_amd.build).
 extern "C" int anoddpm_internal_variant(int32_t key, int32_t value)
 {
     if (key < 0 || key >= 16) return ANODDPM_EINVAL;
 #ifndef ANODDPM_ABLATE
-    if (!(key == 0 || key == 4 || key == 5 || key == 8 || (key >= 9 && key <= 12))) {
+    if (!(key == 0 || key == 4 || key == 5 || key == 8)) {
         set_error("internal_variant: key %d selects a timing ablation; this library was built without ANODDPM_ABLATE", key);
         return ANODDPM_EINVAL;
     }

@@ -435,13 +435,11 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
         ANODDPM_REQUIRE((a->ksplit - 1) * cps < K16, "winograd43: ksplit leaves a slice without channels");
         return launch_winograd43r(a, s);
     }
-    if (dbg == 0 && ((!half && anoddpm::g_debug[5] != 1) || (a->N % 128 == 0 && anoddpm::g_debug[5] == 3))) {
-        // several tiles per CU: the persistent form (winograd43p.hip) pipelines across tile boundaries
-        int taken = 0;
-        const int rc = anoddpm::g_debug[6] == 0 ? launch_winograd43p(a, s, &taken) : ANODDPM_OK;
-        if (taken || rc != ANODDPM_OK) return rc;
-        return launch_winograd43r(a, s);
-    }
+    // (round 5: a persistent form of the channel-sliced kernel -- one workgroup per CU, the step pipeline running across tile
+    // boundaries -- measured SLOWER, 307 vs 285 us on the 256x256 128->128 layer: vmcnt retires in order, so the next tile's B
+    // fragments wait behind the epilogue's 64 stores per lane, while a fresh workgroup starts beside its predecessor's
+    // draining stores for free; profiles/r5_f43_persistent_ab.txt)
+    if (dbg == 0 && ((!half && anoddpm::g_debug[5] != 1) || (a->N % 128 == 0 && anoddpm::g_debug[5] == 3))) return launch_winograd43r(a, s);
 #ifdef ANODDPM_ABLATE           // timing ablations (wrong results): measurement builds only
     if (fast && dbg == 1) hipLaunchKernelGGL((wino43_kernel<true, 1>), grid, dim3(F4_NT), 0, s, *a);
     else if (fast && dbg == 2) hipLaunchKernelGGL((wino43_kernel<true, 2>), grid, dim3(F4_NT), 0, s, *a);

@@ -470,77 +470,6 @@ def test_winograd_f43_conv(case, f43_variant):
     assert torch.allclose(tot[..., 1], (o * o).sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
 
 
-F43P_CASES = [
-    # B, (c0, c1), Cout, Hout, a_mode, temb, res (0 none, 1 full resolution, 2 half resolution), grid (0 = 256)
-    (2, (64, 0), 128, 64, 0, True, 1, 8),          # 32 tiles on 8 workgroups: four tiles each, XCD-contiguous walk
-    (3, (48, 0), 128, 48, 0, False, 0, 8),         # 27 tiles (not a multiple of 8): round-robin walk, ragged tile counts, 3 chunks
-    (2, (64, 64), 256, 64, 1, True, 2, 16),        # two channel blocks, concat, fused nearest x2, half-resolution residual
-    (1, (128, 0), 128, 128, 0, True, 1, 0),        # 64 tiles on a 256-wide grid request: one tile each (G = 64)
-    (4, (128, 0), 128, 256, 0, True, 1, 0),        # the 256x256 128 -> 128 layer of config 2 itself: 1024 tiles, four per CU
-    (2, (32, 0), 128, 32, 0, False, 0, 0),         # K = 32: two chunks -- not taken, falls back to the channel-sliced kernel
-]
-
-
-@pytest.mark.parametrize("case", F43P_CASES)
-@pytest.mark.parametrize("gn_act", [True, False])
-def test_winograd_f43_persistent_equals_channel_sliced(case, gn_act):
-    """csrc/winograd43p.hip (persistent workgroups, pipeline running across tile boundaries) against wino43r_kernel on the same
-    launch: same arithmetic in the same order, so outputs and GroupNorm statistic rows are equal BIT FOR BIT; and against the
-    direct fp64 convolution at the F(4x4) tolerance.  Start offsets and store policies change timing only."""
-    import hipops
-    from anoddpm_amd._lib import lib
-    B, (c0, c1), N, Hout, a_mode, use_temb, res_kind, grid = case
-    if gn_act is False and Hout >= 128:
-        pytest.skip("large shapes once")
-    C = c0 + c1
-    Hin = Hout if a_mode == 0 else Hout // 2
-    x = rnd(B, C, Hin, Hin, seed=191)
-    w = rnd(N, C, 3, 3, seed=192, scale=1.0 / math.sqrt(C * 9))
-    b = rnd(N, seed=193, scale=0.1)
-    gamma, beta = 1 + 0.1 * rnd(C, seed=194), 0.1 * rnd(C, seed=195)
-    temb = rnd(B, N, seed=196).to(dev()) if use_temb else None
-    res = None
-    if res_kind == 1:
-        res = hipops.nhwc(rnd(B, N, Hout, Hout, seed=197).to(dev())).contiguous()
-    elif res_kind == 2:
-        res = hipops.nhwc(rnd(B, N, Hout // 2, Hout // 2, seed=197).to(dev())).contiguous()
-    xs = hipops.nhwc(x.to(dev()))
-    srcs = [xs[..., :c0].contiguous()] + ([xs[..., c0:].contiguous()] if c1 else [])
-    gn = hipops.gn_affine(srcs, gamma.to(dev()), beta.to(dev())) if gn_act else None
-    kw = dict(Hout=Hout, ks=3, gn=gn, act=1 if gn_act else 0, a_mode=a_mode, temb=temb, res=res, res_up=res_kind == 2, cfg=3)
-
-    def run(mode, delay=0, aux=0):
-        for k, v in ((5, 3), (9, mode), (10, delay), (11, aux), (12, grid)):
-            assert lib().anoddpm_internal_variant(k, v) == 0
-        st = []
-        try:
-            y = hipops.conv_igemm(srcs, w.to(dev()), b.to(dev()), stats_out=st, **kw)
-        finally:
-            for k in (5, 9, 10, 11, 12):
-                lib().anoddpm_internal_variant(k, 0)
-        return y, st[0]
-    want, st_want = run(1)                                             # channel-sliced, never persistent
-    got, st_got = run(2)                                               # persistent wherever the shape allows
-    assert torch.equal(got, want), float((got - want).abs().max())
-    assert torch.equal(st_got, st_want)
-    for delay, aux in ((20000, 0), (0, 2), (0, 16)):
-        y, st = run(2, delay, aux)
-        assert torch.equal(y, want) and torch.equal(st, st_want)
-    if Hout <= 64:
-        hh = x
-        if gn_act:
-            hh = F.silu(F.group_norm(hh, 32, gamma, beta, eps=1e-5))
-        if a_mode == 1:
-            hh = F.interpolate(hh, scale_factor=2, mode="nearest")
-        ref = F.conv2d(hh.double(), w.double(), b.double(), padding=1)
-        if temb is not None:
-            ref = ref + temb.cpu()[:, :, None, None].double()
-        if res is not None:
-            r = hipops.nchw(res).cpu().double()
-            ref = ref + (F.interpolate(r, scale_factor=2, mode="nearest") if res_kind == 2 else r)
-        assert relerr(hipops.nchw(got), ref.float()) < 1e-4
-
-
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_winograd_conv(case):
     """cfg = 2: Winograd F(2x2,3x3) on the matrix pipe must equal the direct 3x3 convolution (fp32; the
