@@ -41,6 +41,8 @@ constexpr int F4_MS = 52;                             // floats per (pos, tile) 
 constexpr int F4_LOOP_FLOATS = (2 * F4_DT + 2 * F4_V) * 4;
 constexpr int F4_EX_FLOATS = 36 * 16 * F4_MS;
 constexpr int F4_LDS_FLOATS = F4_EX_FLOATS > F4_LOOP_FLOATS ? F4_EX_FLOATS : F4_LOOP_FLOATS;
+constexpr int F4_KMAX = 1024;                         // input channels whose GroupNorm affine fits the LDS table
+constexpr int F4_AFF_FLOATS = 2 * F4_KMAX;            // [K] scales, then [K] shifts of this workgroup's image, behind both uses of `lds`
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc43(const float *base)
@@ -58,9 +60,10 @@ __device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned lane_by
 template <bool FAST, int DBG = 0, int NTL = 8>
 __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_args a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[F4_LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[F4_LDS_FLOATS + F4_AFF_FLOATS];
     f32x4 *ldsD = reinterpret_cast<f32x4 *>(lds);
     f32x4 *ldsV = ldsD + 2 * F4_DT;
+    f32x4 *ldsAff = reinterpret_cast<f32x4 *>(lds + F4_LDS_FLOATS);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,11 +113,13 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
     };
     auto store_patch = [&](int buf, int chunk) {                    // transform, zero padding AFTER it
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        // the GroupNorm affine of this chunk's channels is fetched here (L2-hot, 32 bytes per lane) instead of riding in eight
-        // registers from the patch request to its use: the register file belongs to the accumulators
+        // the GroupNorm affine of this chunk's channels comes from the LDS table filled in the prologue (round 5).  Until then it
+        // was fetched from L2 right here, to keep eight registers free -- but its use two instructions later is an
+        // `s_waitcnt vmcnt(0)`, and vmcnt retires in order: every wave drained its B-fragment ring and sat out an L2 round trip in
+        // the middle of each chunk's MFMAs
         if (FAST || affine) {
-            asc = bld4(rSc, (unsigned)(pq * 16), (unsigned)(chunk * F4_KC) * 4u);
-            ash = bld4(rSh, (unsigned)(pq * 16), (unsigned)(chunk * F4_KC) * 4u);
+            asc = ldsAff[chunk * 4 + pq];
+            ash = ldsAff[K4 + chunk * 4 + pq];
         }
 #pragma unroll
         for (int j = 0; j < F4_PJ; ++j) {
@@ -196,6 +201,13 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
     // prologue: patch(0) -> LDS -> V(0); patch(1) -> LDS; patch(2) requested
     const int last = nchunks - 1;
     const int c1 = last >= 1 ? 1 : 0, c2 = last >= 2 ? 2 : last;
+    // GroupNorm affine of the image -> LDS, requested first (threads 0 .. K/4-1: one float4 of scales and one of shifts each)
+    f32x4 aff_sc = {0.f, 0.f, 0.f, 0.f}, aff_sh = {0.f, 0.f, 0.f, 0.f};
+    const bool aff_slot = (FAST || affine) && tid < K4;
+    if (aff_slot) {
+        aff_sc = bld4(rSc, (unsigned)(tid * 16), 0u);
+        aff_sh = bld4(rSh, (unsigned)(tid * 16), 0u);
+    }
     load_patch(0);
     f32x4 praw0[F4_PJ];
 #pragma unroll
@@ -203,6 +215,13 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
     load_patch(c1);                                                 // both requests in flight: one HBM latency, not two
 #pragma unroll
     for (int g = 0; g < 4; ++g) load_group(0, g, g);
+    if (FAST || affine) {
+        if (aff_slot) {                                                // oldest requests: no wait for the patches behind them
+            ldsAff[tid] = aff_sc;
+            ldsAff[K4 + tid] = aff_sh;
+        }
+        __syncthreads();
+    }
     {
         f32x4 keep[F4_PJ];
 #pragma unroll
@@ -409,6 +428,7 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
     const int K = a->c0 + a->c1;
     ANODDPM_REQUIRE(K % F4_KC == 0 && (a->c1 == 0 || a->c0 % F4_KC == 0), "winograd43: channel counts must be multiples of 16");
     ANODDPM_REQUIRE((int64_t)36 * K * a->N * 4 < ((int64_t)1 << 31), "winograd43: transformed weights exceed 32-bit buffer offsets");
+    ANODDPM_REQUIRE(!a->gn_scale || K <= F4_KMAX, "winograd43: the GroupNorm affine table holds %d input channels", F4_KMAX);
     ANODDPM_REQUIRE((int64_t)a->H * a->W * (a->a0_ld > a->a1_ld ? a->a0_ld : a->a1_ld) * 4 < ((int64_t)1 << 31),
                     "winograd43: operand slice exceeds 32-bit buffer offsets");
     // 64-channel workgroups when 128-channel ones would leave CUs idle (or N is not a multiple of 128): rounds over the 256 CUs x

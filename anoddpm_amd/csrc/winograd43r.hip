@@ -35,7 +35,9 @@ constexpr int R4_PJ = 3;                   // staging slots per thread (3 * 512 
 constexpr int R4_SLOTPX = R4_PJ * R4_NT / 4;          // 384 pixel slots per buffer
 constexpr int R4_DT = R4_SLOTPX * R4_PITCH;           // float4 per patch buffer
 constexpr int R4_V = 36 * 16 * 4;                     // float4 per V buffer: [pos][tile][quad]
-constexpr int R4_LDS_FLOATS = (2 * R4_DT + 2 * R4_V) * 4;
+constexpr int R4_KMAX = 1024;                         // input channels whose GroupNorm affine fits the LDS table (launcher: larger K is refused)
+constexpr int R4_AFF = 2 * R4_KMAX / 4;               // float4: [K/4] scales, then [K/4] shifts of this workgroup's image (K / 4 <= 256 <= threads)
+constexpr int R4_LDS_FLOATS = (2 * R4_DT + 2 * R4_V + R4_AFF) * 4;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const float *base)
 {
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     __shared__ __attribute__((aligned(16))) float lds[R4_LDS_FLOATS];
     f32x4 *ldsD = reinterpret_cast<f32x4 *>(lds);
     f32x4 *ldsV = ldsD + 2 * R4_DT;
+    f32x4 *ldsAff = ldsV + 2 * R4_V;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,8 +124,10 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     auto store_patch = [&](int buf, int chunk) {                    // GroupNorm-apply + SiLU, zero padding AFTER it
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if (FAST || affine) {
-            asc = bld4(rSc, (unsigned)(pq * 16), (unsigned)((cb + chunk) * R4_KC) * 4u);
-            ash = bld4(rSh, (unsigned)(pq * 16), (unsigned)((cb + chunk) * R4_KC) * 4u);
+            // from the LDS table filled in the prologue: a global load here was followed by `s_waitcnt vmcnt(0)` -- vmcnt retires
+            // in order, so every wave drained its B-fragment ring and sat out an L2 round trip in the middle of each chunk's MFMAs
+            asc = ldsAff[(cb + chunk) * 4 + pq];
+            ash = ldsAff[K4 + (cb + chunk) * 4 + pq];
         }
 #pragma unroll
         for (int j = 0; j < R4_PJ; ++j) {
@@ -200,6 +205,13 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     // prologue: patch(0) -> LDS -> V(0); patch(1) -> LDS; patch(2) requested
     const int last = nchunks - 1;
     const int c1 = last >= 1 ? 1 : 0, c2 = last >= 2 ? 2 : last;
+    // GroupNorm affine of the image -> LDS, requested first (one float4 per thread: K / 4 scales, K / 4 shifts, K <= 1024)
+    f32x4 aff_sc = {0.f, 0.f, 0.f, 0.f}, aff_sh = {0.f, 0.f, 0.f, 0.f};
+    const bool aff_slot = (FAST || affine) && tid < K4;
+    if (aff_slot) {
+        aff_sc = bld4(rSc, (unsigned)(tid * 16), 0u);
+        aff_sh = bld4(rSh, (unsigned)(tid * 16), 0u);
+    }
     load_patch(0);
     f32x4 praw0[R4_PJ];
 #pragma unroll
@@ -207,6 +219,13 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     load_patch(c1);
 #pragma unroll
     for (int g = 0; g < R4_RING; ++g) load_b(0, g, g);
+    if (FAST || affine) {
+        if (aff_slot) {                                                // oldest requests: no wait for the patches behind them
+            ldsAff[tid] = aff_sc;
+            ldsAff[K4 + tid] = aff_sh;
+        }
+        __syncthreads();
+    }
     {
         f32x4 keep[R4_PJ];
 #pragma unroll
@@ -355,6 +374,7 @@ int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
 {
     dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / 128), (unsigned)(a->B * a->ksplit));
     const bool fast = a->gn_scale && a->act;
+    ANODDPM_REQUIRE(!a->gn_scale || a->c0 + a->c1 <= R4_KMAX, "winograd43r: GroupNorm affine table holds %d input channels", R4_KMAX);
 #ifdef ANODDPM_ABLATE           // timing ablations (wrong results) and ring-depth variants: measurement builds only
     const int dbg = g_debug[6];
     if (fast && dbg == 1) hipLaunchKernelGGL((wino43r_kernel<true, 1>), grid, dim3(R4_NT), 0, s, *a);
