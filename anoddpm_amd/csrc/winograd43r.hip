@@ -16,6 +16,8 @@
 //
 // K advances 16 channels per iteration; per iteration a wave issues 144 v_mfma_f32_16x16x4_f32 (16 tiles x 16 channels x 4 k),
 // 36 A-fragment reads (LDS) and 36 B-fragment loads (U[pos][k/4][n][4] from L2, six-deep register ring).
+#include <type_traits>
+
 #include "common.h"
 
 using anoddpm::silu_f;
@@ -59,10 +61,14 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4])
 }
 
 // DBG (timing ablations only, wrong results; ANODDPM_DEBUG6): 1 no epilogue, 2 no input transform, 3 no patch staging, 4 no B requests
+// DBG 5 / 6 (tools/f43_phases.py; results stay correct): wave 0 records s_memtime at the phase boundaries + its CU into
+// a.ws[block][8] (int64): entry, prologue done, K loop done, epilogue issued, stores acknowledged (5: waited for; 6: not waited for)
 // R4_RING = B-fragment requests in flight per wave
 template <bool FAST, int DBG = 0, int R4_RING = 6>
 __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_args a)
 {
+    unsigned long long tstamp[5];
+    if (DBG == 5 || DBG == 6) tstamp[0] = __builtin_amdgcn_s_memtime();
     __shared__ __attribute__((aligned(16))) float lds[R4_LDS_FLOATS];
     f32x4 *ldsD = reinterpret_cast<f32x4 *>(lds);
     f32x4 *ldsV = ldsD + 2 * R4_DT;
@@ -239,22 +245,26 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     store_patch(1, c1);
     load_patch(c2);
     __syncthreads();
+    if (DBG == 5 || DBG == 6) tstamp[1] = __builtin_amdgcn_s_memtime();
 
-    // One iteration per 16-channel chunk (clamped tail indices instead of `if (more)`, as wino43_kernel):
+    // One step per 16-channel chunk c; what a step does besides its 144 MFMAs is fixed at compile time, so that the last three
+    // chunks of the tile run without the work nobody would consume (round 5: the clamped-index form re-staged and re-transformed
+    // already consumed patches there -- two SiLU passes and one transform per tile, ~2 us of issue time -- to keep ONE loop body):
     //   T  V(c+1) <- patch(c+1)    positions 0..8    S  patch(c+2) -> LDS    positions 9..26    L  request patch(c+3)
-    //   positions 27..35           barrier
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        if (DBG != 2) transform_all((chunk + 1) & 1, (chunk + 1) & 1);
+    //   positions 27..35           barrier (not after the last chunk)
+    //   R  (last chunk only) from position 30 on no B fragment is requested any more: the first tile's 16 residual pixels are,
+    //      so that the epilogue starts with them in flight instead of waiting out an HBM round trip first
+    auto step = [&](const int chunk, auto doT, auto doS, auto doL, auto doR, auto &&res_prefetch) {
+        if (decltype(doT)::value && DBG != 2) transform_all((chunk + 1) & 1, (chunk + 1) & 1);
         const f32x4 *V = ldsV + (chunk & 1) * R4_V + vread;
-        const int nxt = chunk < last ? chunk + 1 : last;
-        const int s2 = chunk + 2 <= last ? chunk + 2 : last, l3 = chunk + 3 <= last ? chunk + 3 : last;
         f32x4 av[3];                                                // A fragments: two positions ahead of the MFMAs
         av[0] = V[0];
         av[1] = V[64];
 #pragma unroll
         for (int p = 0; p < 36; ++p) {
-            if (p == 9 && DBG != 3) store_patch(chunk & 1, s2);     // patch(chunk+2) replaces patch(chunk): its readers passed the last barrier
-            if (p == 27 && DBG != 3) load_patch(l3);
+            if (p == 9 && decltype(doS)::value && DBG != 3) store_patch(chunk & 1, chunk + 2);   // patch(c+2) replaces patch(c): its readers passed the last barrier
+            if (p == 27 && decltype(doL)::value && DBG != 3) load_patch(chunk + 3);
+            if (p == 30 && decltype(doR)::value) res_prefetch();
             const f32x4 a_cur = av[p % 3];
             if (p + 2 < 36) av[(p + 2) % 3] = V[(p + 2) * 64];
             const f32x4 bv = ring[p % R4_RING];
@@ -262,21 +272,19 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
             for (int kk = 0; kk < 4; ++kk)
                 acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[kk], bv[kk], acc[p], 0, 0, 0);
             if (DBG != 4) {
-                if (p + R4_RING < 36) load_b(chunk, p + R4_RING, p % R4_RING);
-                else                  load_b(nxt, p + R4_RING - 36, p % R4_RING);
+                if (p + R4_RING < 36)             load_b(chunk, p + R4_RING, p % R4_RING);
+                else if (!decltype(doR)::value)   load_b(chunk + 1, p + R4_RING - 36, p % R4_RING);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                                            // publishes V(chunk+1) and patch(chunk+2); retires V(chunk)
-    }
+        if (!decltype(doR)::value) __syncthreads();                 // publishes V(c+1) and patch(c+2); retires V(c)
+    };
+    constexpr std::true_type YES{};
+    constexpr std::false_type NO{};
+    auto nothing = []() {};
+    int chunk = 0;
+    for (; chunk + 3 <= last; ++chunk) step(chunk, YES, YES, YES, NO, nothing);
 
-    if (DBG == 1) {
-        float sum = 0.f;
-#pragma unroll
-        for (int p = 0; p < 36; ++p) sum += (acc[p][0] + acc[p][1]) + (acc[p][2] + acc[p][3]);
-        if (sum == 12345.678f) a.out[0] = sum;
-        return;
-    }
     // ---- epilogue, in registers: lane = (channel nw, tiles kq*4 .. kq*4+3); tile r of the lane sits in component r of every acc.
     // (The transposed form -- D = channels x tiles, one 16-byte store per pixel and lane -- measured slower: 292 vs 282 us on the
     // 256x256 128->128 layer; the stores of a round are HBM-burst-bound, not issue-bound.)
@@ -320,9 +328,21 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
                         rR, (int)vr, (int)((((unsigned)(r * 4) + (unsigned)i * uW + (unsigned)j) * 4u) * r_ld), 0));
         }
     };
-    float cs = 0.f, cq = 0.f;
     float rv[2][16];
-    load_res(0, rv[0]);
+    // the tile's last three chunks (fewer when the slice has fewer)
+    if (last >= 2) step(last - 2, YES, YES, NO, NO, nothing);
+    if (last >= 1) step(last - 1, YES, NO, NO, NO, nothing);
+    step(last, NO, NO, NO, YES, [&]() { load_res(0, rv[0]); });
+
+    if (DBG == 5 || DBG == 6) tstamp[2] = __builtin_amdgcn_s_memtime();
+    if (DBG == 1) {
+        float sum = 0.f;
+#pragma unroll
+        for (int p = 0; p < 36; ++p) sum += (acc[p][0] + acc[p][1]) + (acc[p][2] + acc[p][3]);
+        if (sum == 12345.678f) a.out[0] = sum;
+        return;
+    }
+    float cs = 0.f, cq = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         if (r + 1 < 4) load_res(r + 1, rv[(r + 1) & 1]);           // the next tile's residual pixels ride behind this tile's arithmetic
@@ -363,6 +383,20 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
             st[1] = cq;
         }
     }
+    if (DBG == 5 || DBG == 6) {
+        tstamp[3] = __builtin_amdgcn_s_memtime();
+        if (DBG == 5) __builtin_amdgcn_s_waitcnt(0);                  // vmcnt(0) (and the other counters): the stores are acknowledged
+        tstamp[4] = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            unsigned long long *d = reinterpret_cast<unsigned long long *>(a.ws) +
+                                    (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) d[i] = tstamp[i];
+            d[5] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);            // HW_REG_HW_ID (wave, SIMD, CU, SH, SE)
+            d[6] = (unsigned long long)__builtin_amdgcn_s_getreg(63508);            // HW_REG_XCC_ID
+            d[7] = 0;
+        }
+    }
 }
 
 }  // namespace
@@ -381,11 +415,16 @@ int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
     else if (fast && dbg == 2) hipLaunchKernelGGL((wino43r_kernel<true, 2>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 3) hipLaunchKernelGGL((wino43r_kernel<true, 3>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 4) hipLaunchKernelGGL((wino43r_kernel<true, 4>), grid, dim3(R4_NT), 0, s, *a);
-    else if (fast && dbg == 8) hipLaunchKernelGGL((wino43r_kernel<true, 0, 8>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 5) hipLaunchKernelGGL((wino43r_kernel<true, 5>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 6) hipLaunchKernelGGL((wino43r_kernel<true, 6>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 8) hipLaunchKernelGGL((wino43r_kernel<true, 0, 8>), grid, dim3(R4_NT), 0, s, *a);   // (8 does not divide 36: timing only)
+    else if (fast && dbg == 10) hipLaunchKernelGGL((wino43r_kernel<true, 0, 6>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 9) hipLaunchKernelGGL((wino43r_kernel<true, 0, 4>), grid, dim3(R4_NT), 0, s, *a);
     else
 #endif
-    if (fast) hipLaunchKernelGGL((wino43r_kernel<true>), grid, dim3(R4_NT), 0, s, *a);
+    // nine B fragments in flight (250 VGPRs) for the GroupNorm + SiLU form: 9.05 -> 9.01 ms per config-2 step over six (round 5,
+    // once the per-chunk vmcnt(0) drain was gone; the depth must divide 36); the plain form sits at 247 VGPRs with six
+    if (fast) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9>), grid, dim3(R4_NT), 0, s, *a);
     else      hipLaunchKernelGGL((wino43r_kernel<false>), grid, dim3(R4_NT), 0, s, *a);
     return check_launch("winograd43r");
 }
