@@ -233,9 +233,9 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
     load_dy(cur, 0);
     __syncthreads();                                                // affine table
     for (int it = 0; it < iters; ++it) {
-        store_in(cur);
         store_dy();
-        load_dy(cur, 1);
+        load_dy(cur, 1);                                            // requested BEFORE the input staging: its GroupNorm + SiLU pass covers the latency
+        store_in(cur);
         __syncthreads();
         transform_v();
         transform_z(0, cur);

@@ -49,6 +49,11 @@ __device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned lane_by
 {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)wave_bytes, 0));
 }
+template <int AUX>
+__device__ __forceinline__ f32x4 bld4x(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned wave_bytes)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)wave_bytes, AUX));
+}
 
 // A^T of F(4x4,3x3) applied to six values: rows (1 1 1 1 1 0), (0 1 -1 2 -2 0), (0 1 1 4 4 0), (0 1 -1 8 -8 1)
 __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4])
@@ -61,12 +66,21 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4])
 }
 
 // DBG (timing ablations only, wrong results; ANODDPM_DEBUG6): 1 no epilogue, 2 no input transform, 3 no patch staging, 4 no B requests
+// DBG 7: every patch request reads the tile's first pixel (same instruction stream, no HBM latency in the in-order vmcnt queue)
+// DBG 11: patches requested but not activated / staged (the VALU + LDS half of DBG 3)
 // DBG 5 / 6 (tools/f43_phases.py; results stay correct): wave 0 records s_memtime at the phase boundaries + its CU into
 // a.ws[block][8] (int64): entry, prologue done, K loop done, epilogue issued, stores acknowledged (5: waited for; 6: not waited for)
 // R4_RING = B-fragment requests in flight per wave
-template <bool FAST, int DBG = 0, int R4_RING = 6>
+// NPOS < 36 (timing only, wrong results): only the first NPOS transform positions are multiplied -- frees accumulator registers for
+// ring-depth experiments (the epilogue is skipped)
+template <bool FAST, int DBG = 0, int R4_RING = 6, int NPOS = 36>
 __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_args a)
 {
+    // cache policy experiments (results unchanged): DBG 18 patch requests nt; 19 patch + residual requests and stores nt;
+    // 20 stores sc1 (written through, not kept in L2); 21 patch + residual nt, stores sc1
+    constexpr int PATCH_AUX = (DBG == 18 || DBG == 19 || DBG == 21) ? 2 : 0;
+    constexpr int RES_AUX = (DBG == 19 || DBG == 21) ? 2 : 0;
+    constexpr int STORE_AUX = DBG == 19 ? 2 : ((DBG == 20 || DBG == 21) ? 16 : 0);
     unsigned long long tstamp[5];
     if (DBG == 5 || DBG == 6) tstamp[0] = __builtin_amdgcn_s_memtime();
     __shared__ __attribute__((aligned(16))) float lds[R4_LDS_FLOATS];
@@ -123,8 +137,8 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
         const unsigned koff = (unsigned)(first ? kbase : kbase - a.c0) * 4u;
 #pragma unroll
         for (int j = 0; j < R4_PJ; ++j) {
-            const unsigned sp = spix[j] >= 0 ? (unsigned)spix[j] : 0u;
-            praw[j] = bld4(r, (sp * ld + (unsigned)(pq * 4)) * 4u, koff);
+            const unsigned sp = (DBG == 7) ? (unsigned)(y0 * W + x0) : (spix[j] >= 0 ? (unsigned)spix[j] : 0u);
+            praw[j] = bld4x<PATCH_AUX>(r, (sp * ld + (unsigned)(pq * 4)) * 4u, koff);
         }
     };
     auto store_patch = [&](int buf, int chunk) {                    // GroupNorm-apply + SiLU, zero padding AFTER it
@@ -192,9 +206,9 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     };
 
     // ---- accumulators: all 36 positions x this wave's 16 channels x 16 tiles
-    f32x4 acc[36];
+    f32x4 acc[NPOS];
 #pragma unroll
-    for (int p = 0; p < 36; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < NPOS; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int l15 = lane & 15, kq = lane >> 4;
     const int nw = n0 + wave * 16 + l15;                            // this lane's output channel
@@ -260,20 +274,24 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
         f32x4 av[3];                                                // A fragments: two positions ahead of the MFMAs
         av[0] = V[0];
         av[1] = V[64];
+        constexpr int PS = NPOS / 4, PL = 3 * NPOS / 4, PR = NPOS - 6;
 #pragma unroll
-        for (int p = 0; p < 36; ++p) {
-            if (p == 9 && decltype(doS)::value && DBG != 3) store_patch(chunk & 1, chunk + 2);   // patch(c+2) replaces patch(c): its readers passed the last barrier
-            if (p == 27 && decltype(doL)::value && DBG != 3) load_patch(chunk + 3);
-            if (p == 30 && decltype(doR)::value) res_prefetch();
+        for (int p = 0; p < NPOS; ++p) {
+            // (round 5, measured and dropped: the two waves of a SIMD staging half a chunk apart -- S / L at positions 0 / 9 for waves
+            // 4..7 -- so that they would not wait for their patch requests together: 8.99 vs 9.01 ms per step, no difference;
+            // nor does a deeper B ring or a non-temporal policy on the streamed tensors help: profiles/r5_f43_phases_ablations.txt)
+            if (p == PS && decltype(doS)::value && DBG != 3 && DBG != 11) store_patch(chunk & 1, chunk + 2);   // patch(c+2) replaces patch(c): its readers passed the last barrier
+            if (p == PL && decltype(doL)::value && DBG != 3) load_patch(chunk + 3);
+            if (p == PR && decltype(doR)::value) res_prefetch();
             const f32x4 a_cur = av[p % 3];
-            if (p + 2 < 36) av[(p + 2) % 3] = V[(p + 2) * 64];
+            if (p + 2 < NPOS) av[(p + 2) % 3] = V[(p + 2) * 64];
             const f32x4 bv = ring[p % R4_RING];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
                 acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[kk], bv[kk], acc[p], 0, 0, 0);
             if (DBG != 4) {
-                if (p + R4_RING < 36)             load_b(chunk, p + R4_RING, p % R4_RING);
-                else if (!decltype(doR)::value)   load_b(chunk + 1, p + R4_RING - 36, p % R4_RING);
+                if (p + R4_RING < NPOS)           load_b(chunk, p + R4_RING, p % R4_RING);
+                else if (!decltype(doR)::value)   load_b(chunk + 1, p + R4_RING - NPOS, p % R4_RING);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
 #pragma unroll
                 for (int j2 = 0; j2 < 2; ++j2) {
                     const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rR, (int)vrh, (int)((((unsigned)(r * 2) + (unsigned)i2 * hW + (unsigned)j2) * 4u) * r_ld), 0));
+                        rR, (int)vrh, (int)((((unsigned)(r * 2) + (unsigned)i2 * hW + (unsigned)j2) * 4u) * r_ld), RES_AUX));
                     rv[(2 * i2) * 4 + 2 * j2] = v; rv[(2 * i2) * 4 + 2 * j2 + 1] = v;
                     rv[(2 * i2 + 1) * 4 + 2 * j2] = v; rv[(2 * i2 + 1) * 4 + 2 * j2 + 1] = v;
                 }
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     rv[i * 4 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rR, (int)vr, (int)((((unsigned)(r * 4) + (unsigned)i * uW + (unsigned)j) * 4u) * r_ld), 0));
+                        rR, (int)vr, (int)((((unsigned)(r * 4) + (unsigned)i * uW + (unsigned)j) * 4u) * r_ld), RES_AUX));
         }
     };
     float rv[2][16];
@@ -335,10 +353,10 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     step(last, NO, NO, NO, YES, [&]() { load_res(0, rv[0]); });
 
     if (DBG == 5 || DBG == 6) tstamp[2] = __builtin_amdgcn_s_memtime();
-    if (DBG == 1) {
+    if (DBG == 1 || NPOS < 36) {
         float sum = 0.f;
 #pragma unroll
-        for (int p = 0; p < 36; ++p) sum += (acc[p][0] + acc[p][1]) + (acc[p][2] + acc[p][3]);
+        for (int p = 0; p < NPOS; ++p) sum += (acc[p][0] + acc[p][1]) + (acc[p][2] + acc[p][3]);
         if (sum == 12345.678f) a.out[0] = sum;
         return;
     }
@@ -365,7 +383,7 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
             for (int j = 0; j < 4; ++j) {
                 const unsigned so = ((unsigned)(r * 4) + (unsigned)i * uW + (unsigned)j) * 4u;      // wave-uniform pixel offset (x ld below)
                 const float v = alpha * o4[j] + add + rv[r & 1][i * 4 + j];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, (int)vo, (int)(so * o_ld), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, (int)vo, (int)(so * o_ld), STORE_AUX);
                 cs += v;
                 cq += v * v;
             }
@@ -417,6 +435,18 @@ int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
     else if (fast && dbg == 4) hipLaunchKernelGGL((wino43r_kernel<true, 4>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 5) hipLaunchKernelGGL((wino43r_kernel<true, 5>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 6) hipLaunchKernelGGL((wino43r_kernel<true, 6>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 7) hipLaunchKernelGGL((wino43r_kernel<true, 7, 9>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 11) hipLaunchKernelGGL((wino43r_kernel<true, 11, 9>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 12) hipLaunchKernelGGL((wino43r_kernel<true, 3, 9>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 13) hipLaunchKernelGGL((wino43r_kernel<true, 4, 9>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 18) hipLaunchKernelGGL((wino43r_kernel<true, 18, 9>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 19) hipLaunchKernelGGL((wino43r_kernel<true, 19, 9>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 20) hipLaunchKernelGGL((wino43r_kernel<true, 20, 9>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 21) hipLaunchKernelGGL((wino43r_kernel<true, 21, 9>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 14) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9, 18>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 15) hipLaunchKernelGGL((wino43r_kernel<true, 0, 18, 18>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 16) hipLaunchKernelGGL((wino43r_kernel<true, 7, 9, 18>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 17) hipLaunchKernelGGL((wino43r_kernel<true, 0, 6, 18>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 8) hipLaunchKernelGGL((wino43r_kernel<true, 0, 8>), grid, dim3(R4_NT), 0, s, *a);   // (8 does not divide 36: timing only)
     else if (fast && dbg == 10) hipLaunchKernelGGL((wino43r_kernel<true, 0, 6>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 9) hipLaunchKernelGGL((wino43r_kernel<true, 0, 4>), grid, dim3(R4_NT), 0, s, *a);
