@@ -68,6 +68,7 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4])
 // DBG (timing ablations only, wrong results; ANODDPM_DEBUG6): 1 no epilogue, 2 no input transform, 3 no patch staging, 4 no B requests
 // DBG 7: every patch request reads the tile's first pixel (same instruction stream, no HBM latency in the in-order vmcnt queue)
 // DBG 11: patches requested but not activated / staged (the VALU + LDS half of DBG 3)
+// DBG 22: real patch requests, but every staged pixel gets the same values (separates the memory effect of DBG 7 from its data effect)
 // DBG 5 / 6 (tools/f43_phases.py; results stay correct): wave 0 records s_memtime at the phase boundaries + its CU into
 // a.ws[block][8] (int64): entry, prologue done, K loop done, epilogue issued, stores acknowledged (5: waited for; 6: not waited for)
 // R4_RING = B-fragment requests in flight per wave
@@ -153,6 +154,10 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
         for (int j = 0; j < R4_PJ; ++j) {
             const int idx = tid + j * R4_NT;
             f32x4 v = praw[j];
+            if (DBG == 22) {                                        // real requests, regular DATA: every pixel of the patch gets the same values
+                const f32x4 same = {0.25f, -0.5f, 0.75f, 1.0f};
+                v = (praw[j][0] == 12345.678f) ? praw[j] : same;
+            }
             if (FAST) {
                 v = v * asc + ash;
                 v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
@@ -439,6 +444,7 @@ int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
     else if (fast && dbg == 11) hipLaunchKernelGGL((wino43r_kernel<true, 11, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 12) hipLaunchKernelGGL((wino43r_kernel<true, 3, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 13) hipLaunchKernelGGL((wino43r_kernel<true, 4, 9>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 22) hipLaunchKernelGGL((wino43r_kernel<true, 22, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 18) hipLaunchKernelGGL((wino43r_kernel<true, 18, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 19) hipLaunchKernelGGL((wino43r_kernel<true, 19, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 20) hipLaunchKernelGGL((wino43r_kernel<true, 20, 9>), grid, dim3(R4_NT), 0, s, *a);

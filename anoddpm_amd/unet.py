@@ -454,6 +454,13 @@ def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None
         else:
             cps = -(-wch // wino_ksplit)
             wino_ksplit = -(-wch // cps)                   # no empty trailing block
+    if (wino_ok and f43 and N % 128 == 0 and H * W == 32 * 32 and K >= 512 and os.environ.get("ANODDPM_F43_32", "0") == "1"):
+        # (round 5 experiment, off: the deep 32x32 layers on the channel-sliced F(4x4) kernel with split-K -- 16 x 16-pixel tiles x
+        # 128 channels x K slices of >= 4 chunks -- instead of F(2x2) + split-K)
+        wg = (H // 16) * (W // 16) * (N // 128) * Z
+        ks43 = int(min(max(1, (K // 16) // 4), -(-256 // wg)))
+        cps = -(-(K // 16) // ks43)
+        return 3, -(-(K // 16) // cps)
     if wino_ok and f43 and N % 64 == 0 and H * W >= int(os.environ.get("ANODDPM_F43_MIN_PIXELS", 64 * 64)) \
             and (H // 16) * (W // 16) * (N // 64) * Z >= 128 and os.environ.get("ANODDPM_NO_F43", "0") != "1":
         # the kernel picks 64- or 128-channel workgroups itself.  ANODDPM_F43_SPLITK=1 (measured slower, off): a 128-channel grid

@@ -10,7 +10,7 @@ export ANODDPM_NO_GRAPH=1            # eager launches so that every kernel is at
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2_stats -o c2 -- $B > $OUT/c2_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/c2_fetch -o c2 -- $B > $OUT/c2_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/c2_write -o c2 -- $B > $OUT/c2_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/c2_sq -o c2 -- $B > $OUT/c2_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/c2_sq -o c2 -- $B > $OUT/c2_sq.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_stats -o c3 -- $B --config c3 --steps 3 --warmup 1 > $OUT/c3_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stats -o c4 -- $B --config c4 > $OUT/c4_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY --output-format csv -d $OUT/c4_sq -o c4 -- $B --config c4 > $OUT/c4_sq.log 2>&1
@@ -39,5 +39,5 @@ python bench.py > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 python bench.py --config c3 --steps 5 --warmup 2 > $OUT/bench_c3.json 2> $OUT/bench_c3.err
 python bench.py --config c4 --steps 10 > $OUT/bench_c4.json 2> $OUT/bench_c4.err
 python bench.py --config c5 --steps 10 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
-python bench.py --config det --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_det.json 2> $OUT/bench_det.err
+python bench.py --config det --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_det.json 2> $OUT/bench_det.err   # a step = one image's whole sweep (~35 s)
 ls -la $OUT
