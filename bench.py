@@ -14,8 +14,9 @@ Other BASELINE configurations, same JSON contract (`--config`):
       -> backward -> [RCCL bucketed all-reduce when N > 1] -> clip + AdamW + EMA; value = trained images/s
   c4  simplex microbench: rand_3d_octaves((1000,256,256), 8 octaves) volumes on the device; value = noise voxels/s
   c1  config 1's 64x64 model on the GPU (used by the contract test; runs in seconds)
-  det one detection_B setting end to end (5 averaged chains x 50 reverse steps, batched, + on-device anomaly maps): the loop the
-      reference runs around the hot path; value = reverse chain-steps/s; a side line, no roofline object
+  det one image's whole detection_B sweep end to end (every (t_distance, avg) chain of range(50, 600, 50) x 5 in one slot-batched
+      reverse loop + on-device anomaly maps per setting): the loop the reference runs around the hot path; a step
+      is one image (~32 s; default --steps 2 --warmup 1); value = reverse chain-steps/s; a side line, no roofline object
 
 Multi-GPU: one process per GPU (torchrun), each rank works on its own shard; inference and the simplex microbench
 have no data-path collective -- RCCL is used only for the timing barrier and the max-over-ranks

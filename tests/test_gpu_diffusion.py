@@ -150,3 +150,34 @@ def test_graph_replay_equals_eager_chain():
     np.random.seed(11)
     full = d.forward_backward(m, x, None, 9, denoise_fn=GD.SimplexNoiseFn(d.simplex, octave=4))
     assert full.shape == x.shape and torch.isfinite(full).all()
+
+
+def test_kept_chain_is_not_replayed_for_a_train_mode_dropout_model():
+    """a chain captured under model.eval() replays the dropout-free inference graph; once the SAME model is in
+    train() mode with dropout > 0 (UNet.py:192 draws a fresh mask per forward) forward_backward must not reuse it, and an explicit
+    use_graph=True is refused instead of replaying one baked-in mask."""
+    import GaussianDiffusion as GD
+    from UNet import UNetModel
+    from oracle import unet_oracle as uo
+    m = UNetModel(img_size=32, base_channels=32, n_heads=2, attention_resolutions="16,8", dropout=0.5)
+    m.load_state_dict(uo.fill_deterministic({k: tuple(v.shape) for k, v in m.state_dict().items()}))
+    m.to(DEV).eval()
+    d = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(100, "linear"), noise="gauss")
+    x = torch.rand(2, 1, 32, 32, device=DEV) * 2 - 1
+    torch.manual_seed(1)
+    a = d.forward_backward(m, x, None, 4)
+    assert len(d._chains) == 1
+    kept = next(iter(d._chains.values()))
+    assert kept.use_graph and kept.hip_model
+    torch.manual_seed(1)
+    assert torch.equal(d.forward_backward(m, x, None, 4), a)          # eval: the kept chain is restarted, same draws -> same result
+    m.train()
+    torch.manual_seed(1)
+    b = d.forward_backward(m, x, None, 4)                             # train + dropout: a fresh eager chain through model.forward
+    assert torch.isfinite(b).all() and not torch.equal(a, b)          # masks were drawn
+    assert len(d._chains) == 1 and next(iter(d._chains.values())) is kept      # the eager chain is not kept
+    with pytest.raises(ValueError, match="dropout-free"):
+        GD.ReverseChain(d, m, x, 4, "gauss", use_graph=True)
+    m.eval()
+    torch.manual_seed(1)
+    assert torch.equal(d.forward_backward(m, x, None, 4), a)          # back in eval: the kept chain again
