@@ -68,6 +68,7 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4])
 // DBG (timing ablations only, wrong results; ANODDPM_DEBUG6): 1 no epilogue, 2 no input transform, 3 no patch staging, 4 no B requests
 // DBG 7: every patch request reads the tile's first pixel (same instruction stream, no HBM latency in the in-order vmcnt queue)
 // DBG 11: patches requested but not activated / staged (the VALU + LDS half of DBG 3)
+// DBG 23: A fragments of positions >= 2 not read from LDS (34 of 36 ds_read_b128 per chunk and wave gone)
 // DBG 22: real patch requests, but every staged pixel gets the same values (separates the memory effect of DBG 7 from its data effect)
 // DBG 5 / 6 (tools/f43_phases.py; results stay correct): wave 0 records s_memtime at the phase boundaries + its CU into
 // a.ws[block][8] (int64): entry, prologue done, K loop done, epilogue issued, stores acknowledged (5: waited for; 6: not waited for)
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
             if (p == PL && decltype(doL)::value && DBG != 3) load_patch(chunk + 3);
             if (p == PR && decltype(doR)::value) res_prefetch();
             const f32x4 a_cur = av[p % 3];
-            if (p + 2 < NPOS) av[(p + 2) % 3] = V[(p + 2) * 64];
+            if (p + 2 < NPOS && DBG != 23) av[(p + 2) % 3] = V[(p + 2) * 64];   // DBG 23: only the first two A fragments of a chunk are read
             const f32x4 bv = ring[p % R4_RING];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -444,6 +445,7 @@ int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
     else if (fast && dbg == 11) hipLaunchKernelGGL((wino43r_kernel<true, 11, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 12) hipLaunchKernelGGL((wino43r_kernel<true, 3, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 13) hipLaunchKernelGGL((wino43r_kernel<true, 4, 9>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 23) hipLaunchKernelGGL((wino43r_kernel<true, 23, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 22) hipLaunchKernelGGL((wino43r_kernel<true, 22, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 18) hipLaunchKernelGGL((wino43r_kernel<true, 18, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 19) hipLaunchKernelGGL((wino43r_kernel<true, 19, 9>), grid, dim3(R4_NT), 0, s, *a);

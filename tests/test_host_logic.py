@@ -191,6 +191,15 @@ def test_conv_launch_policy_on_config2_shapes():
     assert pick(8, 8, 512, 512, Z) == (1, 16)                       # H % 16 != 0: direct kernel, split-K
     assert pick(128, 128, 128, 128, Z, a_mode=2) == (0, 1)          # pool-fused operand: direct 128x128 tiles
     assert pick(256, 256, 256, 128, Z, ks=1) == (0, 1)              # 1x1 skip convolution
+    # round 5, opt-in (ANODDPM_F43_32=1, measured +-0 in the step): the deep 32x32 layers on F(4x4) + split-K; default policy unchanged
+    assert pick(32, 32, 512, 512, Z, f43=True) == (2, 2) and pick(32, 32, 768, 256, Z, f43=True) == (2, 4)
+    os.environ["ANODDPM_F43_32"] = "1"
+    try:
+        assert pick(32, 32, 512, 512, Z, f43=True) == (3, 4) and pick(32, 32, 512, 256, Z, f43=True) == (3, 8)
+        assert pick(32, 32, 768, 256, Z, f43=True) == (3, 8) and pick(32, 32, 256, 256, Z, f43=True) == (2, 4)
+        assert pick(16, 16, 512, 512, Z, f43=True) == (2, 8)
+    finally:
+        del os.environ["ANODDPM_F43_32"]
     assert pick(16, 16, 512, 1536, Z, ks=1) == (1, 2)               # qkv projection
     assert pick(256, 256, 128, 128, Z, wino=False)[0] in (0, 1)
     # Winograd F(4x4,3x3): only when the caller can supply its weights, on maps >= 128^2 with Cout % 128 == 0
