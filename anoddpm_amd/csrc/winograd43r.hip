@@ -68,6 +68,7 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4])
 // DBG (timing ablations only, wrong results; ANODDPM_DEBUG6): 1 no epilogue, 2 no input transform, 3 no patch staging, 4 no B requests
 // DBG 7: every patch request reads the tile's first pixel (same instruction stream, no HBM latency in the in-order vmcnt queue)
 // DBG 11: patches requested but not activated / staged (the VALU + LDS half of DBG 3)
+// DBG 24 / 25: epilogue without its residual requests / with one store per lane instead of 64
 // DBG 23: A fragments of positions >= 2 not read from LDS (34 of 36 ds_read_b128 per chunk and wave gone)
 // DBG 22: real patch requests, but every staged pixel gets the same values (separates the memory effect of DBG 7 from its data effect)
 // DBG 5 / 6 (tools/f43_phases.py; results stay correct): wave 0 records s_memtime at the phase boundaries + its CU into
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     auto load_res = [&](int r, float (&rv)[16]) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) rv[i] = 0.f;
+        if (DBG == 24) return;                                      // epilogue ablation: no residual requests
         if (has_res && res_up) {
 #pragma unroll
             for (int i2 = 0; i2 < 2; ++i2)
@@ -389,7 +391,8 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
             for (int j = 0; j < 4; ++j) {
                 const unsigned so = ((unsigned)(r * 4) + (unsigned)i * uW + (unsigned)j) * 4u;      // wave-uniform pixel offset (x ld below)
                 const float v = alpha * o4[j] + add + rv[r & 1][i * 4 + j];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, (int)vo, (int)(so * o_ld), STORE_AUX);
+                if (DBG != 25 || (r == 0 && i == 0 && j == 0))      // DBG 25: one store per lane instead of 64
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, (int)vo, (int)(so * o_ld), STORE_AUX);
                 cs += v;
                 cq += v * v;
             }
@@ -445,6 +448,8 @@ int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
     else if (fast && dbg == 11) hipLaunchKernelGGL((wino43r_kernel<true, 11, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 12) hipLaunchKernelGGL((wino43r_kernel<true, 3, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 13) hipLaunchKernelGGL((wino43r_kernel<true, 4, 9>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 24) hipLaunchKernelGGL((wino43r_kernel<true, 24, 9>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 25) hipLaunchKernelGGL((wino43r_kernel<true, 25, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 23) hipLaunchKernelGGL((wino43r_kernel<true, 23, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 22) hipLaunchKernelGGL((wino43r_kernel<true, 22, 9>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 18) hipLaunchKernelGGL((wino43r_kernel<true, 18, 9>), grid, dim3(R4_NT), 0, s, *a);
