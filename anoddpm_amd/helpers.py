@@ -50,61 +50,63 @@ def defaultdict_from_json(jsonDict):
     return dd
 
 
+def _model_dir(arg_num):
+    return os.path.join(".", "model", f"diff-params-ARGS={arg_num}")
+
+
 def load_checkpoint(param, use_checkpoint, device):
-    """helpers.py:26-45: `./model/diff-params-ARGS={param}/params-final.pt`, or the newest checkpoint under
-    `.../checkpoint/` that `torch.load` can read (files that raise RuntimeError -- truncated writes -- are skipped).
-    Returns the dict `{'n_epoch', 'model_state_dict', 'optimizer_state_dict', 'ema', 'args'}` as saved
-    (diffusion_training.py:169-189).  Like upstream: an empty / all-corrupt checkpoint directory ends in
-    UnboundLocalError, a missing directory in FileNotFoundError.  `weights_only=False`: the saved `args` entry is a
+    """helpers.py:26-45.  `use_checkpoint` False: `./model/diff-params-ARGS={param}/params-final.pt`; True: the newest file under
+    `.../checkpoint/` (names sorted descending) that `torch.load` can read -- files that raise RuntimeError (truncated writes)
+    are skipped.  Returns the dict `{'n_epoch', 'model_state_dict', 'optimizer_state_dict', 'ema', 'args'}` as saved
+    (diffusion_training.py:169-189).  Error behaviour as upstream: a missing directory is FileNotFoundError, a checkpoint
+    directory without one readable file UnboundLocalError.  `weights_only=False`: the saved `args` entry is a
     `defaultdict(str)` (diffusion_training.py:303), which torch >= 2.6's default safe unpickler refuses -- upstream was written
     against the old default, and the files are the user's own checkpoints."""
-    root = f'./model/diff-params-ARGS={param}'
+    root = _model_dir(param)
     if not use_checkpoint:
-        return torch.load(f'{root}/params-final.pt', map_location=device, weights_only=False)
-    names = os.listdir(f'{root}/checkpoint')
-    names.sort(reverse=True)
-    for name in names:
+        return torch.load(os.path.join(root, "params-final.pt"), map_location=device, weights_only=False)
+    ckpt_dir = os.path.join(root, "checkpoint")
+    for name in sorted(os.listdir(ckpt_dir), reverse=True):
         try:
-            loaded_model = torch.load(f"{root}/checkpoint/{name}", map_location=device, weights_only=False)
-            break
+            newest_readable = torch.load(os.path.join(ckpt_dir, name), map_location=device, weights_only=False)
         except RuntimeError:
             continue
-    return loaded_model
+        break
+    return newest_readable                                           # unbound when nothing could be read: UnboundLocalError, as upstream
+
+
+def _arg_number(spec):
+    """`28`, `args28` or `args28.json` -> "28" (helpers.py:71-78); anything else is a ValueError."""
+    if spec.isnumeric():
+        return spec
+    if spec.startswith("args"):
+        return spec[4:-5] if spec.endswith(".json") else spec[4:]
+    raise ValueError(f"Unsupported input {spec}")
 
 
 def load_parameters(device):
-    """helpers.py:48-93: argv (`28`, `args28`, `args28.json`, optional leading `CHECKPOINT`) or, without arguments, the
-    entries of ./model, resolved to `(args, checkpoint)`.  Only the FIRST parameter is loaded (upstream returns inside its
-    loop); a checkpoint without an `args` entry falls back to `./test_args/args{param[17:]}.json`; `noise_fn` defaults
-    to "gauss"; anything else raises ValueError."""
+    """helpers.py:48-93: which trained model the detection / evaluation drivers work on.  The specs come from argv (an optional
+    leading `CHECKPOINT` selects the newest checkpoint instead of the final parameters) or, without arguments, from the entries
+    of ./model; only the FIRST spec is loaded (upstream returns from inside its loop).  Returns `(args, checkpoint)`: `args` is
+    the checkpoint's own entry or, for checkpoints saved without one, `./test_args/args{spec[17:]}.json` (the tail of a
+    `diff-params-ARGS=N` directory name) as a defaultdict with `arg_num` set; `noise_fn` defaults to "gauss"."""
     import sys
 
-    params = sys.argv[1:] if len(sys.argv[1:]) > 0 else os.listdir("./model")
-    if ".DS_Store" in params:
-        params.remove(".DS_Store")
-    use_checkpoint = params[0] == "CHECKPOINT"
-    if use_checkpoint:
-        params = params[1:]
-    print(params)
-    for param in params:
-        if param.isnumeric():
-            output = load_checkpoint(param, use_checkpoint, device)
-        elif param[:4] == "args" and param[-5:] == ".json":
-            output = load_checkpoint(param[4:-5], use_checkpoint, device)
-        elif param[:4] == "args":
-            output = load_checkpoint(param[4:], use_checkpoint, device)
-        else:
-            raise ValueError(f"Unsupported input {param}")
-        if "args" in output:
-            args = output["args"]
-        else:
-            try:
-                with open(f'./test_args/args{param[17:]}.json', 'r') as f:
-                    args = json.load(f)
-                args['arg_num'] = param[17:]
-                args = defaultdict_from_json(args)
-            except FileNotFoundError:
-                raise ValueError(f"args{param[17:]} doesn't exist for {param}")
-        if "noise_fn" not in args:
-            args["noise_fn"] = "gauss"
-        return args, output
+    specs = list(sys.argv[1:]) or os.listdir("./model")
+    specs = [s_ for s_ in specs if s_ != ".DS_Store"]
+    newest = specs[0] == "CHECKPOINT"                                # IndexError on an empty list, as upstream
+    if newest:
+        specs = specs[1:]
+    print(specs)
+    for spec in specs:
+        checkpoint = load_checkpoint(_arg_number(spec), newest, device)
+        args = checkpoint.get("args") if "args" in checkpoint else None
+        if args is None:
+            tail = spec[17:]
+            path = os.path.join(".", "test_args", f"args{tail}.json")
+            if not os.path.exists(path):
+                raise ValueError(f"args{tail} doesn't exist for {spec}")
+            with open(path, "r") as f:
+                args = defaultdict_from_json(dict(json.load(f), arg_num=tail))
+        args.setdefault("noise_fn", "gauss")
+        return args, checkpoint
