@@ -11,6 +11,7 @@ recipe from SURVEY.md 8c).  Outputs are DATA (inputs + expected outputs), never 
     metrics_kat.npz      evaluation.py metrics + the mean / mse / threshold images of detection_A/B
     simplex2_kat.npz     2-D noise2 point KATs (bit patterns), a coordinate grid, octave fields
     vlb_kat.npz          calc_vlb_xt (KL and decoder-NLL branches) and the MSE curves of calc_total_vlb
+    vlb_total_kat.npz    calc_total_vlb itself (T = 100, injected randn_like draws, analytic eps-model): all five returned curves
     loss_kat.npz         p_loss / calc_loss for l1, l2, hybrid (uniform and prop-t weights): per-sample terms, the scalar,
                          and d(scalar)/d(model output) from the reference's own autograd
     train_<name>.npz     two optimiser steps of the reference loop body (diffusion_training.py:99-107): p_loss scalars,
@@ -493,6 +494,33 @@ def gen_vlb():
     print("vlb_kat.npz:", len(out), "arrays")
 
 
+def gen_vlb_total():
+    """calc_total_vlb itself (GaussianDiffusion.py:445-478): the reference's loop over all T steps with an analytic eps-model and
+    its `torch.randn_like` draws injected (T pre-generated fields, popped in call order), so that the build can replay the same
+    draws: vb / x_0_mse / mse curves, prior_vlb, total_vlb."""
+    T, B, H = 100, 3, 16
+    g = torch.Generator().manual_seed(29)
+    x0 = torch.rand(B, 1, H, H, generator=g) * 2 - 1
+    x0[:, :, 0, :4] = -1.0
+    x0[:, :, 1, :4] = 1.0
+    draws = torch.randn(T, B, 1, H, H, generator=g)
+    out = {"x0": x0.numpy(), "draws": draws.numpy(), "T": np.int64(T)}
+    model = lambda x, t: 0.3 * x - 0.05 * t.view(-1, 1, 1, 1).float() / T
+    for name in ("linear", "cosine"):
+        d = ref_gd.GaussianDiffusionModel([H, H], ref_gd.get_beta_schedule(T, name), noise="gauss")
+        it = iter(draws)
+        real = torch.randn_like
+        torch.randn_like = lambda x, *a, **k: next(it).clone()
+        try:
+            r = d.calc_total_vlb(x0, model, {"Batch_Size": B})
+        finally:
+            torch.randn_like = real
+        for k in ("total_vlb", "prior_vlb", "vb", "x_0_mse", "mse"):
+            out[f"{name}_{k}"] = r[k].numpy()
+    np.savez_compressed(os.path.join(HERE, "vlb_total_kat.npz"), **out)
+    print("vlb_total_kat.npz:", len(out), "arrays")
+
+
 def gen_loss():
     """p_loss (GaussianDiffusion.py:419-434) of the reference with the model output, the noise and t injected: the loss dict,
     the scalar and -- through the reference's own autograd graph -- d(scalar)/d(estimate_noise), for every loss type, with
@@ -560,7 +588,7 @@ def gen_simplex2():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["simplex", "diffusion", "unet", "metrics", "vlb", "loss", "simplex2", "unet_c5", "training",
+    which = sys.argv[1:] or ["simplex", "diffusion", "unet", "metrics", "vlb", "vlb_total", "loss", "simplex2", "unet_c5", "training",
                              "detection", "loader"]
     torch.set_num_threads(8)
     if "simplex" in which:
@@ -575,6 +603,8 @@ if __name__ == "__main__":
         gen_metrics()
     if "vlb" in which:
         gen_vlb()
+    if "vlb_total" in which:
+        gen_vlb_total()
     if "loss" in which:
         gen_loss()
     if "simplex2" in which:

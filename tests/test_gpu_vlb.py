@@ -131,3 +131,25 @@ def test_evaluation_testing_runs_the_reference_loop_on_device(capsys):
     # keyword form of diffusion_training.py:153
     res2 = EV.testing(loader(), d, ema=ema, args=args, model=model, test_iters=0, sequences=False)
     assert res2["sequence_lengths"] == []
+
+
+@pytest.mark.parametrize("name", ["linear", "cosine"])
+def test_calc_total_vlb_matches_reference_fixture(name, monkeypatch):
+    """calc_total_vlb against the REFERENCE's own loop (tests/golden/vlb_total_kat.npz: T = 100, analytic eps-model, its
+    `torch.randn_like` draws injected and replayed here in the same order): all five returned curves."""
+    import GaussianDiffusion as GD
+    GT = np.load(os.path.join(GOLDEN, "vlb_total_kat.npz"))
+    T = int(GT["T"])
+    d = GD.GaussianDiffusionModel([16, 16], GD.get_beta_schedule(T, name), noise="gauss")
+    x0, draws = dv(GT["x0"]), dv(GT["draws"])
+    B = x0.shape[0]
+    model = lambda x, t: 0.3 * x - 0.05 * t.view(-1, 1, 1, 1).float() / T
+    it = iter(draws)
+    monkeypatch.setattr(torch, "randn_like", lambda x, *a, **k: next(it).clone())
+    out = d.calc_total_vlb(x0, model, {"Batch_Size": B})
+    monkeypatch.undo()
+    assert next(it, None) is None                                    # exactly T draws, in the reference's order
+    for k in ("vb", "x_0_mse", "mse"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), GT[f"{name}_{k}"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(out["prior_vlb"].cpu().numpy(), GT[f"{name}_prior_vlb"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(out["total_vlb"].cpu().numpy(), GT[f"{name}_total_vlb"], rtol=1e-4)
