@@ -255,6 +255,16 @@ def gen_unet(only=None):
     print("unet_c2_256_b128.npz params", int(out["n_params"]), "|y| mean", float(np.abs(out["y"]).mean()))
 
 
+def gen_unet_c2_batch4():
+    """BASELINE config 2 exactly as benchmarked: 256^2, base 128, heads 2, attn 16,8 at BATCH 4 with four different timesteps (the
+    build picks other kernels at batch 4 than at batch 1: 128-channel F(4x4) grids, other split-K factors).  Output only."""
+    kw = dict(img_size=256, base_channels=128, n_heads=2, attention_resolutions="16,8")
+    out = run_unet_case("c2_256_b128_batch4", kw, 4, [0, 249, 500, 999], probes=False)
+    out.pop("keys"); out.pop("key_shapes")
+    np.savez_compressed(os.path.join(HERE, "unet_c2_256_b128_batch4.npz"), **out)
+    print("unet_c2_256_b128_batch4.npz |y| mean", float(np.abs(out["y"]).mean()))
+
+
 def gen_unet_c5():
     """BASELINE config 5: 512^2, base 128, mults (1,1,2,2,4,4), attention at 32/16/8, two heads; batch 1."""
     kw = dict(img_size=512, base_channels=128, n_heads=2, channel_mults=(1, 1, 2, 2, 4, 4), attention_resolutions="32,16,8")
@@ -588,7 +598,7 @@ def gen_simplex2():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["simplex", "diffusion", "unet", "metrics", "vlb", "vlb_total", "loss", "simplex2", "unet_c5", "training",
+    which = sys.argv[1:] or ["simplex", "diffusion", "unet", "metrics", "vlb", "vlb_total", "loss", "simplex2", "unet_c5", "unet_c2_batch4", "training",
                              "detection", "loader"]
     torch.set_num_threads(8)
     if "simplex" in which:
@@ -611,6 +621,8 @@ if __name__ == "__main__":
         gen_simplex2()
     if "unet_c5" in which:
         gen_unet_c5()
+    if "unet_c2_batch4" in which:
+        gen_unet_c2_batch4()
     if "training" in which:
         gen_training()
     if any(w.startswith("training:") for w in which):

@@ -62,6 +62,22 @@ def test_forward_matches_reference_output(name):
     assert torch.equal(y, y2) and y2.data_ptr() != y.data_ptr()
 
 
+def test_config2_at_its_benchmarked_batch_matches_reference_output():
+    """BASELINE config 2 exactly as `bench.py` times it -- 256^2, base 128, attention 16/8, BATCH 4 (the plan picks other kernels
+    than at batch 1: 128-channel F(4x4) grids, other split-K factors), four different timesteps -- against the reference model's
+    output for the same inputs (tests/golden/unet_c2_256_b128_batch4.npz, make_golden.py:gen_unet_c2_batch4)."""
+    g = np.load(os.path.join(GOLDEN, "unet_c2_256_b128_batch4.npz"))
+    m, sd, kw = build("c2_256_b128")
+    x, t = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["t"]).to(DEV)
+    assert x.shape[0] == 4 and len(set(g["t"].tolist())) == 4
+    with torch.no_grad():
+        y = m(x, t)
+    ref = torch.from_numpy(g["y"])
+    for b in range(4):                                                  # per image: none may hide behind another's magnitude
+        err = ((y[b].cpu() - ref[b]).abs().max() / ref[b].abs().max()).item()
+        assert err < 5e-5, f"image {b} (t = {int(g['t'][b])}): rel err {err:.3e}"
+
+
 @pytest.mark.parametrize("name", ["i64_b32_hc32", "c5like_i128_b32", "c2_256_b128", "c5_512_b128", "convrs_i64_b32", "poolrs_i32_b32"])
 def test_layerwise_against_reference_probes(name):
     """Every per-block activation the fixture recorded from the REFERENCE model (forward hooks on each module of

@@ -57,6 +57,15 @@ def test_forward_matches_reference(name):
             np.testing.assert_allclose(v[::stride][:256].numpy(), g[k], rtol=0, atol=2e-5, err_msg=key)
 
 
+def test_config2_batch4_matches_reference():
+    """The oracle on BASELINE config 2 at its benchmarked batch (4 images, four timesteps) against the reference model's output."""
+    kw = CASES["c2_256_b128"]
+    g = np.load(os.path.join(GOLDEN, "unet_c2_256_b128_batch4.npz"))
+    sd = uo.fill_deterministic(shapes_of(kw))
+    y = uo.forward(sd, torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), **kw)
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=0, atol=2e-5)
+
+
 def test_c2_param_count_and_flops():
     kw = CASES["c2_256_b128"]
     shapes = shapes_of(kw)
