@@ -7,7 +7,8 @@ The reference is imported read-only with stubbed third-party modules (tests/gold
 recipe from SURVEY.md 8c).  Outputs are DATA (inputs + expected outputs), never reference source:
     simplex_kat.npz      _init tables, noise3 point KATs (bit patterns), octave fields, C4 crops
     diffusion_kat.npz    schedule tables (linear/cosine), sample_q / p_mean_variance / sample_p
-    unet_<name>.npz      UNetModel.forward outputs (+ per-block activation probes)
+    unet_<name>.npz      UNetModel.forward outputs (+ per-block activation probes); unet_c2_256_b128_batch4.npz: BASELINE
+                         config 2 at its benchmarked batch 4 with four timesteps, output only
     metrics_kat.npz      evaluation.py metrics + the mean / mse / threshold images of detection_A/B
     simplex2_kat.npz     2-D noise2 point KATs (bit patterns), a coordinate grid, octave fields
     vlb_kat.npz          calc_vlb_xt (KL and decoder-NLL branches) and the MSE curves of calc_total_vlb
