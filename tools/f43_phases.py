@@ -38,7 +38,7 @@ def main():
         st = hipops.LAST_IGEMM
         dbg = torch.zeros(nblocks * 8, dtype=torch.int64, device=dev)
         st.ws = dbg.data_ptr()
-        assert lib().anoddpm_internal_variant(6, variant) == 0
+        assert lib().anoddpm_internal_variant(6, variant) == 0, "probe variants exist only in a measurement build: ANODDPM_ABLATE=1 python -m anoddpm_amd.build --force"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
             check(lib().anoddpm_igemm(ctypes.byref(st), current_stream()), "igemm")
@@ -69,7 +69,7 @@ def main():
             rows = rows[np.argsort(rows[:, 0])]
             first.append(rows[0, 0])
             gaps += list(rows[1:, 0] - rows[:-1, 4])
-        gaps = np.array(gaps)
+        gaps = np.array(gaps) if gaps else np.zeros(1)               # one workgroup per CU: no successions
         print(f"  gap end -> next entry on the same CU: mean {gaps.mean() / tick_us:6.2f} us  p10 {np.percentile(gaps, 10) / tick_us:6.2f}  "
               f"p50 {np.percentile(gaps, 50) / tick_us:6.2f}  p90 {np.percentile(gaps, 90) / tick_us:6.2f}   ({len(gaps)} successions)")
         per_cu = np.array([np.sum(cu == c) for c in np.unique(cu)])
