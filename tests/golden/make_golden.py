@@ -18,6 +18,8 @@ recipe from SURVEY.md 8c).  Outputs are DATA (inputs + expected outputs), never 
     train_<name>.npz     two optimiser steps of the reference loop body (diffusion_training.py:99-107): p_loss scalars,
                          gradient probes / norms of every parameter, parameter + EMA probes after each step
     detection_fixedT.npz detection_A_fixedT (GaussianDiffusion.py:596-623) on a 32^2 model, seeded numpy stream
+    detection_loops_kat.npz  detection_B ("gauss", "octave") and detection_A (:480-594) on a 32^2 model, T = 200: per setting the
+                         tensor upstream plots (x_0, chains, mean, mse, threshold, mask), keyed randn_like draws (keyed.py)
     mri_loader.npz       MRIDataset normalisation + slice (dataset.py:585-594, 621-625) and the deterministic part of
                          its transform (centre-crop 235, bilinear resize, scale; torchvision -> PIL) on a synthetic volume
 """
@@ -372,6 +374,86 @@ def gen_detection():
     print("detection_fixedT.npz", out.shape, float(out.abs().mean()))
 
 
+def gen_detection_loops():
+    """detection_B ("gauss" and "octave") and detection_A (GaussianDiffusion.py:480-594) run by the REFERENCE on a 32^2 model with
+    T = 200: the serial (t_distance, avg) loops, their forward-noise draw order, `output[avg]` placement and the
+    mean -> mse -> threshold post-processing.  `torch.randn_like` is replaced by a keyed stream (tests/golden/keyed.py: the value
+    depends on (chain, t), chain = index in upstream's loop order), the simplex forward noise comes from the seeded numpy stream;
+    the figure calls are stubbed and what upstream hands to `gridify_output` (cat[x_0, output[:3], mean, mse, threshold, mask]) is
+    recorded per setting."""
+    import tempfile
+    import keyed
+    kw = dict(img_size=32, base_channels=32, n_heads=2, attention_resolutions="16,8")
+    model = ref_unet.UNetModel(**kw)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(unet_oracle.fill_deterministic(shapes))
+    model.eval()
+    T = 200
+    args = {"T": T, "img_size": [32, 32], "arg_num": 0}
+    g = torch.Generator().manual_seed(777)
+    x0 = torch.rand(1, 1, 32, 32, generator=g) * 2 - 1
+    mask = (torch.rand(1, 1, 32, 32, generator=g) > 0.8).float()
+    out = {"x0": x0.numpy(), "mask": mask.numpy(), "T": np.int64(T)}
+
+    state = {"chain": 0, "t": None}
+    grids = []
+
+    def run(fn_name, np_seed, **kwargs):
+        d = ref_gd.GaussianDiffusionModel([32, 32], ref_gd.get_beta_schedule(T, "linear"), noise="simplex")
+        state["chain"], state["t"] = 0, None
+        grids.clear()
+        real_q, real_p = d.sample_q, d.sample_p
+
+        def sample_q(x_0, t, noise):                    # one call per chain, after its forward noise was drawn
+            r = real_q(x_0, t, noise)
+            return r
+
+        def sample_p(m, x_t, t, denoise_fn="gauss"):
+            state["t"] = int(t[0])
+            r = real_p(m, x_t, t, denoise_fn)
+            if int(t[0]) == 0:
+                state["chain"] += 1                     # the chain's last reverse step
+            return r
+
+        def randn_like(x, *a, **k):
+            if state["t"] is None:                      # detection_B "gauss": the chain's forward noise (:552)
+                return keyed.keyed_normal(state["chain"], keyed.FORWARD, x.shape)
+            t, state["t"] = state["t"], None
+            return keyed.keyed_normal(state["chain"], t, x.shape)
+
+        d.sample_q, d.sample_p = sample_q, sample_p
+        saved = (torch.randn_like, ref_gd.gridify_output, ref_gd.plt.imshow, ref_gd.plt.savefig, ref_gd.plt.axis, ref_gd.plt.clf,
+                 ref_gd.evaluation.heatmap)
+        torch.randn_like = randn_like
+        ref_gd.gridify_output = lambda img, *a, **k: (grids.append(img.detach().clone()), np.zeros((4, 4)))[1]
+        ref_gd.plt.imshow = ref_gd.plt.savefig = ref_gd.plt.axis = ref_gd.plt.clf = lambda *a, **k: None
+        ref_gd.evaluation.heatmap = lambda *a, **k: None
+        cwd = os.getcwd()
+        np.random.seed(np_seed)
+        try:
+            with tempfile.TemporaryDirectory() as tmp:
+                os.chdir(tmp)
+                ret = getattr(d, fn_name)(model, x0, args, ("f", "0"), mask, **kwargs)
+        finally:
+            os.chdir(cwd)
+            (torch.randn_like, ref_gd.gridify_output, ref_gd.plt.imshow, ref_gd.plt.savefig, ref_gd.plt.axis, ref_gd.plt.clf,
+             ref_gd.evaluation.heatmap) = saved
+        after = np.random.randint(-10000000000, 10000000000)
+        return ret, torch.stack(grids).numpy(), state["chain"], after
+
+    ret, gr, nchain, after = run("detection_B", 101, denoise_fn="gauss", total_avg=3)
+    assert ret == [None] * 3 and nchain == 9 and gr.shape == (3, 8, 1, 32, 32)
+    out.update(B_gauss=gr, B_gauss_total_avg=np.int64(3), B_gauss_np_seed=np.int64(101), B_gauss_next_randint=np.int64(after))
+    ret, gr, nchain, after = run("detection_B", 202, denoise_fn="octave", total_avg=3)
+    assert ret == [None] * 2 and nchain == 6 and gr.shape == (2, 8, 1, 32, 32)
+    out.update(B_octave=gr, B_octave_total_avg=np.int64(3), B_octave_np_seed=np.int64(202), B_octave_next_randint=np.int64(after))
+    ret, gr, nchain, after = run("detection_A", 303, total_avg=2)
+    assert ret is None and nchain == 28 and gr.shape == (14, 7, 1, 32, 32)
+    out.update(A=gr, A_total_avg=np.int64(2), A_np_seed=np.int64(303), A_next_randint=np.int64(after))
+    np.savez_compressed(os.path.join(HERE, "detection_loops_kat.npz"), **out)
+    print("detection_loops_kat.npz:", {k: getattr(v, "shape", ()) for k, v in out.items()})
+
+
 def gen_loader():
     """MRIDataset (dataset.py:575-643) run by the reference on a synthetic NIfTI-shaped volume (nibabel stubbed: `nib.load`
     returns an object whose get_fdata() is the array): the normalised .npy cache it writes and the slices it cuts.  The
@@ -600,7 +682,7 @@ def gen_simplex2():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["simplex", "diffusion", "unet", "metrics", "vlb", "vlb_total", "loss", "simplex2", "unet_c5", "unet_c2_batch4", "training",
-                             "detection", "loader"]
+                             "detection", "loader", "detection_loops"]
     torch.set_num_threads(8)
     if "simplex" in which:
         gen_simplex()
@@ -632,3 +714,5 @@ if __name__ == "__main__":
         gen_detection()
     if "loader" in which:
         gen_loader()
+    if "detection_loops" in which:
+        gen_detection_loops()

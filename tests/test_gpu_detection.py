@@ -289,3 +289,142 @@ def test_out_of_range_t_distance_raises_like_extract():
     assert torch.isnan(bad).all()
     ok = d.sample_q(x, torch.tensor([-1], device=DEV), torch.zeros_like(x))       # python-style negative index, as numpy
     assert torch.equal(ok, d.sample_q(x, torch.tensor([99], device=DEV), torch.zeros_like(x)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The slot-batched loops against the REFERENCE's serial loops (tests/golden/detection_loops_kat.npz, make_golden.py:
+# gen_detection_loops): the reference ran detection_B / detection_A on CPU with torch.randn_like replaced by a keyed stream
+# (tests/golden/keyed.py: the value depends on (chain in upstream's loop order, t)); here the same keyed values are handed to
+# whichever slot holds that chain at that timestep.  Pins what the scheduler could get wrong: the forward-noise draw order,
+# which chain lands in output[avg], and the mean -> mse -> threshold post-processing (GaussianDiffusion.py:514-520, 569-576).
+
+class _KeyedDraws:
+    """torch.randn_like replacement for the build: forward noise while the chains are being set up, per-slot step noise inside
+    _run_chains (slot -> (chain, t) from the schedule the loop itself published in last_chain_schedule)."""
+
+    def __init__(self, d, lens):
+        self.d, self.lens, self.fwd, self.k, self.in_loop = d, lens, 0, 0, False
+        real = d._run_chains
+
+        def run_chains(*a, **kw):
+            self.in_loop, self.k = True, 0
+            try:
+                return real(*a, **kw)
+            finally:
+                self.in_loop = False
+        d._run_chains = run_chains
+
+    def __call__(self, x, *a, **kw):
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+        import keyed
+        if not self.in_loop:                                            # detection_B "gauss": one forward draw per chain, upstream order
+            c, self.fwd = self.fwd, self.fwd + 1
+            return keyed.keyed_normal(c, keyed.FORWARD, x.shape).to(x.device)
+        sched = self.d.last_chain_schedule
+        out = torch.zeros(x.shape, dtype=torch.float32)
+        for c, (slot, start) in sched["place"].items():
+            if start <= self.k < start + self.lens[c]:
+                out[slot] = keyed.keyed_normal(c, self.lens[c] - 1 - (self.k - start), x.shape[1:])
+        self.k += 1
+        return out.to(x.device)
+
+
+def _loops_fixture():
+    from conftest import GOLDEN
+    import GaussianDiffusion as GD
+    g = np.load(os.path.join(GOLDEN, "detection_loops_kat.npz"))
+    _, m, _ = tiny()
+    T = int(g["T"])
+    d = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(T, "linear"), noise="simplex")
+    args = {"arg_num": 0, "T": T, "img_size": [32, 32]}
+    return g, m, d, args, torch.from_numpy(g["x0"]).to(DEV), torch.from_numpy(g["mask"]).to(DEV)
+
+
+def _check_settings(recs, ref, x0, mask, navg):
+    """ref[j] = what upstream hands to its figure for setting j: cat[x_0, output[:3], mean, mse, threshold, mask]."""
+    assert len(recs) == ref.shape[0]
+    nshow = min(3, navg)
+    for j, rec in enumerate(recs):
+        r = torch.from_numpy(ref[j])
+        assert torch.equal(r[0], x0[0].cpu()) and torch.equal(r[-1], mask[0].cpu())
+        out = rec["output"].cpu()
+        assert out.shape[0] == navg
+        for a in range(nshow):                                          # the chain upstream stored in output[a]
+            err = float((out[a] - r[1 + a]).abs().max())
+            assert err < 2e-3, (j, a, err)
+        mean, mse, thr = r[1 + nshow], r[2 + nshow], r[3 + nshow]
+        assert float((rec["mean"].cpu()[0] - mean).abs().max()) < 2e-3
+        assert float((rec["mse"].cpu()[0] - mse).abs().max()) < 1e-2
+        away = mse.abs() > 2e-2
+        assert torch.equal(rec["threshold"].cpu()[0][away], thr[away])
+
+
+@pytest.mark.parametrize("slots", [None, 3])
+@pytest.mark.parametrize("mode", ["gauss", "octave"])
+def test_detection_B_matches_reference_loop(mode, slots, monkeypatch, tmp_path):
+    g, m, d, args, x0, mask = _loops_fixture()
+    navg = int(g[f"B_{mode}_total_avg"])
+    end = int(args["T"] * (0.6 if mode == "octave" else 0.8))
+    lens = [t for t in range(50, end, 50) for _ in range(navg)]
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("ANODDPM_NO_GRAPH", "1")                           # the keyed draws are host values: eager steps
+    if slots is not None:
+        monkeypatch.setenv("ANODDPM_DET_SLOTS", str(slots))
+    monkeypatch.setattr(torch, "randn_like", _KeyedDraws(d, lens))
+    np.random.seed(int(g[f"B_{mode}_np_seed"]))
+    ret = d.detection_B(m, x0, args, ("f", "0"), mask, denoise_fn=mode, total_avg=navg)
+    assert np.random.randint(-10000000000, 10000000000) == int(g[f"B_{mode}_next_randint"])
+    assert ret == [None] * len(range(50, end, 50))
+    assert d.last_chain_schedule["slots"] == min(slots or 8, len(lens)) and d.last_chain_schedule["chain_steps"] == sum(lens)
+    assert [r["t_distance"] for r in d.last_detection] == list(range(50, end, 50))
+    _check_settings(d.last_detection, g[f"B_{mode}"], x0, mask, navg)
+
+
+def test_detection_A_matches_reference_loop(monkeypatch, tmp_path):
+    g, m, d, args, x0, mask = _loops_fixture()
+    navg = int(g["A_total_avg"])
+    tds = list(range(50, int(args["T"] * 0.6), 50))
+    lens = [t for _ in range(7) for t in tds for _ in range(navg)]
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("ANODDPM_NO_GRAPH", "1")
+    monkeypatch.setattr(torch, "randn_like", _KeyedDraws(d, lens))
+    np.random.seed(int(g["A_np_seed"]))
+    assert d.detection_A(m, x0, args, ("f", "0"), mask, total_avg=navg) is None
+    assert np.random.randint(-10000000000, 10000000000) == int(g["A_next_randint"])
+    assert d.last_chain_schedule["slots"] == 16 and d.last_chain_schedule["chain_steps"] == sum(lens)
+    assert [(r["freq"], r["t_distance"]) for r in d.last_detection] == [(i, t) for i in range(7, 0, -1) for t in tds]
+    _check_settings(d.last_detection, g["A"], x0, mask, navg)
+
+
+@pytest.mark.parametrize("slots", [None, 16])
+def test_config2_chains_on_slots_equal_serial_chains(slots):
+    """The slot-batched loop at the size the product runs it: the 256^2 / base-128 model of BASELINE config 2 stepped at batch
+    16 / 12 / 8 (per-layer kernel choice differs from batch 1 and 4).  Every chain equals the same chain run alone through
+    sample_p (batch 1, itself pinned to the reference) with the draws its slot saw."""
+    import GaussianDiffusion as GD
+    from test_gpu_unet import build
+    m, _, _ = build("c2_256_b128")
+    d = GD.GaussianDiffusionModel([256, 256], GD.get_beta_schedule(1000, "linear"), noise="gauss")
+    torch.manual_seed(9)
+    x_0 = torch.rand(1, 1, 256, 256, device=DEV) * 2 - 1
+    dists = [3, 3, 3, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 3, 2]      # 19 chains, 32 chain-steps
+    n = len(dists)
+    fwd = torch.randn(n, 1, 256, 256, device=DEV)
+    torch.manual_seed(23)
+    out = d._run_chains(m, x_0, dists, fwd, slots=slots)
+    sched = d.last_chain_schedule
+    G = sched["slots"]
+    assert G in (16, 12, 8) and (slots is None or G == 16) and sched["chain_steps"] == sum(dists)
+    torch.manual_seed(23)
+    draws = [torch.randn(G, 1, 256, 256, device=DEV) for _ in range(sched["steps"])]
+    worst = 0.0
+    for c, dist in enumerate(dists):
+        x = d.sample_q(x_0, torch.full((1,), dist, device=DEV, dtype=torch.int64), fwd[c:c + 1])
+        slot, start = sched["place"][c]
+        for i, t in enumerate(range(dist - 1, -1, -1)):
+            tb = torch.full((1,), t, device=DEV, dtype=torch.int64)
+            with torch.no_grad():
+                x = d.sample_p(m, x, tb, denoise_fn=lambda xx, tt, k=start + i, s=slot: draws[k][s:s + 1])["sample"]
+        worst = max(worst, float((out[c:c + 1] - x).abs().max()))
+    assert worst < 1e-4, worst

@@ -163,18 +163,21 @@ def test_batch_invariance_and_training_path_agree():
     assert m.out["2"].weight.grad is not None and torch.isfinite(m.out["2"].weight.grad).all()
 
 
-@pytest.mark.parametrize("B", [4, 5])
+@pytest.mark.parametrize("B", [4, 5, 8, 12, 16])
 def test_config2_batch_equals_single_image_forwards(B):
-    """BASELINE config 2 runs at batch 4 per GPU (and the detection loop at batch 5: five averaged chains); the reference fixture
-    pins batch 1.  Images are independent, so the batched forward -- different kernels per layer than batch 1: split-K factors, the
-    64- / 128-channel F(4x4,3x3) workgroups (batch 5 takes the 128-channel ones on the 64x64 maps), the no-split-K small-map
-    kernels -- must reproduce B batch-1 forwards, the first of which is the reference-pinned input."""
+    """BASELINE config 2 runs at batch 4 per GPU; the detection loops step the same model at batch 16 / 12 / 8 (one image per chain
+    slot, `GaussianDiffusionModel._run_chains`; batch 5 was round 4's five averaged chains); the reference fixture pins batch 1 (and
+    batch 4, `test_config2_at_its_benchmarked_batch`).  Images are independent, so the batched forward -- different kernels per
+    layer than batch 1: split-K factors, the 64- / 128-channel F(4x4,3x3) workgroups (batch >= 5 takes the 128-channel ones on the
+    64x64 maps), the no-split-K small-map kernels (row tiles over the batch) -- must reproduce B batch-1 forwards, the first of
+    which is the reference-pinned input.  Timesteps are per slot and spread over [0, 999] as in the slot-batched loop."""
     name = "c2_256_b128"
     g = np.load(os.path.join(GOLDEN, f"unet_{name}.npz"))
     m, sd, kw = build(name)
     gen = torch.Generator().manual_seed(5)
     x = torch.cat([torch.from_numpy(g["x"]), torch.rand(B - 1, 1, 256, 256, generator=gen) * 2 - 1]).to(DEV)
-    t = torch.tensor([int(g["t"][0]), 0, 500, 999, 250][:B], device=DEV)
+    spread = [int(g["t"][0]), 0, 500, 999, 250] + [int(v) for v in np.linspace(1, 998, 11)]
+    t = torch.tensor(spread[:B], device=DEV)
     with torch.no_grad():
         yb = m(x, t)
         y1 = torch.cat([m(x[i:i + 1], t[i:i + 1]) for i in range(B)])
