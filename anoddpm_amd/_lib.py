@@ -8,8 +8,10 @@ import os
 from ctypes import POINTER, Structure, c_double, c_float, c_int16, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip.so")
-ABI_VERSION = 21
+# ANODDPM_LIB_TAG=<tag>: load lib/libanoddpm_hip_<tag>.so instead -- a second build of the same sources with other compiler flags
+# (ANODDPM_BUILD_TAG / ANODDPM_EXTRA_FLAGS of anoddpm_amd.build), for A/B measurements of one gpurun session.  Same ABI, same checks.
+SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip%s.so" % ("_" + os.environ["ANODDPM_LIB_TAG"] if os.environ.get("ANODDPM_LIB_TAG") else ""))
+ABI_VERSION = 22
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 (OP_WGRAD3, OP_WGRAD1, OP_GN_BWD, OP_PACK, OP_SOFTMAX_BWD, OP_TRANSPOSE, OP_LINEAR_BWD, OP_STEM_BWD, OP_HEAD_BWD,
@@ -50,7 +52,7 @@ class IgemmArgs(Structure):
                 ("tail_c1", c_int32), ("tail_groups", c_int32), ("tail_eps", c_float),
                 ("fold_stats0", c_void_p), ("fold_stats1", c_void_p), ("fold_gamma", c_void_p), ("fold_beta", c_void_p),
                 ("fold_rows0", c_int32), ("fold_rows1", c_int32), ("fold_fmt0", c_int32), ("fold_fmt1", c_int32),
-                ("fold_groups", c_int32), ("fold_eps", c_float), ("res_mode", c_int32)]
+                ("fold_groups", c_int32), ("fold_eps", c_float), ("res_mode", c_int32), ("stats_csum", c_void_p)]
 
 
 class GnArgs(Structure):
@@ -110,7 +112,7 @@ class LinearArgs(Structure):
 
 class PosembArgs(Structure):
     _fields_ = [("t", c_void_p), ("freqs", c_void_p), ("out", c_void_p), ("B", c_int32), ("dim", c_int32),
-                ("scale", c_float)]
+                ("scale", c_float), ("zero", c_void_p), ("zero_doubles", c_int64)]
 
 
 class StemArgs(Structure):

@@ -48,12 +48,25 @@ def hipcc():
 
 
 def build(force=False, verbose=False):
+    global OBJDIR, SO
+    # measurement builds beside the product library: ANODDPM_BUILD_TAG=<tag> writes lib/libanoddpm_hip_<tag>.so (objects in
+    # lib/obj_<tag>); ANODDPM_EXTRA_FLAGS="file.hip:-flag1,-flag2;other.hip:-flag" appends per-file compiler flags.  Loaded with
+    # ANODDPM_LIB_TAG=<tag> (_lib.py).  The product build (no tag) ignores ANODDPM_EXTRA_FLAGS.
+    tag = os.environ.get("ANODDPM_BUILD_TAG", "")
+    extra_flags = {}
+    if tag:
+        OBJDIR = os.path.join(LIBDIR, "obj_" + tag)
+        SO = os.path.join(LIBDIR, "libanoddpm_hip_%s.so" % tag)
+        for item in filter(None, os.environ.get("ANODDPM_EXTRA_FLAGS", "").split(";")):
+            f, _, fl = item.partition(":")
+            extra_flags[f.strip()] = [x for x in fl.split(",") if x]
     os.makedirs(OBJDIR, exist_ok=True)
     # ANODDPM_ABLATE=1: measurement build that also contains the timing ablations (kernels that skip work and produce wrong
     # results by design; selected through anoddpm_internal_variant / ANODDPM_DEBUGn).  The product build has none of them.
     flags = list(COMMON) + (["-DANODDPM_ABLATE"] if os.environ.get("ANODDPM_ABLATE", "0") == "1" else [])
     stamp = os.path.join(OBJDIR, "flags.txt")
-    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+    stamp_text = " ".join(flags) + "".join(f" | {k}: {' '.join(v)}" for k, v in sorted(extra_flags.items()))
+    if not os.path.exists(stamp) or open(stamp).read() != stamp_text:
         force = True
         if os.path.exists(stamp):
             os.remove(stamp)                     # re-written only after EVERY object compiled with the new flags
@@ -67,7 +80,7 @@ def build(force=False, verbose=False):
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), dep_m):
-            cmd = [hipcc(), *flags, *extra, "-c", s, "-o", o]
+            cmd = [hipcc(), *flags, *extra, *extra_flags.get(src, []), "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -85,7 +98,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("\n".join(failed))
     with open(stamp, "w") as f:
-        f.write(" ".join(flags))
+        f.write(stamp_text)
     if rebuilt or not os.path.exists(SO):
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs]
         subprocess.check_call(cmd)

@@ -388,6 +388,11 @@ __global__ void posemb_kernel(anoddpm_posemb_args a)
 {
     const int half = a.dim >> 1;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // side job (round 6): clear the plan's statistics accumulators (anoddpm_igemm_args.stats_csum), 16 bytes per thread and trip
+    for (int64_t z = (int64_t)i * 2; z < a.zero_doubles; z += (int64_t)gridDim.x * blockDim.x * 2) {
+        a.zero[z] = 0.0;
+        if (z + 1 < a.zero_doubles) a.zero[z + 1] = 0.0;
+    }
     if (i >= a.B * half) return;
     const int b = i / half, j = i % half;
     const float arg = ((float)a.t[b] * a.scale) * a.freqs[j];
@@ -824,9 +829,14 @@ __global__ __launch_bounds__(256) void conv_head_mfma2_kernel(anoddpm_head_args 
 #pragma unroll
             for (int j = 0; j < NJ; ++j) v[cur ^ 1][j] = *reinterpret_cast<const hf32x4 *>(xp + 16 * j);
         }
-        hf32x4 accr[NT];
+        // round 6: one accumulator per float4 component.  With Cout = 1 (NT = 1) the 4 * NJ MFMAs of a tile row were ONE dependent
+        // chain (58 % of the wave cycles were issue stalls, profiles/r5_c2_sq_by_kernel.csv); four chains keep the pipe fed from
+        // a single wave.  The partial sums are added pairwise at the end of the row: (s0 + s1) + (s2 + s3).
+        hf32x4 accs[4][NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) accr[nt] = hf32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) accs[s][nt] = hf32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const hf32x4 x4 = v[cur][j] * aff[0][4 * j + q] + aff[1][4 * j + q];
@@ -838,8 +848,11 @@ __global__ __launch_bounds__(256) void conv_head_mfma2_kernel(anoddpm_head_args 
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) accr[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[s], bw[nt][j][s], accr[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) accs[s][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[s], bw[nt][j][s], accs[s][nt], 0, 0, 0);
         }
+        hf32x4 accr[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accr[nt] = (accs[0][nt] + accs[1][nt]) + (accs[2][nt] + accs[3][nt]);
         // D[row = 4 q + r][col = m]: zero padding of the ACTIVATED map = zero product rows of out-of-image pixels
         const int gy = oy0 + wave * RPW + mt - 1;
         const bool rowok = gy >= 0 && gy < a.H;
@@ -1004,7 +1017,11 @@ extern "C" int anoddpm_posemb(const anoddpm_posemb_args *a, void *stream)
 {
     ANODDPM_REQUIRE(a && a->t && a->freqs && a->out && a->B >= 1 && a->dim >= 2 && a->dim % 2 == 0, "posemb: bad arguments");
     const int n = a->B * (a->dim / 2);
-    hipLaunchKernelGGL(posemb_kernel, dim3((n + 255) / 256), dim3(256), 0, anoddpm::as_stream(stream), *a);
+    ANODDPM_REQUIRE(a->zero_doubles >= 0 && (a->zero_doubles == 0 || (a->zero && (uintptr_t)a->zero % 8 == 0)), "posemb: bad zero range");
+    int64_t blocks = (n + 255) / 256;
+    const int64_t zblocks = (a->zero_doubles / 2 + 255) / 256;            // 16 bytes per thread and trip; at most one block per CU x 2
+    if (zblocks > blocks) blocks = zblocks < 512 ? zblocks : 512;
+    hipLaunchKernelGGL(posemb_kernel, dim3((unsigned)blocks), dim3(256), 0, anoddpm::as_stream(stream), *a);
     return anoddpm::check_launch("posemb");
 }
 

@@ -21,6 +21,7 @@
 // buffers); one thread per (tile, channel) forms A^T M A, adds bias / temb / residual, stores 16 pixels through buffer stores with
 // scalar pixel offsets and folds the GroupNorm sums.
 #include "common.h"
+#include "gn_fold.h"
 
 using anoddpm::silu_f;
 
@@ -79,7 +80,10 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
     const float *A1 = a.a1 ? a.a1 + (int64_t)b * a.a1_bs : nullptr;
     const float *gsc = a.gn_scale ? a.gn_scale + (int64_t)b * a.gn_ld : nullptr;
     const float *gsh = a.gn_shift ? a.gn_shift + (int64_t)b * a.gn_ld : nullptr;
-    const bool affine = gsc != nullptr, act = a.act != 0;
+    // GroupNorm finished here from fp64 sums (gn_fold.h) -- in the 64-channel variant only: the 128-channel form of THIS kernel is a
+    // measurement fallback (ANODDPM_DEBUG5=1; the 128-channel grids run winograd43r.hip) at its 168-register budget
+    const bool fold = NTL == 4 && a.fold_gamma != nullptr;
+    const bool affine = gsc != nullptr || fold, act = a.act != 0;
     const int nchunks = K / F4_KC;
 
     // ---- patch staging (pixel = idx >> 2, quad = idx & 3): geometry fixed for the workgroup
@@ -203,10 +207,13 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
     const int c1 = last >= 1 ? 1 : 0, c2 = last >= 2 ? 2 : last;
     // GroupNorm affine of the image -> LDS, requested first (threads 0 .. K/4-1: one float4 of scales and one of shifts each)
     f32x4 aff_sc = {0.f, 0.f, 0.f, 0.f}, aff_sh = {0.f, 0.f, 0.f, 0.f};
-    const bool aff_slot = (FAST || affine) && tid < K4;
+    const bool aff_slot = (FAST || affine) && tid < K4 && !fold;
+    anoddpm::FoldLoads fl;
     if (aff_slot) {
         aff_sc = bld4(rSc, (unsigned)(tid * 16), 0u);
         aff_sh = bld4(rSh, (unsigned)(tid * 16), 0u);
+    } else if (fold) {
+        fl = anoddpm::fold_affine_request(a, b, tid);                 // oldest requests of the workgroup, like the table loads above
     }
     load_patch(0);
     f32x4 praw0[F4_PJ];
@@ -216,7 +223,10 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
 #pragma unroll
     for (int g = 0; g < 4; ++g) load_group(0, g, g);
     if (FAST || affine) {
-        if (aff_slot) {                                                // oldest requests: no wait for the patches behind them
+        if (fold) {
+            // scratch = the V buffers (first written by transform() below, behind two more barriers)
+            anoddpm::fold_affine_finish(a, fl, tid, a_mode == 1 ? (H >> 1) * (W >> 1) : H * W, reinterpret_cast<double *>(ldsV), ldsAff);
+        } else if (aff_slot) {                                         // oldest requests: no wait for the patches behind them
             ldsAff[tid] = aff_sc;
             ldsAff[K4 + tid] = aff_sh;
         }
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
         }
         __syncthreads();                                            // all reads of M done
     }
-    if (a.stats) {
+    if (a.stats || a.stats_csum) {
         // per-channel sums over the workgroup's 256 pixels: ONE statistics row per workgroup, reduced once for all rounds
         float *rs = M, *rq = M + ROUNDS * 16 * 48;
 #pragma unroll
@@ -407,9 +417,13 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int t = 0; t < 16; ++t) { s += rs[(round * 16 + t) * 48 + chl]; q += rq[(round * 16 + t) * 48 + chl]; }
-            float *st = a.stats + (((int64_t)b * gridDim.x + blockIdx.x) * N + n0 + tid) * 2;
-            st[0] = s;
-            st[1] = q;
+            if (a.stats_csum) {
+                anoddpm::csum_atomic_add(a.stats_csum, b, N, n0 + tid, s, q);   // one fp64 pair per workgroup and channel (gn_fold.h)
+            } else {
+                float *st = a.stats + (((int64_t)b * gridDim.x + blockIdx.x) * N + n0 + tid) * 2;
+                st[0] = s;
+                st[1] = q;
+            }
         }
     }
 }
@@ -428,7 +442,17 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
     const int K = a->c0 + a->c1;
     ANODDPM_REQUIRE(K % F4_KC == 0 && (a->c1 == 0 || a->c0 % F4_KC == 0), "winograd43: channel counts must be multiples of 16");
     ANODDPM_REQUIRE((int64_t)36 * K * a->N * 4 < ((int64_t)1 << 31), "winograd43: transformed weights exceed 32-bit buffer offsets");
-    ANODDPM_REQUIRE(!a->gn_scale || K <= F4_KMAX, "winograd43: the GroupNorm affine table holds %d input channels", F4_KMAX);
+    ANODDPM_REQUIRE(!(a->gn_scale || a->fold_gamma) || K <= F4_KMAX, "winograd43: the GroupNorm affine table holds %d input channels", F4_KMAX);
+    if (a->fold_gamma) {
+        ANODDPM_REQUIRE(a->fold_beta && a->fold_stats0 && (a->c1 == 0 || a->fold_stats1) && a->fold_fmt0 == 1 && (a->c1 == 0 || a->fold_fmt1 == 1),
+                        "winograd43: the GroupNorm fold takes fp64 sums (fold_fmt 1: stats_csum / tail_csum sources) only");
+        ANODDPM_REQUIRE(a->fold_groups >= 1 && a->fold_groups <= 64 && K % a->fold_groups == 0 && a->ksplit == 1,
+                        "winograd43: GroupNorm fold: bad group count, or split-K");
+        ANODDPM_REQUIRE(((uintptr_t)a->fold_stats0 | (uintptr_t)a->fold_stats1 | (uintptr_t)a->fold_gamma | (uintptr_t)a->fold_beta) % 16 == 0,
+                        "winograd43: GroupNorm fold: sums, gamma and beta must be 16-byte aligned");
+    }
+    if (a->stats_csum)
+        ANODDPM_REQUIRE(!a->stats && a->ksplit == 1 && a->heads == 1, "winograd43: stats_csum excludes stats rows, split-K and heads");
     ANODDPM_REQUIRE((int64_t)a->H * a->W * (a->a0_ld > a->a1_ld ? a->a0_ld : a->a1_ld) * 4 < ((int64_t)1 << 31),
                     "winograd43: operand slice exceeds 32-bit buffer offsets");
     // 64-channel workgroups when 128-channel ones would leave CUs idle (or N is not a multiple of 128): rounds over the 256 CUs x
@@ -440,7 +464,7 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
     const int nblk = half ? 64 : 128;
     dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / nblk), (unsigned)a->B);
     ANODDPM_REQUIRE(a->B <= 65535, "winograd43: batch too large");
-    const bool fast = a->gn_scale && a->act;
+    const bool fast = (a->gn_scale || a->fold_gamma) && a->act;
     ANODDPM_REQUIRE(a->res_mode == 0 || (a->res_mode == 1 && a->res && a->ksplit == 1), "winograd43: res_mode 1 needs a residual and ksplit 1");
 #ifdef ANODDPM_ABLATE
     const int dbg = anoddpm::g_debug[2];
@@ -467,6 +491,7 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
     else if (fast && dbg == 4) hipLaunchKernelGGL((wino43_kernel<true, 4>), grid, dim3(F4_NT), 0, s, *a);
     else
 #endif
+    ANODDPM_REQUIRE(half || !a->fold_gamma, "winograd43: the position-sliced 128-channel kernel (ANODDPM_DEBUG5=1) does not fold the GroupNorm");
     if (fast && half) hipLaunchKernelGGL((wino43_kernel<true, 0, 4>), grid, dim3(F4_NT), 0, s, *a);
     else if (half) hipLaunchKernelGGL((wino43_kernel<false, 0, 4>), grid, dim3(F4_NT), 0, s, *a);
     else if (fast) hipLaunchKernelGGL((wino43_kernel<true>), grid, dim3(F4_NT), 0, s, *a);

@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gn_fold.h"
 
 using anoddpm::silu_f;
 
@@ -76,9 +77,16 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4])
 // R4_RING = B-fragment requests in flight per wave
 // NPOS < 36 (timing only, wrong results): only the first NPOS transform positions are multiplied -- frees accumulator registers for
 // ring-depth experiments (the epilogue is skipped)
-template <bool FAST, int DBG = 0, int R4_RING = 6, int NPOS = 36>
+// VAR (correct results; measurement switches of round 6): bit 0 = the two waves of a SIMD transform half a chunk apart (waves
+// 4..7 run T at position 18 instead of before position 0, so that a SIMD's MFMA-free transform block of one wave sits beside the
+// other wave's MFMAs); bit 1 = input transform in scalar f32 (v_fma_f32 with SGPR coefficients) instead of packed f32
+template <bool FAST, int DBG = 0, int R4_RING = 6, int NPOS = 36, int VAR = 0>
 __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_args a)
 {
+    constexpr bool V_DEPHASE = (VAR & 1) != 0, V_SCALAR_T = (VAR & 2) != 0;
+    // bit 2 = the MFMAs of two positions interleaved (consecutive MFMAs on different accumulators: no dependent back-to-back chain
+    // when the SIMD's other wave is not issuing MFMAs); bit 3 = static s_setprio 1 for the younger half (waves 4..7)
+    constexpr bool V_PAIR = (VAR & 4) != 0, V_PRIO = (VAR & 8) != 0;
     // cache policy experiments (results unchanged): DBG 18 patch requests nt; 19 patch + residual requests and stores nt;
     // 20 stores sc1 (written through, not kept in L2); 21 patch + residual nt, stores sc1
     constexpr int PATCH_AUX = (DBG == 18 || DBG == 19 || DBG == 21) ? 2 : 0;
@@ -110,7 +118,8 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     const float *A1 = a.a1 ? a.a1 + (int64_t)b * a.a1_bs : nullptr;
     const float *gsc = a.gn_scale ? a.gn_scale + (int64_t)b * a.gn_ld : nullptr;
     const float *gsh = a.gn_shift ? a.gn_shift + (int64_t)b * a.gn_ld : nullptr;
-    const bool affine = gsc != nullptr, act = a.act != 0;
+    const bool fold = a.fold_gamma != nullptr;                      // GroupNorm finished here from fp64 sums (gn_fold.h)
+    const bool affine = gsc != nullptr || fold, act = a.act != 0;
     const int cps = (K / R4_KC + ksplit - 1) / ksplit;
     const int cb = ksi * cps;                                       // first chunk of this slice
     const int nchunks = (cb + cps <= K / R4_KC ? cps : K / R4_KC - cb);
@@ -207,9 +216,35 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
         V[4 * 128] = r - 2.f * s;
         V[5 * 128] = 4.f * t[1] - 5.f * t[3] + t[5];
     };
+    // the same transform on separate floats: v_fma_f32 takes the wave-uniform row coefficients from SGPRs (the packed form keeps
+    // them in eight VGPRs) and dependent packed operations need an s_nop between them
+    auto transform_s = [&](int pbuf, int vbuf, int dofs, int vofs) {
+        const f32x2 *D = reinterpret_cast<const f32x2 *>(ldsD + pbuf * R4_DT) + tbase2 + dofs;
+        float tx[6], ty[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const f32x2 d0 = D[to0 + j * R4_PITCH * 2], d1 = D[to1 + j * R4_PITCH * 2], d2 = D[to2 + j * R4_PITCH * 2], d3 = D[to3 + j * R4_PITCH * 2];
+            tx[j] = tc0 * d0[0] + tc1 * d1[0] + tc2 * d2[0] + tc3 * d3[0];
+            ty[j] = tc0 * d0[1] + tc1 * d1[1] + tc2 * d2[1] + tc3 * d3[1];
+        }
+        f32x2 *V = reinterpret_cast<f32x2 *>(ldsV + vbuf * R4_V) + ((tu * 6) * 16 + ttile) * 8 + tpair + vofs;
+        const float px = tx[4] - 4.f * tx[2], qx = tx[3] - 4.f * tx[1], rx = tx[4] - tx[2], sx = tx[3] - tx[1];
+        const float py = ty[4] - 4.f * ty[2], qy = ty[3] - 4.f * ty[1], ry = ty[4] - ty[2], sy = ty[3] - ty[1];
+        V[0 * 128] = f32x2{4.f * tx[0] - 5.f * tx[2] + tx[4], 4.f * ty[0] - 5.f * ty[2] + ty[4]};
+        V[1 * 128] = f32x2{px + qx, py + qy};
+        V[2 * 128] = f32x2{px - qx, py - qy};
+        V[3 * 128] = f32x2{rx + 2.f * sx, ry + 2.f * sy};
+        V[4 * 128] = f32x2{rx - 2.f * sx, ry - 2.f * sy};
+        V[5 * 128] = f32x2{4.f * tx[1] - 5.f * tx[3] + tx[5], 4.f * ty[1] - 5.f * ty[3] + ty[5]};
+    };
     auto transform_all = [&](int pbuf, int vbuf) {
-        transform(pbuf, vbuf, 0, 0);
-        if (two_pass) transform(pbuf, vbuf, PASS_D, PASS_V);        // wave-uniform branch
+        if (V_SCALAR_T) {
+            transform_s(pbuf, vbuf, 0, 0);
+            if (two_pass) transform_s(pbuf, vbuf, PASS_D, PASS_V);
+        } else {
+            transform(pbuf, vbuf, 0, 0);
+            if (two_pass) transform(pbuf, vbuf, PASS_D, PASS_V);    // wave-uniform branch
+        }
     };
 
     // ---- accumulators: all 36 positions x this wave's 16 channels x 16 tiles
@@ -234,10 +269,13 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     const int c1 = last >= 1 ? 1 : 0, c2 = last >= 2 ? 2 : last;
     // GroupNorm affine of the image -> LDS, requested first (one float4 per thread: K / 4 scales, K / 4 shifts, K <= 1024)
     f32x4 aff_sc = {0.f, 0.f, 0.f, 0.f}, aff_sh = {0.f, 0.f, 0.f, 0.f};
-    const bool aff_slot = (FAST || affine) && tid < K4;
+    const bool aff_slot = (FAST || affine) && tid < K4 && !fold;
+    anoddpm::FoldLoads fl;
     if (aff_slot) {
         aff_sc = bld4(rSc, (unsigned)(tid * 16), 0u);
         aff_sh = bld4(rSh, (unsigned)(tid * 16), 0u);
+    } else if (fold) {
+        fl = anoddpm::fold_affine_request(a, b, tid);                 // oldest requests of the workgroup, like the table loads above
     }
     load_patch(0);
     f32x4 praw0[R4_PJ];
@@ -247,7 +285,10 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
 #pragma unroll
     for (int g = 0; g < R4_RING; ++g) load_b(0, g, g);
     if (FAST || affine) {
-        if (aff_slot) {                                                // oldest requests: no wait for the patches behind them
+        if (fold) {
+            // scratch = the V buffers (first written by transform_all below, behind two more barriers)
+            anoddpm::fold_affine_finish(a, fl, tid, a_mode == 1 ? (H >> 1) * (W >> 1) : H * W, reinterpret_cast<double *>(ldsV), ldsAff);
+        } else if (aff_slot) {                                         // oldest requests: no wait for the patches behind them
             ldsAff[tid] = aff_sc;
             ldsAff[K4 + tid] = aff_sh;
         }
@@ -276,17 +317,46 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     //   R  (last chunk only) from position 30 on no B fragment is requested any more: the first tile's 16 residual pixels are,
     //      so that the epilogue starts with them in flight instead of waiting out an HBM round trip first
     auto step = [&](const int chunk, auto doT, auto doS, auto doL, auto doR, auto &&res_prefetch) {
-        if (decltype(doT)::value && DBG != 2) transform_all((chunk + 1) & 1, (chunk + 1) & 1);
+        if (decltype(doT)::value && DBG != 2 && !(V_DEPHASE && wave >= 4)) transform_all((chunk + 1) & 1, (chunk + 1) & 1);
         const f32x4 *V = ldsV + (chunk & 1) * R4_V + vread;
+        constexpr int PS = NPOS / 4, PL = 3 * NPOS / 4, PR = NPOS - 6;
+        if (V_PAIR) {
+            f32x4 av4[4];                                           // A fragments of two positions, the next two in flight
+            av4[0] = V[0];
+            av4[1] = V[64];
+#pragma unroll
+            for (int p = 0; p < NPOS; p += 2) {
+                if (V_DEPHASE && p == NPOS / 2 && decltype(doT)::value && wave >= 4) transform_all((chunk + 1) & 1, (chunk + 1) & 1);
+                if ((p == PS || p == PS + 1) && decltype(doS)::value) store_patch(chunk & 1, chunk + 2);
+                if ((p == PL || p == PL + 1) && decltype(doL)::value) load_patch(chunk + 3);
+                if ((p == PR || p == PR + 1) && decltype(doR)::value) res_prefetch();
+                const f32x4 a0 = av4[p % 4], a1 = av4[(p + 1) % 4];
+                if (p + 2 < NPOS) { av4[(p + 2) % 4] = V[(p + 2) * 64]; av4[(p + 3) % 4] = V[(p + 3) * 64]; }
+                const f32x4 b0 = ring[p % R4_RING], b1 = ring[(p + 1) % R4_RING];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kk], b0[kk], acc[p], 0, 0, 0);
+                    acc[p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kk], b1[kk], acc[p + 1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = p; q < p + 2; ++q) {
+                    if (q + R4_RING < NPOS)           load_b(chunk, q + R4_RING, q % R4_RING);
+                    else if (!decltype(doR)::value)   load_b(chunk + 1, q + R4_RING - NPOS, q % R4_RING);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!decltype(doR)::value) __syncthreads();
+            return;
+        }
         f32x4 av[3];                                                // A fragments: two positions ahead of the MFMAs
         av[0] = V[0];
         av[1] = V[64];
-        constexpr int PS = NPOS / 4, PL = 3 * NPOS / 4, PR = NPOS - 6;
 #pragma unroll
         for (int p = 0; p < NPOS; ++p) {
             // (round 5, measured and dropped: the two waves of a SIMD staging half a chunk apart -- S / L at positions 0 / 9 for waves
             // 4..7 -- so that they would not wait for their patch requests together: 8.99 vs 9.01 ms per step, no difference;
             // nor does a deeper B ring or a non-temporal policy on the streamed tensors help: profiles/r5_f43_phases_ablations.txt)
+            if (V_DEPHASE && p == NPOS / 2 && decltype(doT)::value && wave >= 4) transform_all((chunk + 1) & 1, (chunk + 1) & 1);
             if (p == PS && decltype(doS)::value && DBG != 3 && DBG != 11) store_patch(chunk & 1, chunk + 2);   // patch(c+2) replaces patch(c): its readers passed the last barrier
             if (p == PL && decltype(doL)::value && DBG != 3) load_patch(chunk + 3);
             if (p == PR && decltype(doR)::value) res_prefetch();
@@ -304,6 +374,7 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
         }
         if (!decltype(doR)::value) __syncthreads();                 // publishes V(c+1) and patch(c+2); retires V(c)
     };
+    if (V_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
     constexpr std::true_type YES{};
     constexpr std::false_type NO{};
     auto nothing = []() {};
@@ -398,16 +469,20 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
             }
         }
     }
-    if (a.stats && !part) {
+    if ((a.stats || a.stats_csum) && !part) {
         // the lane's 64 outputs of channel nw; the four kq lane groups hold the other tiles of the same channel
         cs += __shfl_xor(cs, 16);
         cq += __shfl_xor(cq, 16);
         cs += __shfl_xor(cs, 32);
         cq += __shfl_xor(cq, 32);
         if (kq == 0) {
-            float *st = a.stats + (((int64_t)b * gridDim.x + blockIdx.x) * N + nw) * 2;
-            st[0] = cs;
-            st[1] = cq;
+            if (a.stats_csum) {
+                anoddpm::csum_atomic_add(a.stats_csum, b, N, nw, cs, cq);     // one fp64 pair per workgroup and channel (gn_fold.h)
+            } else {
+                float *st = a.stats + (((int64_t)b * gridDim.x + blockIdx.x) * N + nw) * 2;
+                st[0] = cs;
+                st[1] = cq;
+            }
         }
     }
     if (DBG == 5 || DBG == 6) {
@@ -434,8 +509,8 @@ namespace anoddpm {
 int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
 {
     dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / 128), (unsigned)(a->B * a->ksplit));
-    const bool fast = a->gn_scale && a->act;
-    ANODDPM_REQUIRE(!a->gn_scale || a->c0 + a->c1 <= R4_KMAX, "winograd43r: GroupNorm affine table holds %d input channels", R4_KMAX);
+    const bool fast = (a->gn_scale || a->fold_gamma) && a->act;
+    ANODDPM_REQUIRE(!(a->gn_scale || a->fold_gamma) || a->c0 + a->c1 <= R4_KMAX, "winograd43r: GroupNorm affine table holds %d input channels", R4_KMAX);
 #ifdef ANODDPM_ABLATE           // timing ablations (wrong results) and ring-depth variants: measurement builds only
     const int dbg = g_debug[6];
     if (fast && dbg == 1) hipLaunchKernelGGL((wino43r_kernel<true, 1>), grid, dim3(R4_NT), 0, s, *a);
@@ -463,6 +538,15 @@ int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
     else if (fast && dbg == 8) hipLaunchKernelGGL((wino43r_kernel<true, 0, 8>), grid, dim3(R4_NT), 0, s, *a);   // (8 does not divide 36: timing only)
     else if (fast && dbg == 10) hipLaunchKernelGGL((wino43r_kernel<true, 0, 6>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 9) hipLaunchKernelGGL((wino43r_kernel<true, 0, 4>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 30) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9, 36, 1>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 31) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9, 36, 2>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 32) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9, 36, 3>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 33) hipLaunchKernelGGL((wino43r_kernel<true, 0, 6, 36, 1>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 34) hipLaunchKernelGGL((wino43r_kernel<true, 0, 6, 36, 3>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 35) hipLaunchKernelGGL((wino43r_kernel<true, 0, 6, 36, 4>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 36) hipLaunchKernelGGL((wino43r_kernel<true, 0, 6, 36, 5>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 37) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9, 36, 8>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 38) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9, 36, 9>), grid, dim3(R4_NT), 0, s, *a);
     else
 #endif
     // nine B fragments in flight (250 VGPRs) for the GroupNorm + SiLU form: 9.05 -> 9.01 ms per config-2 step over six (round 5,

@@ -871,12 +871,28 @@ class GaussianDiffusionModel:
             # sample_q at t = t_distance reads the T-entry tables: upstream's extract() raises for t_distance >= T
             raise IndexError(f"t_distance {max(lens)} is out of range for a {self.num_timesteps}-step schedule")
         if slots is None and os.environ.get("ANODDPM_DET_SLOTS"):
-            slots = int(os.environ["ANODDPM_DET_SLOTS"])
-        if slots is None:
+            try:
+                slots = int(os.environ["ANODDPM_DET_SLOTS"])
+            except ValueError:
+                slots = 0
+            if slots < 1:
+                raise ValueError(f"ANODDPM_DET_SLOTS={os.environ['ANODDPM_DET_SLOTS']!r}: expected an integer >= 1")
+        if slots is not None and int(slots) < 1:
+            raise ValueError("_run_chains: slots must be >= 1")
+        auto = slots is None
+        if auto:
             # a batched step costs about (2 + G) image-units (a batch-independent floor worth two images): take the
-            # slot count among the quantisation-free sizes whose longest-first schedule is cheapest
+            # slot count among the quantisation-free sizes whose longest-first schedule is cheapest -- and whose plan fits: a
+            # slot costs the activation buffers of one image (about 0.8 GB at 256^2 / base 128, scaled by pixels x base width;
+            # 512^2 models at batch 16 are 50 GB), so sizes that would take more than half of the free device memory are skipped
             pos = [l for l in lens if l > 0] or [1]
-            slots = min((g for g in (16, 12, 8) if g <= max(n, 8)), key=lambda g: plan_chain_slots(pos, min(g, len(pos)))[0] * (2 + min(g, len(pos))))
+            per_slot = 24.0 * 4.0 * float(getattr(model, "model_channels", 128)) * x_0.shape[-1] * x_0.shape[-2]
+            free = torch.cuda.mem_get_info(x_0.device)[0] if x_0.is_cuda else float("inf")
+            cands = [g for g in (16, 12, 8) if g <= max(n, 8) and (g == 8 or g * per_slot <= 0.5 * free)]
+            while cands[-1] > 1 and cands[-1] * per_slot > 0.5 * free:
+                cands.append(cands[-1] // 2)                             # even eight images do not fit: 4, 2, 1 slots
+            cands = [g for g in cands if g * per_slot <= 0.5 * free] or [1]
+            slots = min(cands, key=lambda g: plan_chain_slots(pos, min(g, len(pos)))[0] * (2 + min(g, len(pos))))
         G = max(1, min(int(slots), n))
         t_all = torch.tensor(lens, device=x_0.device, dtype=torch.int64)
         x_start = self.sample_q(x_0.repeat(n, 1, 1, 1), t_all, noise)
@@ -897,7 +913,30 @@ class GaussianDiffusionModel:
             harvest.setdefault(start + lens[c] - 1, []).append((slot, c))
             last_busy[slot] = max(last_busy[slot], start + lens[c])
         with torch.no_grad():
-            chain = self._chain_for(model, x_start[:1].expand(G, -1, -1, -1).contiguous(), 1, "gauss")
+            # kept slot chains of this model at OTHER slot counts are superseded (each holds a plan + captured graph: 3.4 GB per
+            # four images at config 2): drop them before the new plan is allocated (round-5 advisor finding)
+            cache = self.__dict__.get("_chains", {})
+            for key in [k for k, ch in cache.items() if getattr(ch, "slot_chain", False) and k[0] == id(model)
+                        and k[1][1:] == tuple(x_start.shape[1:]) and k[1][0] != G]:
+                cache.pop(key)
+            while True:
+                try:
+                    chain = self._chain_for(model, x_start[:1].expand(G, -1, -1, -1).contiguous(), 1, "gauss")
+                    break
+                except torch.cuda.OutOfMemoryError:
+                    if not auto or G == 1:
+                        raise
+                    G = max(1, G // 2)                                   # the estimate was too optimistic: fewer slots, new schedule
+                    torch.cuda.empty_cache()
+                    makespan, place = plan_chain_slots([lens[c] for c in live], G)
+                    self.last_chain_schedule.update(slots=G, steps=makespan, place={live[i]: place[i] for i in range(len(live))})
+                    refill, harvest, last_busy = {}, {}, [0] * G
+                    for i, (slot, start) in enumerate(place):
+                        c = live[i]
+                        refill.setdefault(start, []).append((slot, c))
+                        harvest.setdefault(start + lens[c] - 1, []).append((slot, c))
+                        last_busy[slot] = max(last_busy[slot], start + lens[c])
+            chain.slot_chain = True
             chain.remaining = makespan
             for slot in range(G):
                 if last_busy[slot] == 0:                                # fewer chains than slots cannot happen (G <= n); kept for safety

@@ -59,20 +59,52 @@ def load_checkpoint(param, use_checkpoint, device):
     `.../checkpoint/` (names sorted descending) that `torch.load` can read -- files that raise RuntimeError (truncated writes)
     are skipped.  Returns the dict `{'n_epoch', 'model_state_dict', 'optimizer_state_dict', 'ema', 'args'}` as saved
     (diffusion_training.py:169-189).  Error behaviour as upstream: a missing directory is FileNotFoundError, a checkpoint
-    directory without one readable file UnboundLocalError.  `weights_only=False`: the saved `args` entry is a
-    `defaultdict(str)` (diffusion_training.py:303), which torch >= 2.6's default safe unpickler refuses -- upstream was written
-    against the old default, and the files are the user's own checkpoints."""
+    directory without one readable file UnboundLocalError.  Files are read through a restricted unpickler (`_load_saved_dict`)."""
     root = _model_dir(param)
     if not use_checkpoint:
-        return torch.load(os.path.join(root, "params-final.pt"), map_location=device, weights_only=False)
+        return _load_saved_dict(os.path.join(root, "params-final.pt"), device)
     ckpt_dir = os.path.join(root, "checkpoint")
     for name in sorted(os.listdir(ckpt_dir), reverse=True):
         try:
-            newest_readable = torch.load(os.path.join(ckpt_dir, name), map_location=device, weights_only=False)
+            newest_readable = _load_saved_dict(os.path.join(ckpt_dir, name), device)
         except RuntimeError:
             continue
         break
     return newest_readable                                           # unbound when nothing could be read: UnboundLocalError, as upstream
+
+
+def _load_saved_dict(path, device):
+    """torch.load of a training checkpoint through a RESTRICTED unpickler (round-5 advisor finding).  torch's own weights-only
+    loader cannot rebuild the `args` entry -- a `collections.defaultdict(str)` (diffusion_training.py:303; its SETITEMS is refused
+    even when the class is allow-listed) -- so the file is read with an unpickler whose `find_class` admits exactly torch's
+    weights-only allow-list plus `collections.defaultdict` and `builtins.str`.  A pickle that names any other global is refused
+    (pickle.UnpicklingError) unless ANODDPM_UNSAFE_CHECKPOINTS=1 says the files are the user's own and the full unpickler may run."""
+    import pickle
+    import types
+    from torch._weights_only_unpickler import _get_allowed_globals
+
+    allowed = dict(_get_allowed_globals())
+    allowed.update({"collections.defaultdict": defaultdict, "builtins.str": str, "__builtin__.unicode": str, "__builtin__.str": str})   # (torch.save writes protocol 2)
+
+    class _Restricted(pickle.Unpickler):
+        def find_class(self, module, name):
+            key = f"{module}.{name}"
+            if key in allowed:
+                return allowed[key]
+            raise pickle.UnpicklingError(f"global {key} is not on the checkpoint allow-list")
+
+    shim = types.ModuleType("anoddpm_restricted_pickle")
+    shim.Unpickler = _Restricted
+    shim.load = lambda f, **kw: _Restricted(f, **kw).load()
+    shim.__dict__.update({k: getattr(pickle, k) for k in ("UnpicklingError", "PickleError", "HIGHEST_PROTOCOL", "dumps", "dump", "Pickler")})
+    try:
+        return torch.load(path, map_location=device, weights_only=False, pickle_module=shim)
+    except pickle.UnpicklingError as e:
+        if os.environ.get("ANODDPM_UNSAFE_CHECKPOINTS", "0") != "1":
+            raise pickle.UnpicklingError(f"{path}: refused by the restricted checkpoint loader ({e}); set ANODDPM_UNSAFE_CHECKPOINTS=1 "
+                                         "to unpickle it fully (arbitrary code execution: only for files you wrote yourself)") from e
+        print(f"load_checkpoint: {path} needs the full unpickler (ANODDPM_UNSAFE_CHECKPOINTS=1)")
+        return torch.load(path, map_location=device, weights_only=False)
 
 
 def _arg_number(spec):

@@ -194,16 +194,19 @@ def testing(testing_dataset_loader, diffusion, args, ema, model, test_iters=40, 
     ema.eval()
     model.eval()
 
-    def batch():
+    def batch(pairs=("cifar",)):
+        # upstream's own rule per loop: the sequence loop reads data[0] for "cifar" AND "carpet" (evaluation.py:118-120), the VLB
+        # and PSNR loops only for "cifar" (:144-149, :155-160) -- the carpet loader yields dicts, and with sequences=False or
+        # sample_distance <= 100 upstream runs on it
         data = next(testing_dataset_loader)
-        if args["dataset"] == "cifar" or args["dataset"] == "carpet":
-            return data[0].to(device)                      # [data, class] pairs (evaluation.py:118-120)
+        if args["dataset"] in pairs:
+            return data[0].to(device)                      # [data, class] pairs
         return data["image"].to(device)
 
     seq_lens = []
     if sequences:
         for i in range(100, args['sample_distance'], 100):
-            out = diffusion.forward_backward(ema, batch(), see_whole_sequence="half", t_distance=i)
+            out = diffusion.forward_backward(ema, batch(("cifar", "carpet")), see_whole_sequence="half", t_distance=i)
             seq_lens.append(len(out))
     rounds = test_iters // args["Batch_Size"] + 5
     vlb = [diffusion.calc_total_vlb(batch(), model, args) for _ in range(rounds)]

@@ -407,6 +407,9 @@ def wino23s_ok(H, W, K, N, B, *, ks, a_mode=0, b_mode=0, heads=1, c0=None):
     return lib().anoddpm_wino23s_tile(H, W, K, K if c0 is None else c0, N, B, a_mode) != 0
 
 
+F43_MAX_GN_K = 1024          # R4_KMAX / W43_KMAX of the F(4x4,3x3) kernels: input channels whose GroupNorm affine fits their LDS table
+
+
 def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None, c1=0, wino=True, f43=False, plain=False, small=False):
     """Tile configuration (0: 128x128 direct, 1: 64x64 direct, 4: streaming 1x1 for large maps, 2: Winograd F(2x2,3x3),
     3: Winograd F(4x4,3x3) -- only when the
@@ -454,6 +457,10 @@ def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None
         else:
             cps = -(-wch // wino_ksplit)
             wino_ksplit = -(-wch // cps)                   # no empty trailing block
+    # the F(4x4) kernels keep the image's GroupNorm affine in an LDS table of F43_MAX_GN_K input channels (csrc/winograd43.hip,
+    # winograd43r.hip refuse more): wider GroupNorm-fused layers -- none in the shipped configurations, max 1024 -- fall through to
+    # F(2x2) / the direct kernels (round-5 advisor finding); `plain` launches carry no affine and are not limited
+    f43 = f43 and (plain or K <= F43_MAX_GN_K)
     if (wino_ok and f43 and N % 128 == 0 and H * W == 32 * 32 and K >= 512 and os.environ.get("ANODDPM_F43_32", "0") == "1"):
         # (round 5 experiment, off: the deep 32x32 layers on the channel-sliced F(4x4) kernel with split-K -- 16 x 16-pixel tiles x
         # 128 channels x K slices of >= 4 chunks -- instead of F(2x2) + split-K)
@@ -505,8 +512,24 @@ class _Plan:
         self.stats_of = {}
         self.igemm_log = []
         self.block_out = {}      # block prefix -> (NHWC buffer [B][H*W][C], C, H): layer-wise parity tests read these
+        # Round 6: the F(4x4,3x3) layers of the INFERENCE plan accumulate their output's GroupNorm sums with fp64 atomics into
+        # [B][N][2] (anoddpm_igemm_args.stats_csum) and an F(4x4,3x3) consumer finishes the GroupNorm in its prologue (fold_*):
+        # no gn_finalize launch between two such layers.  One arena for all accumulators, cleared by the plan's first op (posemb).
+        # OPT-IN (ANODDPM_CSUM=1): measured on the config-2 step it removes 24-26 launches (227 -> 201-203) and moves the step by
+        # 0.2-0.6 % (9.05-9.09 -> 9.05-9.06 ms, 9.02-9.06 -> 8.98-9.00 on another box; profiles/r6_csum_ab.txt) -- the atomics and
+        # the fold put 2-3 us of the 4.7 us launch they remove back into the F(4x4) launches.  Off by default: statistics rows +
+        # finalize launches everywhere (what the training plan always does: its backward needs mean / rstd as tensors).
+        self.csum_mode = type(self) is _Plan and os.environ.get("ANODDPM_CSUM", "0") == "1"
+        self._csum_arena, self._csum_used = None, 0
+        if self.csum_mode:
+            cap = 2 * B * sum(p.shape[0] for p in model.parameters() if p.dim() == 4 and p.shape[-1] == 3)
+            self._csum_arena = torch.zeros(max(cap, 2), dtype=torch.float64, device=device)
+            self.keep.append(self._csum_arena)
         with torch.no_grad():
             self._build()
+        if self.csum_mode and getattr(self, "posemb", None) is not None:
+            self.posemb.zero = self._csum_arena.data_ptr() if self._csum_used else None
+            self.posemb.zero_doubles = self._csum_used
         n = len(self.ops)
         self.op_array = (Op * n)()
         for i, (code, st) in enumerate(self.ops):
@@ -630,7 +653,7 @@ class _Plan:
         other = None
         if c1:
             e1 = self.stats_of.get(srcs[1][0].data_ptr())
-            if e1 is None or e1[0] != "csum":
+            if e1 is None or e1[0] not in ("csum", "asum"):         # both hold [B][c1][2] fp64 sums, complete before this launch
                 return None
             other = e1[1]
         st = ent[2]
@@ -660,6 +683,8 @@ class _Plan:
         job = self.gn_tail_job(srcs, gamma, beta)
         if job is not None:
             return job
+        if fold == "f43" and not all(self.stats_of[s_[0].data_ptr()][0] in ("csum", "asum") for s_ in srcs):
+            fold = False                      # an F(4x4,3x3) consumer folds fp64 sums only: a rows source keeps the finalize launch
         if fold and C % 32 == 0:
             d = _GnFold()
             d.gamma, d.beta, d.groups, d.eps = gamma, beta, 32, 1e-5
@@ -680,6 +705,23 @@ class _Plan:
         st.c0, st.c1, st.P, st.B, st.groups, st.eps = c0, c1, P, B, 32, 1e-5
         self.add(_lib.OP_GN_FINALIZE, st)
         return scale, shift
+
+    def csum_take(self, n):
+        """`n` doubles of the plan's accumulator arena (cleared at the start of every forward), as a tensor view."""
+        if self._csum_used + n > self._csum_arena.numel():
+            raise _lib.AnoddpmError("plan: statistics accumulator arena exhausted")
+        v = self._csum_arena[self._csum_used:self._csum_used + n]
+        self._csum_used += n
+        return v
+
+    def f43_fold(self, H, W, K, N, *, a_mode=0, c0=None, c1=0):
+        """"f43" when a 3x3 contraction with these parameters will run on the F(4x4,3x3) kernels without split-K -- they finish a
+        GroupNorm whose sources are all fp64 sums in their prologue (gn(fold="f43")) -- else False."""
+        if not self.csum_mode or self.arith != "fp32" or a_mode not in (0, 1) or os.environ.get("ANODDPM_CSUM_NOFOLD", "0") == "1":
+            return False
+        cfg, ksplit = choose_conv_cfg(H, W, K, N, self.B, ks=3, a_mode=a_mode, c0=(K if c0 is None else c0), c1=c1,
+                                      wino=True, f43=True, plain=False, small=True)
+        return "f43" if (cfg == 3 and ksplit == 1 and K <= F43_MAX_GN_K) else False
 
     def small(self, H, W, K, N, *, ks, a_mode=0, c0=None):
         """True when the contraction with these parameters will run on cfg 5 / 6 (so its GroupNorm can be folded into it)."""
@@ -760,8 +802,8 @@ class _Plan:
         cfg, ksplit = choose_conv_cfg(H, W, K, N, Z, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads, c0=c0, c1=c1,
                                       wino=bool(wino), f43=bool(wino43),
                                       plain=(gn is None and act == 0 and not want_stats), small=True)
-        if fold is not None and cfg not in (5, 6):
-            raise _lib.AnoddpmError("plan: a folded GroupNorm needs a cfg 5 / 6 consumer")
+        if fold is not None and not (cfg in (5, 6) or (cfg == 3 and ksplit == 1 and st.fold_fmt0 == 1 and (not c1 or st.fold_fmt1 == 1))):
+            raise _lib.AnoddpmError("plan: a folded GroupNorm needs a cfg 5 / 6 consumer, or a cfg 3 one with fp64-sum sources")
         if (cfg == 3 and self.arith == "bf16split3" and ksplit == 1 and N % 128 == 0 and K % 32 == 0 and (c1 == 0 or c0 % 32 == 0)
                 and (H // 16) * (W // 16) * (N // 128) * Z >= 200):
             cfg = 7                                             # the 128-channel grids (what winograd43r.hip runs) on split-bf16 products
@@ -802,6 +844,15 @@ class _Plan:
             stats = self.buf(B, rows, N, 2)
             st.stats = stats.data_ptr()
             self.stats_of[out.data_ptr()] = ("rows", stats, rows)
+        elif (want_stats and ksplit == 1 and heads == 1 and cfg == 3 and self.csum_mode
+              and 2 * N * (H // 16) * (W // 16) * B <= int(os.environ.get("ANODDPM_CSUM_MAX_ATOMICS", 100000))):
+            # (measured, profiles/r6_csum_by_layer.txt: the chip retires about 33 of these atomics per ns, so a launch pays
+            # 2 N tiles B / 33 ns for them -- 8-15 us on the 256x256 maps of a batch of four, more than the 4.7 us finalize launch
+            # it replaces, 0.5-2 us on the 128x128 / 64x64 maps: only launches below the threshold accumulate atomically)
+            # F(4x4,3x3): per-channel sums accumulated atomically into ONE fp64 row per image (no rows to fold)
+            csum = self.csum_take(B * N * 2)
+            st.stats_csum = csum.data_ptr()
+            self.stats_of[out.data_ptr()] = ("asum", csum, None)
         elif want_stats and ksplit == 1 and heads == 1:
             # the epilogue emits per-channel {sum, sumsq} per wave-row of every pixel tile
             if cfg in (2, 3, 7):
@@ -833,8 +884,10 @@ class _Plan:
             self.stats_of[out.data_ptr()] = ("rows", stats, nslab)
         self.add(_lib.OP_IGEMM, st)
         self.igemm_log.append(dict(wino=(cfg in (2, 3, 6, 7)), f43=(cfg in (3, 7)), kind=kind, H=H, W=W, K=K, N=N, ks=ks, a_mode=a_mode, b_mode=b_mode, heads=heads,
-                                   cfg=cfg, ksplit=ksplit, dual=bool(c1), gflop=2.0 * K * N * ks * ks * P * Z / 1e9))
-        if want_stats and st.stats is None and not st.tail_csum:
+                                   cfg=cfg, ksplit=ksplit, dual=bool(c1), gflop=2.0 * K * N * ks * ks * P * Z / 1e9,
+                                   # the fused residual the epilogue reads: 0 none, 1 full resolution, 0.25 nearest-x2 source (res_mode 1)
+                                   res=(0.0 if not st.res else (0.25 if st.res_mode == 1 else 1.0))))
+        if want_stats and st.stats is None and not st.tail_csum and not st.stats_csum:
             self.chan_stats(out, N, P)
         fl = 2.0 * K * N * ks * ks * P * Z
         self.flops[kind] = self.flops.get(kind, 0.0) + fl
@@ -892,8 +945,10 @@ class _Plan:
             Hout = Hin * 2 if resample == "up" else (Hin // 2 if resample == "down" else Hin)
             Pin, Pout = Hin * Hin, Hout * Hout
             g1 = self.gn(srcs, Pin, prefix + ".in_layers.0.weight", prefix + ".in_layers.0.bias",
-                         fold=(resample in (None, "up") and self.small(Hout, Hout, cin, cout, ks=3, c0=srcs[0][1],
-                                                                      a_mode=(1 if resample == "up" else 0))))
+                         fold=(resample in (None, "up") and (self.small(Hout, Hout, cin, cout, ks=3, c0=srcs[0][1],
+                                                                        a_mode=(1 if resample == "up" else 0)) or
+                                                             self.f43_fold(Hout, Hout, cin, cout, a_mode=(1 if resample == "up" else 0),
+                                                                           c0=srcs[0][1], c1=cin - srcs[0][1]))))
             h1 = self.buf(B, Pout, cout)
             pooled = None
             if resample == "down" and len(srcs) == 1 and os.environ.get("ANODDPM_NO_POOL_ACT", "0") != "1":
@@ -915,7 +970,7 @@ class _Plan:
                        bias=self.packed(prefix + ".in_layers.2.bias", "copy"),
                        temb=emb_all.data_ptr() + 4 * offs[prefix], temb_ld=tot, out=h1, want_stats=True)
             g2 = self.gn([(h1, cout)], Pout, prefix + ".out_layers.0.weight", prefix + ".out_layers.0.bias",
-                         fold=self.small(Hout, Hout, cout, cout, ks=3))
+                         fold=(self.small(Hout, Hout, cout, cout, ks=3) or self.f43_fold(Hout, Hout, cout, cout)))
             if cin != cout:
                 sk = self.buf(B, Pout, cout)
                 assert resample is None

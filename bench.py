@@ -61,6 +61,8 @@ CONFIGS = {
 T_STEPS = 1000
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_FP64_VECTOR_TFLOPS = 78.6        # MI355X_MICROARCH.md: fp64 vector (FMA = 2 flop)
+BOOST_CLOCK_GHZ = 2.4                 # the clock the peak figures are quoted at
+SUSTAINED_CLOCK_GHZ = 2.28            # GRBM_GUI_ACTIVE / duration of the F(4x4) kernels in the committed counter pass
 SIMPLEX_FP64_FLOP_PER_EVAL = 200.0    # fp64 operations of one 3-D OpenSimplex evaluation
 
 
@@ -130,6 +132,29 @@ def tree_hash():
     for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+# The sources that decide the byte traffic of ONE kernel class (its kernels, the headers they include, the plan that picks
+# shapes and configurations).  A committed traffic file is stale for a class only when THESE changed: round 5's driver line carried
+# `stale: true` because measurement-only edits of other kernels had moved the whole-tree hash.
+CLASS_SOURCES = {
+    "f43": ["csrc/winograd43.hip", "csrc/winograd43r.hip"],
+    "f23": ["csrc/winograd.hip", "csrc/wino23s.hip"],
+    "igemm": ["csrc/igemm.hip", "csrc/pointwise.hip"],
+    "smallmap": ["csrc/smallmap.hip"],
+    "attention": ["csrc/attention.hip"],
+}
+CLASS_COMMON = ["csrc/common.h", "csrc/pack_items.h", "unet.py"]
+
+
+def class_hash(cls):
+    import hashlib
+    h = hashlib.sha1()
+    for rel in CLASS_SOURCES[cls] + CLASS_COMMON:
+        h.update(rel.encode())
+        with open(os.path.join(ROOT, "anoddpm_amd", rel), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
 
@@ -288,7 +313,7 @@ def timed(c, args, step_fn):
     return elapsed
 
 
-def committed_traffic(config_name, batch, kernel_prefixes):
+def committed_traffic(config_name, batch, kernel_prefixes, cls=None):
     """HBM-side bytes per launch of a kernel class from the committed PMC passes (profiles/r*_traffic_<config>.json, written by
     tools/traffic_from_pmc.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench command, corrected with
     the calibration of tools/hbm_calib.hip).  PMC counters cannot be read from inside the process, so the bench line carries the
@@ -313,13 +338,17 @@ def committed_traffic(config_name, batch, kernel_prefixes):
             w += v["write_bytes_per_launch"] * v["launches"]
     if n == 0:
         return None
-    now = tree_hash()
+    # stale = measured on other sources than the ones running now (kernels / plans changed since the PMC passes): the byte counts
+    # are of that tree, the timings beside them of this one.  Compared per kernel class when the file carries class hashes
+    # (round 6 on), over the whole tree otherwise.
+    if cls is not None and cls in d.get("class_hashes", {}):
+        was, now = d["class_hashes"][cls], class_hash(cls)
+    else:
+        was, now = d.get("sources_hash"), tree_hash()
     return {"bytes_per_launch": (f + w) / n, "fetch_bytes_per_launch": f / n, "write_bytes_per_launch": w / n,
             "source": os.path.relpath(path, ROOT), "fetch_factor": d["calibration"]["fetch_factor"],
             "write_factor": d["calibration"]["write_factor"], "tree": d.get("tree"),
-            # measured on another tree than the one running now (kernels / plans changed since the PMC passes): byte counts are
-            # of that tree, the timings beside them of this one
-            "measured_on_sources": d.get("sources_hash"), "running_sources": now, "stale": d.get("sources_hash") != now}
+            "measured_on_sources": was, "running_sources": now, "stale": was != now}
 
 
 def per_op_profile(L, plan, steps):
@@ -396,6 +425,75 @@ def hbm_kernel_rows(plan, B, ms, cnt, steps, extra=()):
     return rows
 
 
+def contraction_roofline(plan, ms, cnt, steps, prof_ms_per_step):
+    """`roofline` object of a reverse step from the executor's HIP-event totals (`ms`, `cnt` per profiler slot over `steps`
+    instrumented steps of `plan`): the dominant contraction class against the fp32 matrix peak, the other classes, the per-class
+    time table.  Returns (roofline, classes, dominant class name)."""
+    from anoddpm_amd import _lib
+
+    # contraction classes: profiler slot, launches of the plan, fraction of the direct-convolution FLOPs the matrix pipe executes
+    classes = {
+        "wino43_kernel (Winograd F(4x4,3x3) 3x3 convolutions on maps >= 64x64, v_mfma_f32_16x16x4_f32)":
+            (14, [e for e in plan.igemm_log if e.get("f43")], 36.0 / (16 * 9)),
+        "wino_kernel (Winograd F(2x2,3x3) 3x3 convolutions, v_mfma_f32_32x32x2_f32)":
+            (12, [e for e in plan.igemm_log if e["wino"] and not e.get("f43")], 4.0 / 9.0),
+        "igemm_kernel / pointwise_stream_kernel (direct implicit GEMM with 64x64 / 128x128 tiles, streaming 1x1; v_mfma_f32_32x32x2_f32)":
+            (_lib.OP_IGEMM, [e for e in plan.igemm_log if not e["wino"] and e["cfg"] != 5], 1.0),
+        "smallmap_kernel (maps <= 16x16 without split-K: 8x8 3x3, 1x1, qkv / proj, GroupNorm finalize in the prologue; v_mfma_f32_16x16x4_f32)":
+            (13, [e for e in plan.igemm_log if e["cfg"] == 5], 1.0),
+        "attention_kernel (fused QK^T - softmax - AV per attention block, v_mfma_f32_16x16x4_f32)":
+            (_lib.OP_ATTENTION, getattr(plan, "attention_log", []), 1.0),
+    }
+    flops_per_step = plan.igemm_flops
+
+    def tf(flops, msec):
+        return flops * steps / (msec / 1000.0) / 1e12 if msec > 0 else 0.0
+    rows = {}
+    for name, (slot, entries, frac_exec) in classes.items():
+        fl = sum(e["gflop"] for e in entries) * 1e9
+        rows[name] = dict(ms=ms[slot], n=cnt[slot], alg=fl, exe=fl * frac_exec)
+    # dominant kernel = the class with the most time.  `achieved` / `frac` price the FLOPs the matrix pipe EXECUTES
+    # (Winograd issues 4/9 resp. 1/4 of the direct-convolution count), so frac <= 1 is a pipe utilisation; the
+    # algorithmic (direct-convolution) rate of the same launches is a side field.
+    dom = max(rows, key=lambda k: rows[k]["ms"])
+    d = rows[dom]
+    nl = d["n"] / steps
+    ig_ms = sum(r["ms"] for r in rows.values())
+    roofline = {"bound": "mfma", "kernel": dom,
+                "achieved": tf(d["exe"], d["ms"]), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf(d["exe"], d["ms"]) / PEAK_FP32_MATRIX_TFLOPS,
+                "achieved_is": "FLOPs the matrix pipe executes for the kernel's launches (Winograd F(4x4,3x3): 1/4, F(2x2,3x3): 4/9 of the "
+                               "direct-convolution count) / their HIP-event time",
+                "algorithmic_tflops": tf(d["alg"], d["ms"]),
+                # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this
+                # is the committed measurement of the same command (profiles/, corrected by the calibrated FETCH_SIZE factor)
+                "traffic": None,
+                "launches_per_step": nl,
+                "avg_launch_ms": d["ms"] / max(d["n"], 1),
+                "ms_per_step": d["ms"] / steps,
+                "algorithmic_gflop_per_launch": d["alg"] / 1e9 / max(nl, 1),
+                "executed_gflop_per_launch": d["exe"] / 1e9 / max(nl, 1),
+                "share_of_model_flops": d["alg"] / max(flops_per_step, 1.0),
+                "other_contraction_kernels": [{"kernel": k, "achieved": tf(r["exe"], r["ms"]), "algorithmic_tflops": tf(r["alg"], r["ms"]),
+                                               "launches_per_step": r["n"] / steps, "ms_per_step": r["ms"] / steps}
+                                              for k, r in rows.items() if k != dom and r["n"]],
+                "all_contractions": {"executed_tflops": tf(sum(r["exe"] for r in rows.values()), ig_ms),
+                                     "algorithmic_tflops": tf(flops_per_step, ig_ms),
+                                     "ms_per_step": ig_ms / steps, "algorithmic_gflop_per_step": flops_per_step / 1e9},
+                "class_ms_per_step": {name: ms[code] / steps for name, code in
+                                      (("winograd_f43", 14), ("winograd_f23", 12), ("igemm_direct", 1), ("smallmap", 13), ("gn_stats", 2), ("softmax", 3), ("resample", 4),
+                                       ("linear", 5), ("posemb", 6), ("stem", 7), ("layout", 8), ("chan_stats", 9),
+                                       ("gn_finalize", 10), ("head", 11), ("attention", 26))},
+                "instrumented_ms_per_step": prof_ms_per_step}
+    # the contract figure prices the pipe at its 2.4 GHz boost clock; under this kernel mix the chip holds the clock the committed
+    # GRBM_GUI_ACTIVE pass shows (profiles/r5_c2_sq_by_kernel.csv: 2.28 GHz for the F(4x4) class; tools/mfma_ubench.hip probes 2.1 GHz
+    # at full matrix load) -- the same achieved rate against that ceiling, for reference
+    roofline["peak_at_sustained_clock"] = {"clock_GHz": SUSTAINED_CLOCK_GHZ, "peak": PEAK_FP32_MATRIX_TFLOPS * SUSTAINED_CLOCK_GHZ / BOOST_CLOCK_GHZ,
+                                           "frac": roofline["achieved"] / (PEAK_FP32_MATRIX_TFLOPS * SUSTAINED_CLOCK_GHZ / BOOST_CLOCK_GHZ),
+                                           "source": "GRBM_GUI_ACTIVE / kernel duration of the committed SQ counter pass (profiles/)"}
+    return roofline, classes, dom
+
+
 def run_reverse(c, args, cfg):
     import GaussianDiffusion as GD
     from UNet import UNetModel
@@ -447,68 +545,18 @@ def run_reverse(c, args, cfg):
         per_op_us = per_op_profile(L, plan, args.steps)
         pu_ms_tot, pu_n, _ = pu_t.finish()
         sx_ms_tot, sx_n, _ = sx_t.finish()
-        # contraction classes: profiler slot, launches of the plan, fraction of the direct-convolution FLOPs the matrix pipe executes
-        classes = {
-            "wino43_kernel (Winograd F(4x4,3x3) 3x3 convolutions on maps >= 64x64, v_mfma_f32_16x16x4_f32)":
-                (14, [e for e in plan.igemm_log if e.get("f43")], 36.0 / (16 * 9)),
-            "wino_kernel (Winograd F(2x2,3x3) 3x3 convolutions, v_mfma_f32_32x32x2_f32)":
-                (12, [e for e in plan.igemm_log if e["wino"] and not e.get("f43")], 4.0 / 9.0),
-            "igemm_kernel / pointwise_stream_kernel (direct implicit GEMM with 64x64 / 128x128 tiles, streaming 1x1; v_mfma_f32_32x32x2_f32)":
-                (_lib.OP_IGEMM, [e for e in plan.igemm_log if not e["wino"] and e["cfg"] != 5], 1.0),
-            "smallmap_kernel (maps <= 16x16 without split-K: 8x8 3x3, 1x1, qkv / proj, GroupNorm finalize in the prologue; v_mfma_f32_16x16x4_f32)":
-                (13, [e for e in plan.igemm_log if e["cfg"] == 5], 1.0),
-            "attention_kernel (fused QK^T - softmax - AV per attention block, v_mfma_f32_16x16x4_f32)":
-                (_lib.OP_ATTENTION, getattr(plan, "attention_log", []), 1.0),
-        }
-        flops_per_step = plan.igemm_flops
-
-        def tf(flops, msec):
-            return flops * args.steps / (msec / 1000.0) / 1e12 if msec > 0 else 0.0
-        rows = {}
-        for name, (slot, entries, frac_exec) in classes.items():
-            fl = sum(e["gflop"] for e in entries) * 1e9
-            rows[name] = dict(ms=ms[slot], n=cnt[slot], alg=fl, exe=fl * frac_exec)
-        # dominant kernel = the class with the most time.  `achieved` / `frac` price the FLOPs the matrix pipe EXECUTES
-        # (Winograd issues 4/9 resp. 1/4 of the direct-convolution count), so frac <= 1 is a pipe utilisation; the
-        # algorithmic (direct-convolution) rate of the same launches is a side field.
-        dom = max(rows, key=lambda k: rows[k]["ms"])
-        d = rows[dom]
-        nl = d["n"] / args.steps
-        ig_ms = sum(r["ms"] for r in rows.values())
-        roofline = {"bound": "mfma", "kernel": dom,
-                    "achieved": tf(d["exe"], d["ms"]), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf(d["exe"], d["ms"]) / PEAK_FP32_MATRIX_TFLOPS,
-                    "achieved_is": "FLOPs the matrix pipe executes for the kernel's launches (Winograd F(4x4,3x3): 1/4, F(2x2,3x3): 4/9 of the "
-                                   "direct-convolution count) / their HIP-event time",
-                    "algorithmic_tflops": tf(d["alg"], d["ms"]),
-                    # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this
-                    # is the committed measurement of the same command (profiles/, corrected by the calibrated FETCH_SIZE factor)
-                    "traffic": None,
-                    "launches_per_step": nl,
-                    "avg_launch_ms": d["ms"] / max(d["n"], 1),
-                    "ms_per_step": d["ms"] / args.steps,
-                    "algorithmic_gflop_per_launch": d["alg"] / 1e9 / max(nl, 1),
-                    "executed_gflop_per_launch": d["exe"] / 1e9 / max(nl, 1),
-                    "share_of_model_flops": d["alg"] / max(flops_per_step, 1.0),
-                    "other_contraction_kernels": [{"kernel": k, "achieved": tf(r["exe"], r["ms"]), "algorithmic_tflops": tf(r["alg"], r["ms"]),
-                                                   "launches_per_step": r["n"] / args.steps, "ms_per_step": r["ms"] / args.steps}
-                                                  for k, r in rows.items() if k != dom and r["n"]],
-                    "all_contractions": {"executed_tflops": tf(sum(r["exe"] for r in rows.values()), ig_ms),
-                                         "algorithmic_tflops": tf(flops_per_step, ig_ms),
-                                         "ms_per_step": ig_ms / args.steps, "algorithmic_gflop_per_step": flops_per_step / 1e9},
-                    "class_ms_per_step": {name: ms[code] / args.steps for name, code in
-                                          (("winograd_f43", 14), ("winograd_f23", 12), ("igemm_direct", 1), ("smallmap", 13), ("gn_stats", 2), ("softmax", 3), ("resample", 4),
-                                           ("linear", 5), ("posemb", 6), ("stem", 7), ("layout", 8), ("chan_stats", 9),
-                                           ("gn_finalize", 10), ("head", 11), ("attention", 26))},
-                    "instrumented_ms_per_step": prof_ms_per_step}
+        roofline, classes, dom = contraction_roofline(plan, ms, cnt, args.steps, prof_ms_per_step)
         prefix = {14: ["wino43_kernel", "wino43r_kernel"], 12: ["wino_kernel"], _lib.OP_IGEMM: ["igemm_kernel", "pointwise_stream_kernel"], 13: ["smallmap_kernel"],
                   _lib.OP_ATTENTION: ["attention_kernel"]}[classes[dom][0]]
-        tr = committed_traffic(args.config, B, prefix)
+        cls = {14: "f43", 12: "f23", _lib.OP_IGEMM: "igemm", 13: "smallmap", _lib.OP_ATTENTION: "attention"}[classes[dom][0]]
+        tr = committed_traffic(args.config, B, prefix, cls)
         if tr is not None:
-            # algorithmic bytes of the same launches: operand read once + output written once + the layer's packed weights once
+            # algorithmic bytes of the same launches: operand read once + the fused residual read once (full or quarter
+            # resolution; part of the layer the kernel computes) + output written once + the layer's packed
+            # weights once
             ent = classes[dom][1]
             wmul = {14: 36.0, 12: 16.0}.get(classes[dom][0], None)
-            alg = sum(4.0 * B * e["H"] * e["W"] * (e["K"] * (0.25 if e.get("a_mode") == 1 else 1.0) + e["N"])
+            alg = sum(4.0 * B * e["H"] * e["W"] * (e["K"] * (0.25 if e.get("a_mode") == 1 else 1.0) + e["N"] * (1.0 + e.get("res", 0.0)))
                       + 4.0 * e["K"] * e["N"] * (wmul if wmul else e["ks"] * e["ks"]) for e in ent) / max(len(ent), 1)
             roofline["traffic"] = tr["bytes_per_launch"]
             roofline["traffic_detail"] = dict(tr, algorithmic_bytes_per_launch=alg, ratio_to_algorithmic=tr["bytes_per_launch"] / alg,
@@ -739,6 +787,9 @@ def run_simplex(c, args, cfg):
         ach = evals * SIMPLEX_FP64_FLOP_PER_EVAL / (k_ms / 1000.0) / 1e12
         roofline = {"bound": "fp64-alu", "kernel": "simplex3_octaves_kernel<double> (lattice hash in LDS, octaves accumulated in registers)",
                     "achieved": ach, "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP64_VECTOR_TFLOPS,
+                    # bit-exactness with the reference forbids contraction (-ffp-contract=off: every multiply and add is its own
+                    # instruction), so the ceiling this kernel can reach is the fp64 vector rate WITHOUT fma, half the quoted peak
+                    "peak_no_fma": PEAK_FP64_VECTOR_TFLOPS / 2, "frac_of_peak_no_fma": ach / (PEAK_FP64_VECTOR_TFLOPS / 2),
                     "traffic": None, "avg_launch_ms": k_ms, "launches_per_step": 1,
                     "evaluations_per_launch": evals, "fp64_flop_per_evaluation": SIMPLEX_FP64_FLOP_PER_EVAL,
                     "Gevals_per_s": evals / k_ms / 1e6,
@@ -788,10 +839,42 @@ def run_detect(c, args, cfg):
                       "slot_utilisation": chain_steps / (sched["slots"] * sched["steps"]),
                       "ms_per_image": ms_per_step, "ms_per_chain_step": ms_per_step / chain_steps,
                       "ms_per_batched_step": ms_per_step / sched["steps"],
-                      "round4_ms_per_chain_step": 13.36 / 5,
+                      # metric_version 2 (round 5 on): a step is one image's WHOLE sweep and value = chain-steps / s; version 1
+                      # (rounds 3-4) timed one setting's batch-of-total_avg chain -- the two are not comparable line to line
+                      "metric_version": 2,
                       "parallelism": f"images x{c.world} (one image's sweep per rank, no collective)",
                       "output_finite": bool(all(torch.isfinite(r["mse"]).all().item() for r in diff.last_detection))}}
-    return out, None, (lambda: {"value": None, "note": "see config c2: the per-step CPU baseline is the same reverse step"})
+    # ---- roofline leg: what a batched step of the sweep is made of -- `slots` images through the same plan the sweep ran
+    # (per-slot timesteps spread like a running sweep's), one HIP-event pair per op, five instrumented steps
+    roofline = None
+    if not args.no_prof:
+        from anoddpm_amd import _lib
+        L = _lib.lib()
+        G = sched["slots"]
+        xs = mri_like(G, cfg["img"], c.dev, seed=77 + c.rank)
+        chain = diff.reverse_chain(model, xs, T_STEPS, "gauss")
+        chain.t.copy_(torch.linspace(T_STEPS - 1, 60, G, device=c.dev).long())
+        for _ in range(2):
+            chain.step()
+        nsteps = 5
+        L.anoddpm_prof_enable(1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(nsteps):
+            chain.step()
+        torch.cuda.synchronize()
+        prof_ms = 1000.0 * (time.perf_counter() - t1) / nsteps
+        ms = (ctypes.c_double * _lib.OP_MAX)()
+        cnt = (ctypes.c_int64 * _lib.OP_MAX)()
+        _lib.check(L.anoddpm_prof_collect(ms, cnt), "prof_collect")
+        L.anoddpm_prof_enable(0)
+        plan = model._plan_for(G, cfg["img"], c.dev)
+        roofline, _, _ = contraction_roofline(plan, ms, cnt, nsteps, prof_ms)
+        roofline["batch"] = G
+        roofline["note"] = (f"one batched step of the sweep = {G} chain slots through the UNet plan + update; HIP-event pairs over {nsteps} "
+                            "instrumented steps after the timed sweep")
+        roofline["ms_per_image_step_instrumented"] = sum(roofline["class_ms_per_step"].values()) / G
+    return out, roofline, (lambda: {"value": None, "note": "see config c2: the per-step CPU baseline is the same reverse step"})
 
 
 def main():

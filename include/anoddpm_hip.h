@@ -228,7 +228,7 @@ typedef struct {
     float *tail_mean, *tail_rstd;   /* optional [B][tail_groups] (training) */
     int32_t tail_c1, tail_groups;
     float tail_eps;
-    /* cfg 5 / 6 only (smallmap.hip, wino23s.hip): the GroupNorm of the A operand FINISHED IN THE KERNEL'S PROLOGUE from its producers' statistics
+    /* cfg 5 / 6 (smallmap.hip, wino23s.hip), and cfg 3 with fp64 sums (fold_fmt* == 1, see stats_csum): the GroupNorm of the A operand FINISHED IN THE KERNEL'S PROLOGUE from its producers' statistics
      * (UNet.py:409-411 over torch.cat([h, skip], 1)) -- the arguments of anoddpm_gn_finalize, consumed in place: no finalize
      * launch between producer and consumer.  With fold_gamma set, gn_scale / gn_shift are ignored.  fp64 fold in a fixed order
      * (rows ascending per channel, channels ascending per group), biased variance, fold_eps. */
@@ -241,6 +241,14 @@ typedef struct {
      * `x_upd = Upsample(x)` skip path of an up-sampling ResBlock, UNet.py:196-198, 89: F.interpolate(scale_factor=2, mode="nearest")
      * is never materialised); res: [B][(H/2)*(W/2)][res_ld], r_bs its batch stride.  0: res has the output's resolution. */
     int32_t res_mode;
+    /* cfg 3 only, ksplit == 1, heads == 1, `stats` NULL (round 6): per-channel {sum, sum of squares} of the OUTPUT, added to
+     * [B][N][2] fp64 with device-scope atomic adds, one pair per workgroup and channel (fp32 sums over the workgroup's 256 pixels,
+     * as the `stats` rows hold them).  The buffer must be ZERO before the launch (anoddpm_posemb_args.zero clears a whole plan's
+     * buffers at the start of a forward).  It is the fmt-1 statistics source of anoddpm_gn_finalize / fold_*: a cfg 3 consumer
+     * finishes the GroupNorm in its prologue from it (fold_* with fold_fmt0 = fold_fmt1 = 1 -- the only formats cfg 3 folds),
+     * so that no finalize launch sits between two F(4x4,3x3) layers.  fp64 sums of fp32 partials: the order of the atomic adds
+     * changes the result by at most an ulp of the double. */
+    double *stats_csum;
 } anoddpm_igemm_args;
 
 int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream);
@@ -381,6 +389,10 @@ typedef struct {
     float *out;                     /* [B][dim] */
     int32_t B, dim;
     float scale;
+    /* optional (round 6): `zero_doubles` doubles at `zero` are cleared by the same launch -- the statistics accumulators
+     * (anoddpm_igemm_args.stats_csum) of a whole forward plan, whose first op this is */
+    double *zero;
+    int64_t zero_doubles;
 } anoddpm_posemb_args;
 
 int anoddpm_posemb(const anoddpm_posemb_args *a, void *stream);

@@ -108,7 +108,7 @@ _LAST_KEEP = None
 
 
 def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=None, res=None, cfg=0, ksplit=1,
-               stats_out=None, gn_tail=None, fold=None, res_up=False):
+               stats_out=None, gn_tail=None, fold=None, res_up=False, csum_out=None):
     """srcs: NHWC sources; w: OIHW weights.  Returns NHWC [B,Hout,Hout,N].  res_up: `res` is [B,Hout/2,Hout/2,N] and is repeated
     2x2 on the read (cfg 3, res_mode 1)."""
     dev = srcs[0].device
@@ -154,6 +154,13 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
         if c1:
             (s1, f1) = fold["stats"][1]
             st.fold_stats1, st.fold_rows1, st.fold_fmt1 = s1.data_ptr(), (1 if f1 else s1.shape[1]), f1
+    if csum_out is not None:
+        # cfg 3: per-channel fp64 {sum, sum of squares} of the output accumulated atomically (anoddpm_igemm_args.stats_csum); the
+        # caller passes a ZEROED [B, N, 2] float64 tensor (or a list to receive a fresh one)
+        if isinstance(csum_out, list):
+            csum_out.append(torch.zeros(B, N, 2, dtype=torch.float64, device=dev))
+            csum_out = csum_out[-1]
+        st.stats_csum = csum_out.data_ptr()
     if cfg in (5, 6) and stats_out is not None:
         tm = 64 if cfg == 6 else 16 * (lib().anoddpm_smallmap_tile(ks, Hout, Hout, c0 + c1, c0, N, B) >> 4)
         stats = torch.full((B, P // tm, N, 2), float("nan"), device=dev)

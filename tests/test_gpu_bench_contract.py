@@ -81,6 +81,13 @@ def test_bench_line_detection_sweep():
     assert cf["chains_per_setting"] == 5 and cf["settings"] == [50, 100] and cf["chains"] == 10 and cf["chain_steps_per_image"] == 750
     assert cf["slots"] * cf["batched_steps_per_image"] >= 750 and 0 < cf["slot_utilisation"] <= 1
     assert abs(d["value"] - 750 / (d["ms_per_step"] / 1000.0)) < 1e-6 * d["value"]
+    # round 6: the line says what a batched step of the sweep is made of (the plan at batch = slots): class table + the dominant
+    # contraction class against the fp32 matrix peak
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["batch"] == cf["slots"] and 0 < r["frac"] <= 1.0 and cf["metric_version"] == 2
+    assert r["class_ms_per_step"]["winograd_f43"] > 0 and "peak_at_sustained_clock" in r
+    d = run_bench("--config", "c4", "--no-cpu-baseline", "--steps", "3", "--warmup", "1")
+    assert abs(d["roofline"]["peak_no_fma"] - d["roofline"]["peak"] / 2) < 1e-9 and 0 < d["roofline"]["frac_of_peak_no_fma"] <= 1.0
 
 
 def test_bench_under_torchrun_one_rank_uses_rccl():

@@ -470,6 +470,59 @@ def test_winograd_f43_conv(case, f43_variant):
     assert torch.allclose(tot[..., 1], (o * o).sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("case", [
+    # B, (c0, c1), Cout, Hout, a_mode
+    (2, (64, 0), 128, 32, 0),          # one source, 2 channels per group... K = 64: cpg 2 (a thread's four channels span two groups)
+    (4, (128, 0), 128, 64, 0),         # the 64-channel grid (128 workgroups would not fill the chip): 16 workgroups add to every pair
+    (2, (256, 128), 128, 32, 0),       # virtual concat, 12 channels per group: a group straddles the two sources
+    (1, (128, 0), 128, 32, 1),         # nearest x2 operand: the statistics are those of the half-resolution source
+    (3, (96, 32), 256, 48, 0),         # concat with a narrow second source, three images, two channel blocks
+])
+def test_winograd_f43_groupnorm_from_atomic_sums(case, f43_variant):
+    """Round 6: two F(4x4,3x3) layers with NO finalize launch between them.  The producer adds its output's per-channel
+    {sum, sum of squares} to a zeroed [B][N][2] fp64 buffer with device-scope atomics (anoddpm_igemm_args.stats_csum -- every
+    workgroup of every XCD must be counted); the consumer finishes nn.GroupNorm(32, C) (UNet.py:409-411) in its prologue from those
+    sums (fold_* with fmt 1) and must give what the same launch gives with the affine from anoddpm_gn_finalize, and what fp64
+    group_norm -> SiLU -> conv2d gives."""
+    import hipops
+    B, (c0, c1), N, Hout, a_mode = case
+    C = c0 + c1
+    Hin = Hout if a_mode == 0 else Hout // 2
+    d = dev()
+    # producers: one F(4x4) launch per source (16 input channels are enough), output = the consumer's operand
+    prod, sums = [], []
+    for i, c in enumerate([c0] + ([c1] if c1 else [])):
+        if c % 64:                                          # not an F(4x4) width: sums from a reduction instead (tail_csum format)
+            t = hipops.nhwc(rnd(B, c, Hin, Hin, seed=300 + i).to(d))
+            prod.append(t)
+            td = t.double()
+            sums.append(torch.stack([td.sum(dim=(1, 2)), (td * td).sum(dim=(1, 2))], dim=-1).contiguous())
+            continue
+        xin = hipops.nhwc(rnd(B, 16, Hin, Hin, seed=310 + i).to(d))
+        wp = rnd(c, 16, 3, 3, seed=320 + i, scale=1.0 / 12).to(d)
+        got_sums = []
+        y = hipops.conv_igemm([xin], wp, rnd(c, seed=330 + i, scale=0.3).to(d), Hout=Hin, ks=3, cfg=3, csum_out=got_sums)
+        prod.append(y)
+        sums.append(got_sums[0])
+        yd = y.double()
+        want = torch.stack([yd.sum(dim=(1, 2)), (yd * yd).sum(dim=(1, 2))], dim=-1)
+        assert torch.allclose(got_sums[0], want, rtol=2e-5, atol=2e-3), float((got_sums[0] - want).abs().max())
+    gamma, beta = (1 + 0.1 * rnd(C, seed=94)).to(d), (0.1 * rnd(C, seed=95)).to(d)
+    w = rnd(N, C, 3, 3, seed=92, scale=1.0 / math.sqrt(C * 9)).to(d)
+    b = rnd(N, seed=93, scale=0.1).to(d)
+    fold = dict(stats=[(s_, 1) for s_ in sums], gamma=gamma, beta=beta)
+    got = hipops.conv_igemm(prod, w, b, Hout=Hout, ks=3, act=1, a_mode=a_mode, cfg=3, fold=fold)
+    gn = hipops.gn_affine(prod, gamma, beta)
+    base = hipops.conv_igemm(prod, w, b, Hout=Hout, ks=3, gn=gn, act=1, a_mode=a_mode, cfg=3)
+    assert relerr(got, base) < 1e-5, relerr(got, base)                 # same kernel, affine from the two GroupNorm routes
+    x = torch.cat([hipops.nchw(t) for t in prod], dim=1).double().cpu()
+    hh = F.silu(F.group_norm(x, 32, gamma.double().cpu(), beta.double().cpu(), eps=1e-5))
+    if a_mode == 1:
+        hh = F.interpolate(hh, scale_factor=2, mode="nearest")
+    ref = F.conv2d(hh, w.double().cpu(), b.double().cpu(), padding=1)
+    assert relerr(hipops.nchw(got).cpu(), ref.float()) < 1e-4
+
+
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_winograd_conv(case):
     """cfg = 2: Winograd F(2x2,3x3) on the matrix pipe must equal the direct 3x3 convolution (fp32; the

@@ -186,6 +186,30 @@ def test_config2_batch_equals_single_image_forwards(B):
     assert ((yb - y1).abs().max() / y1.abs().max()).item() < 2e-5
 
 
+def test_config2_with_atomic_groupnorm_sums_matches_reference(monkeypatch):
+    """ANODDPM_CSUM=1 (round 6, opt-in: measured +-0 on the step): the 128x128 / 64x64 F(4x4,3x3) layers accumulate
+    their GroupNorm sums with fp64 atomics and their F(4x4,3x3) consumers finish the GroupNorm in the prologue -- 24 gn_finalize
+    launches fewer per forward.  Same reference fixture, same bound as the default plan; and the accumulators are cleared by every
+    forward (a second call gives the same output)."""
+    monkeypatch.setenv("ANODDPM_CSUM", "1")
+    from anoddpm_amd import _lib
+    name = "c2_256_b128"
+    g = np.load(os.path.join(GOLDEN, f"unet_{name}_batch4.npz"))
+    m, sd, kw = build(name)
+    x, t = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["t"]).to(DEV)
+    with torch.no_grad():
+        y = m(x, t)
+        y2 = m(x, t)
+    plan = next(iter(m._plans.values()))
+    assert plan.csum_mode and plan._csum_used > 0
+    nfin = sum(1 for code, _ in plan.ops if code == _lib.OP_GN_FINALIZE)
+    nfold = sum(1 for code, st in plan.ops if code == _lib.OP_IGEMM and st.cfg == 3 and st.fold_gamma)
+    assert nfold >= 20 and nfin <= 35, (nfold, nfin)
+    ref = torch.from_numpy(g["y"])
+    assert ((y.cpu() - ref).abs().max() / ref.abs().max()).item() < 5e-5
+    assert ((y2 - y).abs().max() / y.abs().max()).item() < 1e-6        # (fp64 atomics: equal up to the order of the adds)
+
+
 def test_packed_weights_are_not_repacked_every_forward():
     """Regression: packed buffers once aliased fp32 parameters, so every forward bumped the parameters' version
     counters and re-packed all weights."""

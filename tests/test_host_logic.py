@@ -174,6 +174,24 @@ def test_helpers_surface(tmp_path):
         sys.argv = ["detection.py", "bogus"]
         with pytest.raises(ValueError):
             HP.load_parameters("cpu")
+        # round-5 advisor finding: the safe (weights-only) unpickler is what reads checkpoints; a pickle that names other
+        # globals is refused unless the user opts in for their own files
+        import pickle
+
+        class Foreign:
+            pass
+        import __main__
+        __main__.Foreign = Foreign
+        Foreign.__module__, Foreign.__qualname__ = "__main__", "Foreign"
+        torch.save(dict(ck, extra=Foreign()), "model/diff-params-ARGS=28/params-final.pt")
+        with pytest.raises(pickle.UnpicklingError):
+            HP.load_checkpoint("28", False, "cpu")
+        os.environ["ANODDPM_UNSAFE_CHECKPOINTS"] = "1"
+        try:
+            assert HP.load_checkpoint("28", False, "cpu")["n_epoch"] == 3
+        finally:
+            del os.environ["ANODDPM_UNSAFE_CHECKPOINTS"]
+            del __main__.Foreign
     finally:
         os.chdir(cwd)
         sys.argv = argv
@@ -233,6 +251,23 @@ def test_small_map_launch_policy_round4():
     assert pick(8, 8, 512, 512, 4) == (1, 16)                                  # the training plan does not ask for the small-map kernels here
     assert pick(64, 64, 128, 256, 4, ks=1, plain=True, small=True) == (4, 1)   # 1024 items: streaming 1x1, no split-K tail
     assert pick(32, 32, 512, 256, 4, ks=1, plain=True, small=True)[0] != 4     # 512 items: direct kernel
+
+
+def test_f43_is_not_chosen_beyond_its_groupnorm_table():
+    """Round-5 advisor finding: the F(4x4,3x3) kernels keep the image's GroupNorm affine in an LDS table of 1024 input channels and
+    refuse wider GroupNorm-fused launches; the policy must not hand them one (a wider custom model, or a lowered
+    ANODDPM_F43_MIN_PIXELS / ANODDPM_F43_32 on the deep layers of a base-256 model)."""
+    from anoddpm_amd.unet import choose_conv_cfg as pick, F43_MAX_GN_K
+    assert F43_MAX_GN_K == 1024
+    assert pick(64, 64, 1024, 256, 4, f43=True) == (3, 1)                      # the widest shipped shape class still takes F(4x4)
+    assert pick(64, 64, 1280, 256, 4, c0=768, c1=512, f43=True)[0] == 2        # K = 1280 with a fused GroupNorm: F(2x2)
+    assert pick(64, 64, 1280, 256, 4, c0=768, c1=512, f43=True, plain=True) == (3, 1)      # no affine to table: not limited
+    os.environ["ANODDPM_F43_32"] = "1"
+    try:
+        assert pick(32, 32, 1280, 256, 4, c0=768, c1=512, f43=True)[0] == 2
+        assert pick(32, 32, 1024, 256, 4, f43=True)[0] == 3
+    finally:
+        del os.environ["ANODDPM_F43_32"]
 
 
 def test_host_side_shape_helpers_of_the_library():

@@ -79,5 +79,6 @@ if __name__ == "__main__":
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
         d["sources_hash"] = bench.tree_hash()          # bench.py flags the file as stale when the kernels / plans change
+        d["class_hashes"] = {c: bench.class_hash(c) for c in bench.CLASS_SOURCES}    # ... per kernel class (round 6)
         d["command"] = "ANODDPM_NO_GRAPH=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof"
         print(json.dumps(d, indent=1))
