@@ -75,7 +75,7 @@ extern "C" int anoddpm_internal_variant(int32_t key, int32_t value)
 {
     if (key < 0 || key >= 16) return ANODDPM_EINVAL;
 #ifndef ANODDPM_ABLATE
-    if (!(key == 0 || key == 4 || key == 5 || key == 8)) {
+    if (!(key == 0 || key == 4 || key == 5 || key == 8 || key == 9)) {
         set_error("internal_variant: key %d selects a timing ablation; this library was built without ANODDPM_ABLATE", key);
         return ANODDPM_EINVAL;
     }

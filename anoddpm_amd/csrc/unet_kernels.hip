@@ -411,6 +411,100 @@ constexpr int STEM_STRIP = 8;
 // Cout = 128).  With a.stats the kernel also emits the GroupNorm partial sums of its range --
 // one row {sum, sum of squares} per channel, the format of the contraction kernels' epilogues -- so that the stem output is not
 // read back by a statistics pass (134 MB at 256^2 x 128 x batch 4).
+// TWO: a workgroup owns two consecutive trips and requests the input rows of BOTH before it computes the first (round 6: half the
+// workgroups, statistics rows and weight loads; the serialised loads of the LOOP form -- 38 us -- are what made more than one
+// trip per workgroup lose in round 3)
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_stem_strip2_kernel(anoddpm_stem_args a)
+{
+    __shared__ float lds_s[256 * 4];
+    __shared__ float lds_q[256 * 4];
+    const int QP = a.Cout >> 2;
+    const int spb = 256 / QP;
+    const int q = threadIdx.x % QP;
+    const int sl = threadIdx.x / QP;
+    const bool lane_on = sl < spb;
+    const int strips_x = a.W / STEM_STRIP;
+    const int64_t nstrips = (int64_t)a.B * a.H * strips_x;
+    const int64_t strip0 = (int64_t)blockIdx.x * spb * 2;
+    const float4 *w = reinterpret_cast<const float4 *>(a.w);
+    float4 wr[9 * CIN];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) wr[t * CIN + ci] = w[(t * CIN + ci) * QP + (lane_on ? q : 0)];
+    const float4 bias = a.bias ? reinterpret_cast<const float4 *>(a.bias)[lane_on ? q : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), ssq = make_float4(0.f, 0.f, 0.f, 0.f);
+    float in[2][CIN][3][STEM_STRIP + 2];
+    float4 *outp[2];
+    bool on[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int64_t strip = strip0 + (int64_t)it * spb + sl;
+        on[it] = lane_on && strip < nstrips;
+        if (!on[it]) strip = 0;                                     // clamped: loaded and discarded
+        const int sx = (int)(strip % strips_x);
+        const int y = (int)((strip / strips_x) % a.H);
+        const int b = (int)(strip / ((int64_t)strips_x * a.H));
+        const int x0 = sx * STEM_STRIP;
+        const bool has_l = x0 > 0, has_r = x0 + STEM_STRIP < a.W;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float *plane = a.x + ((int64_t)b * CIN + ci) * a.H * a.W;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = y + dy - 1;
+                const bool yin = yy >= 0 && yy < a.H;
+                const float *row = plane + (int64_t)(yin ? yy : y) * a.W + x0;
+                const float4 m0 = *reinterpret_cast<const float4 *>(row), m1 = *reinterpret_cast<const float4 *>(row + 4);
+                const float l = row[has_l ? -1 : 0], r = row[has_r ? STEM_STRIP : STEM_STRIP - 1];
+                in[it][ci][dy][0] = (yin && has_l) ? l : 0.f;
+                in[it][ci][dy][1] = yin ? m0.x : 0.f; in[it][ci][dy][2] = yin ? m0.y : 0.f;
+                in[it][ci][dy][3] = yin ? m0.z : 0.f; in[it][ci][dy][4] = yin ? m0.w : 0.f;
+                in[it][ci][dy][5] = yin ? m1.x : 0.f; in[it][ci][dy][6] = yin ? m1.y : 0.f;
+                in[it][ci][dy][7] = yin ? m1.z : 0.f; in[it][ci][dy][8] = yin ? m1.w : 0.f;
+                in[it][ci][dy][9] = (yin && has_r) ? r : 0.f;
+            }
+        }
+        outp[it] = reinterpret_cast<float4 *>(a.out) + (((int64_t)b * a.H + y) * a.W + x0) * QP + q;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        if (!on[it]) continue;
+#pragma unroll
+        for (int i = 0; i < STEM_STRIP; ++i) {
+            float4 acc = bias;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float v = in[it][ci][dy][i + dx];
+                        const float4 wv = wr[(dy * 3 + dx) * CIN + ci];
+                        acc.x += v * wv.x; acc.y += v * wv.y; acc.z += v * wv.z; acc.w += v * wv.w;
+                    }
+            outp[it][(int64_t)i * QP] = acc;
+            ssum.x += acc.x; ssum.y += acc.y; ssum.z += acc.z; ssum.w += acc.w;
+            ssq.x += acc.x * acc.x; ssq.y += acc.y * acc.y; ssq.z += acc.z * acc.z; ssq.w += acc.w * acc.w;
+        }
+    }
+    if (!a.stats) return;
+    if (lane_on) {
+        const int o = (sl * QP + q) * 4;
+        lds_s[o] = ssum.x; lds_s[o + 1] = ssum.y; lds_s[o + 2] = ssum.z; lds_s[o + 3] = ssum.w;
+        lds_q[o] = ssq.x; lds_q[o + 1] = ssq.y; lds_q[o + 2] = ssq.z; lds_q[o + 3] = ssq.w;
+    }
+    __syncthreads();
+    float *row = a.stats + (int64_t)blockIdx.x * a.Cout * 2;
+    for (int c = threadIdx.x; c < a.Cout; c += 256) {
+        float s = 0.f, qq = 0.f;
+        for (int r = 0; r < spb; ++r) { s += lds_s[r * QP * 4 + c]; qq += lds_q[r * QP * 4 + c]; }
+        row[c * 2] = s;
+        row[c * 2 + 1] = qq;
+    }
+}
+
 template <int CIN, bool LOOP>
 __global__ __launch_bounds__(256) void conv_stem_strip_kernel(anoddpm_stem_args a, int iters_arg)
 {
@@ -829,14 +923,9 @@ __global__ __launch_bounds__(256) void conv_head_mfma2_kernel(anoddpm_head_args 
 #pragma unroll
             for (int j = 0; j < NJ; ++j) v[cur ^ 1][j] = *reinterpret_cast<const hf32x4 *>(xp + 16 * j);
         }
-        // round 6: one accumulator per float4 component.  With Cout = 1 (NT = 1) the 4 * NJ MFMAs of a tile row were ONE dependent
-        // chain (58 % of the wave cycles were issue stalls, profiles/r5_c2_sq_by_kernel.csv); four chains keep the pipe fed from
-        // a single wave.  The partial sums are added pairwise at the end of the row: (s0 + s1) + (s2 + s3).
-        hf32x4 accs[4][NT];
+        hf32x4 accr[NT];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) accs[s][nt] = hf32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) accr[nt] = hf32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const hf32x4 x4 = v[cur][j] * aff[0][4 * j + q] + aff[1][4 * j + q];
@@ -848,11 +937,8 @@ __global__ __launch_bounds__(256) void conv_head_mfma2_kernel(anoddpm_head_args 
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) accs[s][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[s], bw[nt][j][s], accs[s][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) accr[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(e[s], bw[nt][j][s], accr[nt], 0, 0, 0);
         }
-        hf32x4 accr[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) accr[nt] = (accs[0][nt] + accs[1][nt]) + (accs[2][nt] + accs[3][nt]);
         // D[row = 4 q + r][col = m]: zero padding of the ACTIVATED map = zero product rows of out-of-image pixels
         const int gy = oy0 + wave * RPW + mt - 1;
         const bool rowok = gy >= 0 && gy < a.H;
@@ -1036,6 +1122,10 @@ extern "C" int anoddpm_stem_stats_rows(int H, int W, int Cin, int Cout)
     if (per_image % ppb) return 0;
     const int64_t trips = per_image / ppb;
     int64_t iters = 1;
+    // round 6: two trips per workgroup with BOTH trips' input rows requested up front (conv_stem_strip2_kernel): 31.1 -> 28.4 us at
+    // 256^2 x 128 x batch 4 (4.35 -> 4.77 TB/s); Cin = 1 only (the two-channel form would need 244 registers).  ANODDPM_DEBUG9=1
+    // keeps one trip per workgroup.
+    if (anoddpm::g_debug[9] != 1 && Cin == 1 && trips % 2 == 0 && trips / 2 >= 256) iters = 2;
     while (trips / iters > 1024) iters *= 2;
     while (iters > 1 && trips % iters) iters /= 2;
     return (int)(trips / iters);
@@ -1057,11 +1147,12 @@ extern "C" int anoddpm_conv_stem(const anoddpm_stem_args *a, void *stream)
             ANODDPM_REQUIRE(a->stats_rows > 0 && per_image % ((int64_t)a->stats_rows * ppb) == 0, "conv_stem: stats_rows must divide the strips of an image into whole workgroup trips");
             iters = (int)(per_image / ((int64_t)a->stats_rows * ppb));
         } else {
-            iters = 1;
+            iters = (a->Cin == 1 && anoddpm::g_debug[9] != 1 && per_image % (2 * (int64_t)ppb) == 0 && per_image / (2 * ppb) >= 256) ? 2 : 1;
         }
         const dim3 grid((unsigned)((nstrips + (int64_t)ppb * iters - 1) / ((int64_t)ppb * iters)));
         hipStream_t st = anoddpm::as_stream(stream);
-        if (a->Cin == 1 && iters == 1) hipLaunchKernelGGL((conv_stem_strip_kernel<1, false>), grid, dim3(256), 0, st, *a, 1);
+        if (a->Cin == 1 && iters == 2)      hipLaunchKernelGGL((conv_stem_strip2_kernel<1>), grid, dim3(256), 0, st, *a);
+        else if (a->Cin == 1 && iters == 1) hipLaunchKernelGGL((conv_stem_strip_kernel<1, false>), grid, dim3(256), 0, st, *a, 1);
         else if (a->Cin == 1)          hipLaunchKernelGGL((conv_stem_strip_kernel<1, true>), grid, dim3(256), 0, st, *a, iters);
         else if (iters == 1)           hipLaunchKernelGGL((conv_stem_strip_kernel<2, false>), grid, dim3(256), 0, st, *a, 1);
         else                           hipLaunchKernelGGL((conv_stem_strip_kernel<2, true>), grid, dim3(256), 0, st, *a, iters);

@@ -275,8 +275,10 @@ def test_host_side_shape_helpers_of_the_library():
     the Winograd-domain weight gradient -- the values the plans size their buffers with."""
     from anoddpm_amd._lib import lib
     L = lib()
-    # stem: one row per workgroup range; 8 strips of 8 pixels per workgroup at Cout = 128, at most 1024 rows per image
-    assert L.anoddpm_stem_stats_rows(256, 256, 1, 128) == 1024 and L.anoddpm_stem_stats_rows(512, 512, 1, 128) == 1024
+    # stem: one row per workgroup range; 8 strips of 8 pixels per workgroup trip at Cout = 128, at most 1024 rows per image; round 6:
+    # two prefetched trips per workgroup for one input channel while that leaves >= 256 rows (256^2: 512 rows)
+    assert L.anoddpm_stem_stats_rows(256, 256, 1, 128) == 512 and L.anoddpm_stem_stats_rows(512, 512, 1, 128) == 1024
+    assert L.anoddpm_stem_stats_rows(256, 256, 2, 128) == 1024
     assert L.anoddpm_stem_stats_rows(128, 128, 1, 128) == 256 and L.anoddpm_stem_stats_rows(64, 64, 2, 64) == 32
     assert L.anoddpm_stem_stats_rows(64, 64, 3, 128) == 0 and L.anoddpm_stem_stats_rows(60, 60, 1, 128) == 0     # no fused form
     for (H, C) in ((256, 128), (512, 128), (64, 64), (16, 1024)):
