@@ -104,7 +104,11 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     const int H = a.H, W = a.W;
     const int K = a.c0 + a.c1, N = a.N, K4 = K >> 2;
     const int tiles_x = W >> 4;
-    const int y0 = (blockIdx.x / tiles_x) * 16, x0 = (blockIdx.x % tiles_x) * 16;
+    // VAR bit 4: XCD-aware tile walk.  Workgroup b runs on XCD b % 8 (observed dispatch rule); handing XCD k the k-th contiguous
+    // eighth of the tile list keeps neighbouring tiles -- which share two halo rows / columns -- behind ONE L2 instead of eight
+    int tile = blockIdx.x;
+    if ((VAR & 16) && (gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int y0 = (tile / tiles_x) * 16, x0 = (tile % tiles_x) * 16;
     const int n0 = blockIdx.y * 128;
     // split-K (grids that would leave CUs idle, e.g. the 64x64 maps of a batch of four): blockIdx.z = image * ksplit + slice; a
     // slice accumulates a contiguous range of 16-channel chunks and leaves its output-transformed partial tile in the workspace
@@ -543,6 +547,7 @@ int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
     else if (fast && dbg == 32) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9, 36, 3>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 33) hipLaunchKernelGGL((wino43r_kernel<true, 0, 6, 36, 1>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 34) hipLaunchKernelGGL((wino43r_kernel<true, 0, 6, 36, 3>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 39) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9, 36, 16>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 35) hipLaunchKernelGGL((wino43r_kernel<true, 0, 6, 36, 4>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 36) hipLaunchKernelGGL((wino43r_kernel<true, 0, 6, 36, 5>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 37) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9, 36, 8>), grid, dim3(R4_NT), 0, s, *a);

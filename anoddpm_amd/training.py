@@ -160,6 +160,14 @@ class GradAllReducer:
         self.launched = 0            # buckets reduced by the last finish() (tests)
         self.launch_log = []         # (bucket, backward ops already enqueued or None) of the step in flight
         self.last_launch_log = []    # ... of the last finished step (tests)
+        # host-clock telemetry of the last finished step (the first real multi-GPU run should be able to tune
+        # ANODDPM_BUCKET_MB from one bench line): when each bucket's all-reduce was ENQUEUED relative to the first one, and how
+        # long finish() then WAITED for the collectives -- the exposed (not hidden behind the backward) part of the all-reduce
+        self._t_first = None
+        self._enqueue_ms = []
+        self.last_timing = {"buckets": len(self.buckets), "bucket_MB": [4.0 * (hi - lo) / (1 << 20) for lo, hi, _ in self.buckets],
+                            "enqueue_offset_ms": [], "exposed_wait_ms": None, "host_timed": True}
+        self.timing_sync = False     # bench.py sets it: finish() then synchronises the stream so that exposed_wait_ms is device time
         self.active = bool(dist.is_initialized() and (self.world > 1 or force))
         if getattr(flat, "module", None) is not None:
             _REDUCERS[flat.module] = weakref.ref(self)        # the native training plan cuts its backward at our buckets
@@ -188,6 +196,11 @@ class GradAllReducer:
             self._launch(b)
 
     def _launch(self, b):
+        import time
+        now = time.perf_counter()
+        if self._t_first is None:
+            self._t_first = now
+        self._enqueue_ms.append((b, 1000.0 * (now - self._t_first)))
         lo, hi, _ = self.buckets[b]
         view = self.flat.flat_grad[lo:hi]
         if self.staged:
@@ -205,10 +218,18 @@ class GradAllReducer:
                 self.pending[b] = 0
                 self.launch_log.append((b, None))
                 self._launch(b)
+        import time
+        t0 = time.perf_counter()
         for work, view, host in self.works:
             work.wait()
             if host is not None:
                 view.copy_(host)
+        if self.flat.flat_grad.is_cuda and not self.staged:
+            # work.wait() only orders the current stream behind the collective: the host-side figure needs the device to get there
+            torch.cuda.current_stream(self.flat.flat_grad.device).synchronize() if self.timing_sync else None
+        self.last_timing = dict(self.last_timing, enqueue_offset_ms=[ms for _, ms in sorted(self._enqueue_ms)],
+                                exposed_wait_ms=1000.0 * (time.perf_counter() - t0), synced=bool(self.timing_sync))
+        self._t_first, self._enqueue_ms = None, []
         self.launched = len(self.works)
         self.last_launch_log, self.launch_log = self.launch_log, []
         if self.world > 1:

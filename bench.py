@@ -751,6 +751,22 @@ def run_train(c, args, cfg):
                       "parallelism": (f"data-parallel x{c.world}, bucketed RCCL all-reduce of the flat gradient" if c.dist is not None
                                       else "single GPU (no collective)"),
                       "loss_finite": finite, "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}}
+    if reducer is not None and reducer.active:
+        # one more step with the stream synchronised inside finish(): where the buckets' all-reduces were enqueued in the
+        # backward (host clock, ms after the first) and how long the step then waited for them -- the EXPOSED part of the
+        # collective.  No 8-GPU node was available to the build: ANODDPM_BUCKET_MB (default 64) and the cut positions are untuned,
+        # this is the line to tune them from.
+        reducer.timing_sync = True
+        step()
+        torch.cuda.synchronize()
+        reducer.timing_sync = False
+        t = reducer.last_timing
+        out["config"]["allreduce"] = {"buckets": t["buckets"], "bucket_MB": [round(v, 1) for v in t["bucket_MB"]],
+                                      "enqueue_offset_ms": [round(v, 3) for v in t["enqueue_offset_ms"]],
+                                      "exposed_wait_ms": t["exposed_wait_ms"], "world": c.world,
+                                      "bucket_MB_setting": reducer.bucket_bytes / (1 << 20),
+                                      "cut_ops": [ops for _, ops in reducer.last_launch_log],
+                                      "note": "host-clock offsets of the enqueues; exposed_wait_ms = finish(): work.wait() + stream sync"}
     return out, roofline, (lambda: cpu_baseline_train(cfg))
 
 

@@ -103,6 +103,11 @@ def _worker_cut_backward(rank, world, port, out_dir):
                 red.launch_bucket(b, ops_done=-1)            # a second call for the same bucket is a no-op
         red.finish()
         logs.append(list(red.last_launch_log))
+        # telemetry of the finished step (bench.py --config c3 --gpus N prints it): one enqueue offset per bucket, first one 0,
+        # non-decreasing in bucket order; the wait inside finish()
+        tm = red.last_timing
+        assert tm["buckets"] == len(red.buckets) and len(tm["enqueue_offset_ms"]) == len(red.buckets) and tm["exposed_wait_ms"] >= 0
+        assert min(tm["enqueue_offset_ms"]) == 0.0 and len(tm["bucket_MB"]) == len(red.buckets)
     torch.save({"grad": flat.flat_grad.clone(), "logs": logs, "nb": len(red.buckets)}, os.path.join(out_dir, f"c{rank}.pt"))
     dist.destroy_process_group()
 
