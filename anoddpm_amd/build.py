@@ -23,6 +23,7 @@ SOURCES = {
     "winograd.hip": [],
     "winograd43.hip": [],
     "winograd43r.hip": [],
+    "winograd43w.hip": [],
     "winograd43b.hip": [],
     "pointwise.hip": [],
     "smallmap.hip": [],

@@ -49,6 +49,7 @@ inline int allow_big_lds(const void *fn, bool *done, const char *what)
 int launch_winograd(const anoddpm_igemm_args *a, hipStream_t s);   // winograd.hip (cfg == 2 of anoddpm_igemm)
 int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s); // winograd43.hip (cfg == 3)
 int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s); // winograd43r.hip (cfg == 3, 128-channel workgroups)
+int launch_winograd43w(const anoddpm_igemm_args *a, hipStream_t s, int tsplit); // winograd43w.hip (the same workgroup as four waves, one per SIMD)
 int launch_pointwise_stream(const anoddpm_igemm_args *a, hipStream_t s); // pointwise.hip (cfg == 4)
 int launch_smallmap(const anoddpm_igemm_args *a, hipStream_t s);         // smallmap.hip (cfg == 5)
 int smallmap_tile(int ks, int H, int W, int K, int c0, int N, int B);

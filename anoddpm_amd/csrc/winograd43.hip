@@ -483,6 +483,14 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
     // boundaries -- measured SLOWER, 307 vs 285 us on the 256x256 128->128 layer: vmcnt retires in order, so the next tile's B
     // fragments wait behind the epilogue's 64 stores per lane, while a fresh workgroup starts beside its predecessor's
     // draining stores for free; profiles/r5_f43_persistent_ab.txt)
+    // ANODDPM_DEBUG5 = 4 / 5: the one-wave-per-SIMD form of the 128-channel workgroup (winograd43w.hip; 5 = transform interleaved
+    // with the MFMA stream), 6 / 7: the same wherever N % 128 == 0 (op tests on small shapes)
+    // 8 / 9: as 4 / 5 with four instead of six positions of B fragments in flight
+    {
+        const int v5 = anoddpm::g_debug[5];
+        if (dbg == 0 && a->N % 128 == 0 && ((!half && (v5 == 4 || v5 == 5 || v5 == 8 || v5 == 9)) || v5 == 6 || v5 == 7))
+            return launch_winograd43w(a, s, (v5 & 1) | (v5 >= 8 ? 2 : 0));
+    }
     if (dbg == 0 && ((!half && anoddpm::g_debug[5] != 1) || (a->N % 128 == 0 && anoddpm::g_debug[5] == 3))) return launch_winograd43r(a, s);
 #ifdef ANODDPM_ABLATE           // timing ablations (wrong results): measurement builds only
     if (fast && dbg == 1) hipLaunchKernelGGL((wino43_kernel<true, 1>), grid, dim3(F4_NT), 0, s, *a);

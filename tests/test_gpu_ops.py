@@ -391,10 +391,12 @@ def test_streaming_pointwise_rejects_fused_operands():
                           Hout=32, ks=1, cfg=4)
 
 
-@pytest.fixture(params=[0, 3], ids=["auto", "channel-sliced"])
+@pytest.fixture(params=[0, 3, 6, 7], ids=["auto", "channel-sliced", "one-wave-per-simd", "one-wave-per-simd-tsplit"])
 def f43_variant(request):
     """0: the launcher's choice (the 64-channel position-sliced kernel on these small grids); 3: force the channel-sliced
-    kernel (csrc/winograd43r.hip, what the 128-channel grids of the real layers run) wherever N % 128 == 0."""
+    kernel (csrc/winograd43r.hip, what the 128-channel grids of the real layers run) wherever N % 128 == 0; 6 / 7: the
+    one-wave-per-SIMD form of that workgroup (csrc/winograd43w.hip, round 6 measurement kernel; 7 = transform interleaved with the
+    MFMA stream) wherever N % 128 == 0 and the launch is not split-K."""
     from anoddpm_amd._lib import lib
     lib().anoddpm_internal_variant(5, request.param)
     yield request.param
