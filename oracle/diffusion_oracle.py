@@ -16,6 +16,8 @@ Restated (reference file:line):
   q_sample_gradual       GaussianDiffusion.py:373-382
   p_mean_variance_eps    GaussianDiffusion.py:269-296 with :228-230, :253-267
   p_sample_update        GaussianDiffusion.py:314-317
+  detection_loop         GaussianDiffusion.py:499-520 / 554-583 (detection_A / detection_B: the serial (setting, avg) chains + the
+                         mean -> mse -> threshold images), PINNED by tests/golden/detection_loops_kat.npz (round 6)
 """
 import numpy as np
 import torch
@@ -197,3 +199,30 @@ def loss_grad_analytic(tb, x0, t, eps, noise, weights=None, kind="l2", dtype=np.
     dmean_nll = np.where(x0 < f(-0.999), lo, np.where(x0 > f(0.999), hi, mid))
     dmean = np.where((tn == 0).reshape(sh), dmean_nll, dmean_kl)
     return grad + cb * dmean * c1 * dpred / (n * f(np.log(2.0)))
+
+
+# ---------------------------------------------------------------------------- detection loops (round 6)
+def detection_loop(tb, model, x0, mask, settings, total_avg, forward_noise, step_noise):
+    """The serial compute of detection_A / detection_B (GaussianDiffusion.py:499-520, 554-583) for a list of settings.
+
+    settings: [(key, t_distance)] in upstream's loop order; per setting `total_avg` chains: x = q_sample(x0, t_distance,
+    forward_noise(key, chain)), then t = t_distance - 1 .. 0 of p_sample_update(x, t, model(x, t), step_noise(chain, t)) -- `chain`
+    counts the chains of the whole call in loop order.  Per setting returns what upstream hands to its figure:
+    cat[x0, output[:3], mean(output), mse = (mean - x0)^2 * 2 - 1, threshold = (mse > 0) * 2 - 1, mask]."""
+    grids, chain = [], 0
+    for key, t_distance in settings:
+        output = torch.empty((total_avg,) + tuple(x0.shape[1:]))
+        for avg in range(total_avg):
+            t = torch.tensor([t_distance]).repeat(x0.shape[0])
+            x = q_sample(tb, x0, t, forward_noise(key, chain))
+            for ti in range(int(t_distance) - 1, -1, -1):
+                tt = torch.tensor([ti]).repeat(x.shape[0])
+                with torch.no_grad():
+                    x, _ = p_sample_update(tb, x, tt, model(x, tt), step_noise(chain, ti))
+            output[avg] = x[0]
+            chain += 1
+        mean = torch.mean(output, dim=0).reshape(1, *x0.shape[1:])
+        mse = ((mean - x0).square() * 2) - 1
+        thr = ((mse > 0).float() * 2) - 1
+        grids.append(torch.cat([x0, output[:3], mean, mse, thr, mask]))
+    return grids
