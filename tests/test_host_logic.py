@@ -209,13 +209,17 @@ def test_conv_launch_policy_on_config2_shapes():
     assert pick(8, 8, 512, 512, Z) == (1, 16)                       # H % 16 != 0: direct kernel, split-K
     assert pick(128, 128, 128, 128, Z, a_mode=2) == (0, 1)          # pool-fused operand: direct 128x128 tiles
     assert pick(256, 256, 256, 128, Z, ks=1) == (0, 1)              # 1x1 skip convolution
-    # round 5, opt-in (ANODDPM_F43_32=1, measured +-0 in the step): the deep 32x32 layers on F(4x4) + split-K; default policy unchanged
-    assert pick(32, 32, 512, 512, Z, f43=True) == (2, 2) and pick(32, 32, 768, 256, Z, f43=True) == (2, 4)
-    os.environ["ANODDPM_F43_32"] = "1"
+    # the deep 32x32 layers on F(4x4) + split-K (round 5: opt-in; round 6: on by default after a repeatable -0.7 % on the step);
+    # ANODDPM_F43_32=0 restores F(2x2) + split-K there
+    assert pick(32, 32, 512, 512, Z, f43=True) == (3, 4) and pick(32, 32, 512, 256, Z, f43=True) == (3, 8)
+    assert pick(32, 32, 768, 256, Z, f43=True) == (3, 8) and pick(32, 32, 256, 256, Z, f43=True) == (2, 4)
+    assert pick(16, 16, 512, 512, Z, f43=True) == (2, 8)
+    assert pick(32, 32, 512, 512, Z) == (2, 2)                      # (a caller without F(4x4) weights keeps F(2x2))
+    assert pick(32, 32, 512, 512, 1, f43=True)[0] == 2              # batch 1 (config 5): too few workgroups, F(2x2) + split-K stays
+    assert pick(32, 32, 512, 512, 16, f43=True) == (3, 1)           # the detection loop's 16 slots: one K slice
+    os.environ["ANODDPM_F43_32"] = "0"
     try:
-        assert pick(32, 32, 512, 512, Z, f43=True) == (3, 4) and pick(32, 32, 512, 256, Z, f43=True) == (3, 8)
-        assert pick(32, 32, 768, 256, Z, f43=True) == (3, 8) and pick(32, 32, 256, 256, Z, f43=True) == (2, 4)
-        assert pick(16, 16, 512, 512, Z, f43=True) == (2, 8)
+        assert pick(32, 32, 512, 512, Z, f43=True) == (2, 2) and pick(32, 32, 768, 256, Z, f43=True) == (2, 4)
     finally:
         del os.environ["ANODDPM_F43_32"]
     assert pick(16, 16, 512, 1536, Z, ks=1) == (1, 2)               # qkv projection
@@ -262,12 +266,8 @@ def test_f43_is_not_chosen_beyond_its_groupnorm_table():
     assert pick(64, 64, 1024, 256, 4, f43=True) == (3, 1)                      # the widest shipped shape class still takes F(4x4)
     assert pick(64, 64, 1280, 256, 4, c0=768, c1=512, f43=True)[0] == 2        # K = 1280 with a fused GroupNorm: F(2x2)
     assert pick(64, 64, 1280, 256, 4, c0=768, c1=512, f43=True, plain=True) == (3, 1)      # no affine to table: not limited
-    os.environ["ANODDPM_F43_32"] = "1"
-    try:
-        assert pick(32, 32, 1280, 256, 4, c0=768, c1=512, f43=True)[0] == 2
-        assert pick(32, 32, 1024, 256, 4, f43=True)[0] == 3
-    finally:
-        del os.environ["ANODDPM_F43_32"]
+    assert pick(32, 32, 1280, 256, 4, c0=768, c1=512, f43=True)[0] == 2          # the deep 32x32 layers (F(4x4) + split-K by default)
+    assert pick(32, 32, 1024, 256, 4, f43=True)[0] == 3
 
 
 def test_host_side_shape_helpers_of_the_library():
