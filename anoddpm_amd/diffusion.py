@@ -306,8 +306,22 @@ class ReverseChain:
                 if self.hip_model:
                     self._plan = self.model._plan_for(self.B, self.x.shape[2], self.x.device)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._step_body()
+                # No cyclic garbage collection INSIDE the capture (round 6: a sporadic `Fatal Python error: Aborted` with the
+                # interpreter "Garbage-collecting" under _step_body, about one GPU test run in five): the collector may pick that
+                # moment to destroy an older chain's captured graph / plan buffers left unreachable by an earlier caller, and HIP
+                # API calls made by those destructors are illegal while a stream capture is open in global mode.  Collect first
+                # (twice: C++ owners release further Python cycles), then keep the collector off until the capture has ended.
+                import gc
+                gc.collect()
+                gc.collect()
+                gc_was_enabled = gc.isenabled()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g):
+                        self._step_body()
+                finally:
+                    if gc_was_enabled:
+                        gc.enable()
                 self.graph = g
                 self._graph_state = 2
                 g.replay()                      # capture does not execute: run the captured step once
@@ -652,6 +666,8 @@ class GaussianDiffusionModel:
         chain = ReverseChain(self, model, x, t_distance, denoise_fn)
         if chain.use_graph and chain.reuse_key is not None:
             if len(cache) >= 8:
+                if x.is_cuda:
+                    torch.cuda.synchronize(x.device)              # its captured graph may still be replaying (see _run_chains)
                 cache.pop(next(iter(cache)))
             cache[(id(model), tuple(x.shape), str(x.device), chain.reuse_key)] = chain
         return chain
@@ -671,6 +687,8 @@ class GaussianDiffusionModel:
     def release_chains(self):
         """Drop every kept ReverseChain (captured HIP graph + the device buffers and plan it holds: about 3.4 GB per chain at
         config 2); the next forward_backward / detection call builds and captures a fresh one."""
+        if self.__dict__.get("_chains") and torch.cuda.is_available():
+            torch.cuda.synchronize()                               # no captured graph may be destroyed while a replay is in flight
         self.__dict__.pop("_chains", None)
 
     def __getstate__(self):
@@ -916,9 +934,14 @@ class GaussianDiffusionModel:
             # kept slot chains of this model at OTHER slot counts are superseded (each holds a plan + captured graph: 3.4 GB per
             # four images at config 2): drop them before the new plan is allocated (round-5 advisor finding)
             cache = self.__dict__.get("_chains", {})
-            for key in [k for k, ch in cache.items() if getattr(ch, "slot_chain", False) and k[0] == id(model)
-                        and k[1][1:] == tuple(x_start.shape[1:]) and k[1][0] != G]:
-                cache.pop(key)
+            stale = [k for k, ch in cache.items() if getattr(ch, "slot_chain", False) and k[0] == id(model)
+                     and k[1][1:] == tuple(x_start.shape[1:]) and k[1][0] != G]
+            if stale:
+                # the dropped chains' captured graphs may still have replays (and the copies that harvested their last images) in
+                # flight on this stream: let the device finish before their hipGraphExec objects are destroyed
+                torch.cuda.synchronize(x_start.device)
+                for key in stale:
+                    cache.pop(key)
             while True:
                 try:
                     chain = self._chain_for(model, x_start[:1].expand(G, -1, -1, -1).contiguous(), 1, "gauss")

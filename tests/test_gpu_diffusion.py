@@ -181,3 +181,43 @@ def test_kept_chain_is_not_replayed_for_a_train_mode_dropout_model():
     m.eval()
     torch.manual_seed(1)
     assert torch.equal(d.forward_backward(m, x, None, 4), a)          # back in eval: the kept chain again
+
+
+def test_graph_capture_survives_garbage_of_older_chains():
+    """Round 6 regression: the cyclic collector used to run INSIDE ReverseChain's stream capture now and then and destroy an older,
+    unreachable chain's captured graph / plan there -- HIP calls that are illegal during a global-mode capture (`Fatal Python error:
+    Aborted`, "Garbage-collecting" under _step_body; about one full GPU test run in five).  With the collector at its most
+    eager (threshold 1) and unreachable chains lying around, a new capture must still go through."""
+    import gc
+    import GaussianDiffusion as GD
+    from UNet import UNetModel
+    from oracle import unet_oracle as uo
+
+    def model():
+        m = UNetModel(img_size=32, base_channels=32, n_heads=2, attention_resolutions="16,8")
+        m.load_state_dict(uo.fill_deterministic({k: tuple(v.shape) for k, v in m.state_dict().items()}))
+        return m.to(DEV).eval()
+
+    x = torch.rand(2, 1, 32, 32, device=DEV) * 2 - 1
+    old = gc.get_threshold()
+    gc.disable()                                               # let the garbage pile up first
+    try:
+        for _ in range(3):                                     # chains with captured graphs, left unreachable in reference cycles
+            m = model()
+            d = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(100, "linear"), noise="gauss")
+            d.forward_backward(m, x, None, 4)
+            d._self, m._d = d, d                               # a cycle: only the collector frees these
+        del m, d
+        gc.set_threshold(1, 1, 1)
+        gc.enable()
+        m2 = model()
+        d2 = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(100, "linear"), noise="gauss")
+        torch.manual_seed(3)
+        a = d2.forward_backward(m2, x, None, 5)                # eager step, capture, three replays -- collector armed throughout
+        torch.manual_seed(3)
+        b = d2.forward_backward(m2, x, None, 5)
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    finally:
+        gc.set_threshold(*old)
+        gc.enable()
+        gc.collect()
