@@ -183,11 +183,13 @@ def test_kept_chain_is_not_replayed_for_a_train_mode_dropout_model():
     assert torch.equal(d.forward_backward(m, x, None, 4), a)          # back in eval: the kept chain again
 
 
-def test_graph_capture_survives_garbage_of_older_chains():
-    """Round 6 regression: the cyclic collector used to run INSIDE ReverseChain's stream capture now and then and destroy an older,
-    unreachable chain's captured graph / plan there -- HIP calls that are illegal during a global-mode capture (`Fatal Python error:
-    Aborted`, "Garbage-collecting" under _step_body; about one full GPU test run in five).  With the collector at its most
-    eager (threshold 1) and unreachable chains lying around, a new capture must still go through."""
+def test_no_garbage_collection_inside_graph_capture(monkeypatch):
+    """Round 6 regression: torch.cuda.graph() no longer collects garbage before a capture (torch.compiler.config.force_cudagraph_gc
+    is off by default), so the cyclic collector could run INSIDE ReverseChain's stream capture and destroy an older, unreachable
+    chain's captured graph / plan there -- HIP calls that are illegal during a global-mode capture (`Fatal Python error: Aborted`
+    with the interpreter "Garbage-collecting" under _step_body: two of ten full GPU test runs).  ReverseChain.step now collects
+    before the capture and keeps the collector off until it has ended: with the collector at its most eager (threshold 1) and
+    unreachable chains lying around, no collection may START between capture begin and end."""
     import gc
     import GaussianDiffusion as GD
     from UNet import UNetModel
@@ -198,26 +200,46 @@ def test_graph_capture_survives_garbage_of_older_chains():
         m.load_state_dict(uo.fill_deterministic({k: tuple(v.shape) for k, v in m.state_dict().items()}))
         return m.to(DEV).eval()
 
+    state = {"in_capture": False, "captures": 0, "hits": []}
+    enter, leave = torch.cuda.graph.__enter__, torch.cuda.graph.__exit__
+
+    def _enter(self):
+        r = enter(self)
+        state["in_capture"] = True
+        state["captures"] += 1
+        return r
+
+    def _exit(self, *a):
+        state["in_capture"] = False
+        return leave(self, *a)
+    monkeypatch.setattr(torch.cuda.graph, "__enter__", _enter)
+    monkeypatch.setattr(torch.cuda.graph, "__exit__", _exit)
+
+    def on_gc(phase, info):
+        if phase == "start" and state["in_capture"]:
+            state["hits"].append(info["generation"])
     x = torch.rand(2, 1, 32, 32, device=DEV) * 2 - 1
     old = gc.get_threshold()
-    gc.disable()                                               # let the garbage pile up first
+    gc.callbacks.append(on_gc)
     try:
-        for _ in range(3):                                     # chains with captured graphs, left unreachable in reference cycles
+        for _ in range(2):                                     # chains with captured graphs, left unreachable in reference cycles
             m = model()
             d = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(100, "linear"), noise="gauss")
             d.forward_backward(m, x, None, 4)
-            d._self, m._d = d, d                               # a cycle: only the collector frees these
+            d._self, m._d = d, d
         del m, d
-        gc.set_threshold(1, 1, 1)
-        gc.enable()
         m2 = model()
         d2 = GD.GaussianDiffusionModel([32, 32], GD.get_beta_schedule(100, "linear"), noise="gauss")
+        gc.set_threshold(1, 1, 1)                              # from here on every allocation may start a collection
         torch.manual_seed(3)
-        a = d2.forward_backward(m2, x, None, 5)                # eager step, capture, three replays -- collector armed throughout
+        a = d2.forward_backward(m2, x, None, 5)                # eager step, capture, three replays
+        gc.set_threshold(*old)
         torch.manual_seed(3)
         b = d2.forward_backward(m2, x, None, 5)
+        assert state["captures"] >= 3 and state["hits"] == [], state
         assert torch.isfinite(a).all() and torch.equal(a, b)
     finally:
+        gc.callbacks.remove(on_gc)
         gc.set_threshold(*old)
         gc.enable()
         gc.collect()
