@@ -461,8 +461,9 @@ def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None
     # winograd43r.hip refuse more): wider GroupNorm-fused layers -- none in the shipped configurations, max 1024 -- fall through to
     # F(2x2) / the direct kernels (round-5 advisor finding); `plain` launches carry no affine and are not limited
     f43 = f43 and (plain or K <= F43_MAX_GN_K)
-    f43_small = H * W == 32 * 32 or (H * W == 16 * 16 and os.environ.get("ANODDPM_F43_16", "0") == "1")     # (16x16: experiment)
-    if (wino_ok and f43 and N % 128 == 0 and f43_small and K >= int(os.environ.get("ANODDPM_F43_32_MINK", 512))
+    # (the same on the 16x16 maps -- one tile per image, 8-16 K slices -- measured 8.974 / 8.972 / 8.985 against 8.960 / 8.950 / 8.961 ms:
+    # not taken, profiles/r6_f43_32_ab.txt)
+    if (wino_ok and f43 and N % 128 == 0 and H * W == 32 * 32 and K >= int(os.environ.get("ANODDPM_F43_32_MINK", 512))
             and os.environ.get("ANODDPM_F43_32", "1") == "1"):
         # the deep 32x32 layers on the channel-sliced F(4x4) kernel with split-K -- 16 x 16-pixel tiles x 128 channels x K slices of
         # >= 4 chunks -- instead of F(2x2) + split-K.  Round 5 measured it inside the box-to-box noise and left it off; round 6
@@ -473,7 +474,7 @@ def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None
         ks43 = int(min(max(1, (K // 16) // 4), -(-256 // wg)))
         cps = -(-(K // 16) // ks43)
         ks43 = -(-(K // 16) // cps)
-        if wg * ks43 >= (200 if H * W == 32 * 32 else 100):      # (batch 1, config 5: 128 workgroups of four chunks -- measured slower than F(2x2): 9.60 vs 9.52 ms)
+        if wg * ks43 >= 200:                  # (batch 1, config 5: 128 workgroups of four chunks -- measured slower than F(2x2): 9.60 vs 9.52 ms)
             return 3, ks43
     if wino_ok and f43 and N % 64 == 0 and H * W >= int(os.environ.get("ANODDPM_F43_MIN_PIXELS", 64 * 64)) \
             and (H // 16) * (W // 16) * (N // 64) * Z >= 128 and os.environ.get("ANODDPM_NO_F43", "0") != "1":
