@@ -266,7 +266,7 @@ class TrainPlan(_Plan):
         # maps where the forward uses that kernel; ANODDPM_NO_WGRAD43=1 keeps the direct nine-tap kernel everywhere
         # (a plain operand -- dropout output, Downsample / Upsample inputs -- takes the direct kernel: gn is None)
         algo = int(gn is not None and a_mode in (0, 1) and H % 8 == 0 and W % 16 == 0 and K % 32 == 0 and N % 64 == 0 and (c1 == 0 or c0 % 16 == 0)
-                   and B <= 15 and H * W >= int(os.environ.get("ANODDPM_WGRAD43_MIN_PIXELS", 32 * 32))
+                   and B <= 15 and H * W >= int(os.environ.get("ANODDPM_WGRAD43_MIN_PIXELS", 16 * 16))   # round 6: the 16x16 maps too (40.55 -> 40.32 ms per config-3 step, profiles/r6_knob_sweep_c3.txt; 32x32 was the limit before)
                    and os.environ.get("ANODDPM_NO_WGRAD43", "0") != "1")
         wa = WgradArgs()
         wa.a0 = srcs[0][0].data_ptr()
