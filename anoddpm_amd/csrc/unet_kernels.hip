@@ -1090,12 +1090,20 @@ extern "C" int anoddpm_dropout(const anoddpm_dropout_args *a, void *stream)
 extern "C" int anoddpm_linear_small(const anoddpm_linear_args *a, void *stream)
 {
     ANODDPM_REQUIRE(a && a->in && a->w && a->out, "linear_small: null pointer");
-    ANODDPM_REQUIRE(a->B >= 1 && a->B <= 16 && a->K % 4 == 0 && a->N >= 1, "linear_small: need 1<=B<=16, K%%4==0");
+    ANODDPM_REQUIRE(a->B >= 1 && a->B <= 4096 && a->K % 4 == 0 && a->N >= 1, "linear_small: need 1<=B<=4096, K%%4==0");
     dim3 grid((a->N + 3) / 4);
     hipStream_t s = anoddpm::as_stream(stream);
-    if (a->B <= 4) hipLaunchKernelGGL(linear_small_kernel<4>, grid, dim3(256), 0, s, *a);
-    else if (a->B <= 8) hipLaunchKernelGGL(linear_small_kernel<8>, grid, dim3(256), 0, s, *a);
-    else hipLaunchKernelGGL(linear_small_kernel<16>, grid, dim3(256), 0, s, *a);
+    // up to 16 batch rows per launch live in registers; larger batches (round 6: the inference plan stopped at batch 16 here --
+    // the detection loop with more than 16 chain slots, a caller's batch of 32) take one launch per 16 rows
+    for (int b0 = 0; b0 < a->B; b0 += 16) {
+        anoddpm_linear_args c = *a;
+        c.in = a->in + (int64_t)b0 * a->K;
+        c.out = a->out + (int64_t)b0 * a->N;
+        c.B = a->B - b0 < 16 ? a->B - b0 : 16;
+        if (c.B <= 4) hipLaunchKernelGGL(linear_small_kernel<4>, grid, dim3(256), 0, s, c);
+        else if (c.B <= 8) hipLaunchKernelGGL(linear_small_kernel<8>, grid, dim3(256), 0, s, c);
+        else hipLaunchKernelGGL(linear_small_kernel<16>, grid, dim3(256), 0, s, c);
+    }
     return anoddpm::check_launch("linear_small");
 }
 

@@ -368,7 +368,7 @@ int anoddpm_resample2x(const anoddpm_resample_args *a, void *stream);
 
 /* Small-batch linear layer (UNet.py:273-275 time MLP; :185-188 per-block embedding projections,
  * all blocks batched into one launch by concatenating their weight rows):
- *   out[b][n] = act_out( sum_k act_in(in[b][k]) * w[n][k] + bias[n] ),  B <= 16. */
+ *   out[b][n] = act_out( sum_k act_in(in[b][k]) * w[n][k] + bias[n] ); 16 batch rows per launch (larger B: one launch per 16 rows). */
 typedef struct {
     const float *in;                /* [B][K] */
     const float *w;                 /* [N][K] (nn.Linear layout) */

@@ -186,6 +186,22 @@ def test_config2_batch_equals_single_image_forwards(B):
     assert ((yb - y1).abs().max() / y1.abs().max()).item() < 2e-5
 
 
+def test_batches_beyond_sixteen():
+    """Round 6: the inference plan stopped at batch 16 (the time-embedding MLP keeps 16 batch rows in registers); the reference has
+    no such limit (UNet.py:390-406).  Batch 24 and 40 on a small model == the same images in batches of at most 16."""
+    name = "i64_b32_hc32"
+    m, sd, kw = build(name)
+    gen = torch.Generator().manual_seed(11)
+    for B in (24, 40):
+        x = (torch.rand(B, 1, 64, 64, generator=gen) * 2 - 1).to(DEV)
+        t = torch.randint(0, 1000, (B,), generator=gen).to(DEV)
+        with torch.no_grad():
+            y = m(x, t)
+            parts = torch.cat([m(x[i:i + 16], t[i:i + 16]) for i in range(0, B, 16)])
+        assert y.shape == x.shape and torch.isfinite(y).all()
+        assert ((y - parts).abs().max() / parts.abs().max()).item() < 2e-5
+
+
 def test_config2_with_atomic_groupnorm_sums_matches_reference(monkeypatch):
     """ANODDPM_CSUM=1 (round 6, opt-in: measured +-0 on the step): the 128x128 / 64x64 F(4x4,3x3) layers accumulate
     their GroupNorm sums with fp64 atomics and their F(4x4,3x3) consumers finish the GroupNorm in the prologue -- 24 gn_finalize
