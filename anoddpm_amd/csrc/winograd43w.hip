@@ -6,14 +6,17 @@
 //   wino43r_kernel   8 waves, wave w = all 36 positions x channels 16w..16w+15 x 16 tiles: 144 accumulator registers, two waves
 //                    per SIMD.  Every wave reads all of V (36 ds_read_b128 per chunk) and its own 36 B fragments.
 //   this kernel      4 waves, wave w = all 36 positions x channels 32w..32w+31: 288 accumulator registers (256 of them AGPRs), one
-//                    wave per SIMD.  An A fragment feeds TWO MFMAs (half the LDS fragment reads per MFMA), the B ring is 9
+//                    wave per SIMD.  An A fragment feeds TWO MFMAs (half the LDS fragment reads per MFMA), the B ring is 4 or 6
 //                    positions x 2 fragments deep, and -- with TSPLIT -- the input transform does not run as an MFMA-free block at the
 //                    top of the chunk: each of the wave's three transform passes issues its 12 ds_read2_b64 at one position of the
 //                    MFMA stream and consumes them three positions later, operands resident.
 //
 // The MFMA and VALU instruction totals per SIMD are those of wino43r_kernel (the 768 transform items and 1 536 staging slots of a
 // chunk do not shrink with fewer waves): on this pipe, where the fp32 MFMA and the VALU share the issue port, the kernel can only
-// win what the two-wave structure loses to idle time.  Selected with ANODDPM_DEBUG5=4 (measurement; DESIGN 5f-3 for the result).
+// win what the two-wave structure loses to idle time.  MEASURED (profiles/r6_f43_onewave_ab.txt): 13-19 % slower than
+// wino43r_kernel on every layer shape of config 2 -- the accumulators overflow the 256 AGPRs (68-116 v_accvgpr moves per chunk) and a
+// lone wave has no partner to cover its waits.  Kept as a measurement selector (ANODDPM_DEBUG5 = 4 / 5 / 8 / 9; 6 / 7 in the op
+// tests); no plan selects it.
 #include <type_traits>
 
 #include "common.h"
