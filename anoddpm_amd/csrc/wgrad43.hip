@@ -13,9 +13,11 @@
 // A workgroup = one (32 ci, 64 co) block x a strided set of 16x8-pixel output patches (8 tiles), which it walks one by one:
 //   1. the activated 18x10 input patch (2 chunks of 16 channels) and the dY patch (4 chunks of 16 channels, two at a time) are
 //      staged in LDS from registers loaded one phase ahead (GroupNorm-apply + SiLU, nearest-x2 / concat resolved on the load);
-//   2. all twelve waves transform: V = B^T d B (768 float2 items = 2 chunks x 8 tiles x 8 channel pairs x 6 rows) and
-//      Z = A dY A^T (2 rounds of 768 items); the row-sum role of the Z transform also emits the per-patch column sums of dY
-//      (bias / embedding gradients) for the workgroups of the first input-channel block;
+//   2. all twelve waves transform: V = B^T d B and Z = A dY A^T (two rounds of 32 output channels), one wave-item per wave and
+//      transform -- an item = (tile, channel, ROW PAIR of B^T / A): the pairs (1,2) and (3,4) share their partial sums, so a pair
+//      costs what one row cost (round 6; until round 5: 768 + 2 x 768 single-row items on packed channel pairs); the (1,1,1,1) row
+//      of the Z transform also emits the column sums of dY per tile row of the patch (bias / embedding gradients) for the
+//      workgroups of the first input-channel block;
 //   3. 48 MFMAs per wave: operands are 4-byte LDS reads of V / Z [pos][tile][channel] (16 channels x 4 tiles per wave read).
 // VALU (transforms) and MFMA phases alternate -- on this hardware they share the issue port anyway -- four barriers per patch.
 // The per-workgroup dU goes to a workspace [PG][36][K][N]; two small kernels sum the PG slabs and apply G^T . G.
@@ -37,6 +39,12 @@ __device__ __forceinline__ f32x4 bld4g(__amdgpu_buffer_rsrc_t r, unsigned lane_b
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)wave_bytes, 0));
 }
 
+// WG43_LEGACY=1 (measurement builds, `ANODDPM_EXTRA_FLAGS="wgrad43.hip:-DWG43_LEGACY=1"`): the round 2-5 form of the transforms (one
+// row of B^T d / A dY per item on packed channel pairs, the next patch requested before the last transform) for A/B runs against the
+// round-6 form (row-pair items on single channels, next patch requested behind the last transform: profiles/r6_wgrad43_ab.txt)
+#ifndef WG43_LEGACY
+#define WG43_LEGACY 0
+#endif
 constexpr int G4_NT = 768;
 constexpr int G4_PW = 18;                          // input patch: 18 x 10 pixels (16 x 8 outputs + halo)
 constexpr int G4_PPIX = 180;
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
         for (int j = 0; j < 6; ++j) {
             t[j] = tc0 * D[tr0 * vrow + j * G4_PITCH * 2] + tc1 * D[tr1 * vrow + j * G4_PITCH * 2] + tc2 * D[tr2 * vrow + j * G4_PITCH * 2] +
                    tc3 * D[tr3 * vrow + j * G4_PITCH * 2];
-            __builtin_amdgcn_sched_barrier(0);                      // one column of reads in flight: the registers belong to the accumulators
+            __builtin_amdgcn_sched_barrier(0);   // one column of reads in flight: the registers belong to the accumulators
         }
         const f32x2 p = t[4] - 4.f * t[2], q = t[3] - 4.f * t[1], r = t[4] - t[2], s = t[3] - t[1];
         f32x2 *V = reinterpret_cast<f32x2 *>(ldsV + tslot * G4_V) + ((tu * 6) * G4_TILES + ttile) * 8 + tpair;
@@ -213,6 +221,110 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
         }
     };
 
+    // ---- round 6: transform items that form TWO rows of B^T d / A dY from one set of reads, on SINGLE channels.  The row pairs (1,2)
+    // and (3,4) share their partial sums (u1, u2 = p +- q; u3, u4 = r +- 2 s), (0,5) read disjoint rows: 4 instead of 8 operations and
+    // half the LDS reads per column and row pair, with coefficients that are literals instead of per-wave registers.
+    // lane = (tile column lane >> 4, channel lane & 15), wave = (row pair w % 3, chunk slot (w / 3) & 1, tile row w / 6): V, Z of
+    // round 0 and Z of round 1 are twelve wave-items each -- one per wave and phase, and every SIMD (waves w, w + 4, w + 8) hosts one
+    // wave of each row pair.  150 VGPRs, nothing spilled: the packed-pair form of the same idea (f32x2 items, six wave-items per
+    // phase) kept 24 more registers live and reloaded spills inside the loop -- vmcnt retires in order, so a reload behind the
+    // dY requests waited out their HBM latency in every patch and the step gained nothing (profiles/r6_wgrad43_ab.txt).
+    const int s_tx = lane >> 4, s_ch = lane & 15;
+    const int s_up = wave % 3, s_slot = (wave / 3) & 1, s_trow = wave / 6;
+    constexpr int SP = G4_PITCH * 4, SVROW = G4_PW * SP, SZROW = 16 * SP;           // floats per staged pixel / input row / dY row
+    const int s_vin = ((4 * s_trow) * G4_PW + 4 * s_tx) * SP + s_ch;
+    const int s_zin = ((4 * s_trow) * 16 + 4 * s_tx) * SP + s_ch;
+    const int s_out = (s_trow * 4 + s_tx) * 16 + s_ch;                               // [pos][tile][channel]: + pos * 128
+    const int s_ua = s_up == 0 ? 0 : (s_up == 1 ? 1 : 3), s_ub = s_up == 0 ? 5 : (s_up == 1 ? 2 : 4);
+    auto col_pass_v1 = [&](const float (&t)[6], float *V) {
+        const float p = t[4] - 4.f * t[2], q = t[3] - 4.f * t[1], r = t[4] - t[2], w = t[3] - t[1];
+        V[0 * 128] = 4.f * t[0] - 5.f * t[2] + t[4];
+        V[1 * 128] = p + q;
+        V[2 * 128] = p - q;
+        V[3 * 128] = r + 2.f * w;
+        V[4 * 128] = r - 2.f * w;
+        V[5 * 128] = 4.f * t[1] - 5.f * t[3] + t[5];
+    };
+    auto transform_v_s = [&]() {
+        const float *D = reinterpret_cast<const float *>(ldsPin + s_slot * G4_PIN) + s_vin;
+        float ta[6], tb[6];
+        if (s_up == 0) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float d0 = D[j * SP], d1 = D[SVROW + j * SP], d2 = D[2 * SVROW + j * SP], d3 = D[3 * SVROW + j * SP], d4 = D[4 * SVROW + j * SP], d5 = D[5 * SVROW + j * SP];
+                ta[j] = 4.f * d0 - 5.f * d2 + d4;
+                tb[j] = 4.f * d1 - 5.f * d3 + d5;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (s_up == 1) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float d1 = D[SVROW + j * SP], d2 = D[2 * SVROW + j * SP], d3 = D[3 * SVROW + j * SP], d4 = D[4 * SVROW + j * SP];
+                const float p = d4 - 4.f * d2, q = d3 - 4.f * d1;
+                ta[j] = p + q;
+                tb[j] = p - q;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float d1 = D[SVROW + j * SP], d2 = D[2 * SVROW + j * SP], d3 = D[3 * SVROW + j * SP], d4 = D[4 * SVROW + j * SP];
+                const float r = d4 - d2, w = d3 - d1;
+                ta[j] = r + 2.f * w;
+                tb[j] = r - 2.f * w;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float *V = reinterpret_cast<float *>(ldsV + s_slot * G4_V) + s_out;
+        col_pass_v1(ta, V + s_ua * 6 * 128);
+        col_pass_v1(tb, V + s_ub * 6 * 128);
+    };
+    auto col_pass_z1 = [&](const float (&t)[4], float *Z) {
+        const float e02 = t[0] + t[2], o13 = t[1] + t[3], e024 = t[0] + 4.f * t[2], o138 = 2.f * t[1] + 8.f * t[3];
+        Z[0 * 128] = t[0];
+        Z[1 * 128] = e02 + o13;
+        Z[2 * 128] = e02 - o13;
+        Z[3 * 128] = e024 + o138;
+        Z[4 * 128] = e024 - o138;
+        Z[5 * 128] = t[3];
+    };
+    auto transform_z_s = [&](const int round, const Geo &g) {
+        const float *D = reinterpret_cast<const float *>(ldsPdy + s_slot * G4_PDY) + s_zin;
+        float ta[4], tb[4];
+        if (s_up == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ta[j] = D[j * SP]; tb[j] = D[3 * SZROW + j * SP]; }
+        } else if (s_up == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float e = D[j * SP] + D[2 * SZROW + j * SP], o = D[SZROW + j * SP] + D[3 * SZROW + j * SP];
+                ta[j] = e + o;
+                tb[j] = e - o;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float e = D[j * SP] + 4.f * D[2 * SZROW + j * SP], o = 2.f * D[SZROW + j * SP] + 8.f * D[3 * SZROW + j * SP];
+                ta[j] = e + o;
+                tb[j] = e - o;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int zc = 2 * round + s_slot;
+        float *Z = reinterpret_cast<float *>(ldsZ + zc * G4_V) + s_out;
+        col_pass_z1(ta, Z + s_ua * 6 * 128);
+        col_pass_z1(tb, Z + s_ub * 6 * 128);
+        if (a.colsum != nullptr && kb == 0 && s_up == 1) {          // row (1,1,1,1): ta[j] are the column sums of the lane's tile
+            float cs = (ta[0] + ta[2]) + (ta[1] + ta[3]);
+            cs += __shfl_xor(cs, 16);                                // the wave's four tiles (one tile row of the patch): a column-sum item
+            cs += __shfl_xor(cs, 32);
+            if (s_tx == 0) {
+                const unsigned wave_off = ((((unsigned)g.b * (unsigned)ppi + (unsigned)g.r) * 2u + (unsigned)s_trow) * (unsigned)N + (unsigned)(n0 + zc * 16)) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cs), rCS, (int)(s_ch * 4), (int)wave_off, 0);
+            }
+        }
+    };
     // ---- accumulators: positions 3*wave + p, 2 input-channel tiles x 4 output-channel tiles of 16 x 16
     f32x4 acc[3][2][4];
 #pragma unroll
@@ -237,17 +349,32 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
         load_dy(cur, 1);                                            // requested BEFORE the input staging: its GroupNorm + SiLU pass covers the latency
         store_in(cur);
         __syncthreads();
-        transform_v();
-        transform_z(0, cur);
+        if (WG43_LEGACY) {
+            transform_v();
+            transform_z(0, cur);
+        } else {
+            transform_v_s();
+            transform_z_s(0, cur);
+        }
         __syncthreads();
         store_dy();
         const Geo nxt = advance(cur);                               // prefetch of the next patch
-        load_in(nxt);
-        load_dy(nxt, 0);
+        if (WG43_LEGACY) {
+            load_in(nxt);
+            load_dy(nxt, 0);
+        }
         __syncthreads();
-        transform_z(1, cur);
+        if (WG43_LEGACY) {
+            transform_z(1, cur);
+        } else {
+            transform_z_s(1, cur);
+            load_in(nxt);                                           // requested behind the last transform (no request registers live across
+            load_dy(nxt, 0);                                        // it); the MFMA phase covers the latency: -2.3 % against requesting before it
+        }
         cur = nxt;
         __syncthreads();
+        // (round 6, measured and dropped: the twelve operand reads of position p + 1 issued before the sixteen MFMAs of position p --
+        // 164 VGPRs, no spill -- 10.10-10.12 against 10.00 ms of weight-gradient ops per step; the compiler's own order stays)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const int pos = wave * 3 + p;
@@ -393,13 +520,14 @@ namespace anoddpm {
 
 // Patch groups of the Winograd-domain weight gradient: one workgroup per CU in total (shared with the host side through
 // anoddpm_wgrad43_groups so that the caller can size the workspace: PG * 36 * K * N floats).
-// column-sum items per image = the kernel's 16 x 8 output patches (exported so that callers do not hard-code the patch shape)
-int wgrad43_patches(int H, int W) { return (H / 8) * (W / 16); }
+// column-sum items per image (exported so that callers do not hard-code the item shape)
+// (one item per tile row of a patch, 16 x 4 pixels: a wave of the dY transform holds one tile row; WG43_LEGACY: per 16 x 8 patch)
+int wgrad43_patches(int H, int W) { return (WG43_LEGACY ? H / 8 : H / 4) * (W / 16); }
 
 int wgrad43_groups(int K, int N, int B, int H, int W)
 {
     const int blocks = (K / G4_KB) * (N / G4_NB);
-    const int patches = B * wgrad43_patches(H, W);
+    const int patches = B * (H / 8) * (W / 16);
     int pg = 256 / (blocks > 0 ? blocks : 1);
     if (pg < 1) pg = 1;
     if (pg > patches) pg = patches;
