@@ -58,6 +58,9 @@ __device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned lane_by
 // DBG (timing ablations only, wrong results; ANODDPM_DEBUG2): 1 no epilogue, 2 no input transform, 3 no patch staging, 4 no B requests
 // NTL = 16-channel tiles per workgroup: 8 (128 output channels) or 4 (64 channels: twice the workgroups when the map is too
 // small to fill the 256 CUs with 128-channel ones, at the price of repeating the staging / input transform per 64 channels)
+#ifndef F43_PAIR_TRANSFORM
+#define F43_PAIR_TRANSFORM 0
+#endif
 template <bool FAST, int DBG = 0, int NTL = 8>
 __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_args a)
 {
@@ -180,6 +183,65 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
         V[5 * 128] = 4.f * t[1] - 5.f * t[3] + t[5];
     };
 
+    // Round 6, F43_PAIR_TRANSFORM=1 (measurement builds; measured equal to the single-row items, profiles/r6_f43_pair_transform_ab.txt,
+    // so NOT the default): row-PAIR items on single channels (the form wgrad43.hip runs; profiles/r6_wgrad43_ab.txt): rows (1,2)
+    // and (3,4) of B^T share their partial sums, (0,5) read disjoint patch rows -- 4 operations per column and row pair instead of
+    // 4 per row, literal coefficients.  768 items = 16 tiles x 16 channels x 3 row pairs: wave w = (row pair w % 3, tile row w / 3),
+    // lane = (tile column lane >> 4, channel lane & 15).
+    const int p_up = wave % 3;
+    const int p_tx = lane >> 4, p_ch = lane & 15;
+    constexpr int PP = F4_PITCH * 4, PROW = F4_PW * PP;             // floats per staged pixel / patch row
+    const int p_in = ((4 * (wave / 3)) * F4_PW + 4 * p_tx) * PP + p_ch;
+    const int p_out = ((wave / 3) * 4 + p_tx) * 16 + p_ch;          // V[pos][tile][channel]: + pos * 256
+    const int p_ua = p_up == 0 ? 0 : (p_up == 1 ? 1 : 3), p_ub = p_up == 0 ? 5 : (p_up == 1 ? 2 : 4);
+    auto col_pass = [&](const float (&t)[6], float *V) {
+        const float p = t[4] - 4.f * t[2], q = t[3] - 4.f * t[1], r = t[4] - t[2], w = t[3] - t[1];
+        V[0 * 256] = 4.f * t[0] - 5.f * t[2] + t[4];
+        V[1 * 256] = p + q;
+        V[2 * 256] = p - q;
+        V[3 * 256] = r + 2.f * w;
+        V[4 * 256] = r - 2.f * w;
+        V[5 * 256] = 4.f * t[1] - 5.f * t[3] + t[5];
+    };
+    auto transform_p = [&](int pbuf, int vbuf) {
+        const float *D = reinterpret_cast<const float *>(ldsD + pbuf * F4_DT) + p_in;
+        float ta[6], tb[6];
+        if (p_up == 0) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float d0 = D[j * PP], d1 = D[PROW + j * PP], d2 = D[2 * PROW + j * PP], d3 = D[3 * PROW + j * PP], d4 = D[4 * PROW + j * PP], d5 = D[5 * PROW + j * PP];
+                ta[j] = 4.f * d0 - 5.f * d2 + d4;
+                tb[j] = 4.f * d1 - 5.f * d3 + d5;
+                __builtin_amdgcn_sched_barrier(0);                  // one column of reads in flight (see transform())
+            }
+        } else if (p_up == 1) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float d1 = D[PROW + j * PP], d2 = D[2 * PROW + j * PP], d3 = D[3 * PROW + j * PP], d4 = D[4 * PROW + j * PP];
+                const float p = d4 - 4.f * d2, q = d3 - 4.f * d1;
+                ta[j] = p + q;
+                tb[j] = p - q;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float d1 = D[PROW + j * PP], d2 = D[2 * PROW + j * PP], d3 = D[3 * PROW + j * PP], d4 = D[4 * PROW + j * PP];
+                const float r = d4 - d2, w = d3 - d1;
+                ta[j] = r + 2.f * w;
+                tb[j] = r - 2.f * w;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float *V = reinterpret_cast<float *>(ldsV + vbuf * F4_V) + p_out;
+        col_pass(ta, V + p_ua * 6 * 256);
+        col_pass(tb, V + p_ub * 6 * 256);
+    };
+    auto transform_sel = [&](int pbuf, int vbuf) {
+        if (F43_PAIR_TRANSFORM) transform_p(pbuf, vbuf);
+        else                    transform(pbuf, vbuf);
+    };
+
     // ---- accumulators: positions 3*wave + {0,1,2} x 8 channel tiles of 16
     f32x4 acc[3][NTL];
 #pragma unroll
@@ -241,7 +303,7 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
         for (int j = 0; j < F4_PJ; ++j) praw[j] = keep[j];
     }
     __syncthreads();
-    transform(0, 0);
+    transform_sel(0, 0);
     store_patch(1, c1);
     load_patch(c2);
     __syncthreads();
@@ -253,7 +315,7 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
     //   T  V(c+1) <- patch(c+1)      groups 0..5      S  patch(c+2) -> LDS (requested in iteration c-1)
     //   groups 6..17                 L  request patch(c+3)                groups 18..23      barrier
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        if (DBG != 2) transform((chunk + 1) & 1, (chunk + 1) & 1);
+        if (DBG != 2) transform_sel((chunk + 1) & 1, (chunk + 1) & 1);
         const f32x4 *V = ldsV + (chunk & 1) * F4_V + vread;
         const int nxt = chunk < last ? chunk + 1 : last;            // clamped: the tail re-loads valid memory, unused
         const int s2 = chunk + 2 <= last ? chunk + 2 : last, l3 = chunk + 3 <= last ? chunk + 3 : last;

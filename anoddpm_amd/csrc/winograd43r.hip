@@ -80,10 +80,19 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4])
 // VAR (correct results; measurement switches of round 6): bit 0 = the two waves of a SIMD transform half a chunk apart (waves
 // 4..7 run T at position 18 instead of before position 0, so that a SIMD's MFMA-free transform block of one wave sits beside the
 // other wave's MFMAs); bit 1 = input transform in scalar f32 (v_fma_f32 with SGPR coefficients) instead of packed f32
+// F43_PAIR_TRANSFORM=1 (measurement builds, ANODDPM_EXTRA_FLAGS): the product launches use the row-pair input transform (VAR bit 5)
+#ifndef F43_PAIR_TRANSFORM
+#define F43_PAIR_TRANSFORM 0
+#endif
+constexpr int R4_VAR = F43_PAIR_TRANSFORM ? 32 : 0;
 template <bool FAST, int DBG = 0, int R4_RING = 6, int NPOS = 36, int VAR = 0>
 __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_args a)
 {
     constexpr bool V_DEPHASE = (VAR & 1) != 0, V_SCALAR_T = (VAR & 2) != 0;
+    // bit 5 = row-pair items on single channels for the input transform (round 6, transform_p below): half the transform's VALU
+    // work, 241 instead of 253 VGPRs, all F43 op tests green -- and the class, the step and the per-layer times do not move
+    // (profiles/r6_f43_pair_transform_ab.txt): the kernel does not wait for the transform's issue slots
+    constexpr bool V_PAIRS = (VAR & 32) != 0;
     // bit 2 = the MFMAs of two positions interleaved (consecutive MFMAs on different accumulators: no dependent back-to-back chain
     // when the SIMD's other wave is not issuing MFMAs); bit 3 = static s_setprio 1 for the younger half (waves 4..7)
     constexpr bool V_PAIR = (VAR & 4) != 0, V_PRIO = (VAR & 8) != 0;
@@ -241,8 +250,65 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
         V[4 * 128] = f32x2{rx - 2.f * sx, ry - 2.f * sy};
         V[5 * 128] = f32x2{4.f * tx[1] - 5.f * tx[3] + tx[5], 4.f * ty[1] - 5.f * ty[3] + ty[5]};
     };
+    // Round 6 (VAR bit 5, measured equal: not the default): items that form TWO rows of B^T d from one set of reads, on SINGLE channels (the form wgrad43.hip runs:
+    // profiles/r6_wgrad43_ab.txt).  Rows (1,2) and (3,4) share their partial sums (u1, u2 = p +- q with p = d4 - 4 d2, q = d3 - 4 d1;
+    // u3, u4 = r +- 2 s with r = d4 - d2, s = d3 - d1) and (0,5) read disjoint patch rows: 4 operations per column and row PAIR where
+    // the single-row items above spend 4 per row, literal coefficients instead of eight coefficient registers, 24-36 4-byte LDS
+    // reads per pair instead of 2 x 24 8-byte ones.  768 items = 16 tiles x 16 channels x 3 row pairs = twelve virtual waves
+    // (row pair v % 3, tile row v / 3); lane = (tile column lane >> 4, channel lane & 15).  Physical wave w runs virtual wave w;
+    // waves 2..5 also run virtual wave w + 6 -- the same row pair two tile rows further down -- so every SIMD hosts three passes.
+    const int p_up = wave % 3;                                      // 0: rows (0,5), 1: (1,2), 2: (3,4)
+    const int p_tx = lane >> 4, p_ch = lane & 15;
+    constexpr int PP = R4_PITCH * 4, PROW = R4_PW * PP;             // floats per staged pixel / patch row
+    const int p_in = ((4 * (wave / 3)) * R4_PW + 4 * p_tx) * PP + p_ch;
+    const int p_out = ((wave / 3) * 4 + p_tx) * 16 + p_ch;          // V[pos][tile][channel]: + pos * 256
+    const int p_ua = p_up == 0 ? 0 : (p_up == 1 ? 1 : 3), p_ub = p_up == 0 ? 5 : (p_up == 1 ? 2 : 4);
+    constexpr int PASS_DP = 8 * PROW, PASS_VP = 2 * 4 * 16;         // second pass: tile row + 2
+    auto col_pass = [&](const float (&t)[6], float *V) {
+        const float p = t[4] - 4.f * t[2], q = t[3] - 4.f * t[1], r = t[4] - t[2], w = t[3] - t[1];
+        V[0 * 256] = 4.f * t[0] - 5.f * t[2] + t[4];
+        V[1 * 256] = p + q;
+        V[2 * 256] = p - q;
+        V[3 * 256] = r + 2.f * w;
+        V[4 * 256] = r - 2.f * w;
+        V[5 * 256] = 4.f * t[1] - 5.f * t[3] + t[5];
+    };
+    auto transform_p = [&](int pbuf, int vbuf, int dofs, int vofs) {
+        const float *D = reinterpret_cast<const float *>(ldsD + pbuf * R4_DT) + p_in + dofs;
+        float ta[6], tb[6];
+        if (p_up == 0) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float d0 = D[j * PP], d1 = D[PROW + j * PP], d2 = D[2 * PROW + j * PP], d3 = D[3 * PROW + j * PP], d4 = D[4 * PROW + j * PP], d5 = D[5 * PROW + j * PP];
+                ta[j] = 4.f * d0 - 5.f * d2 + d4;
+                tb[j] = 4.f * d1 - 5.f * d3 + d5;
+            }
+        } else if (p_up == 1) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float d1 = D[PROW + j * PP], d2 = D[2 * PROW + j * PP], d3 = D[3 * PROW + j * PP], d4 = D[4 * PROW + j * PP];
+                const float p = d4 - 4.f * d2, q = d3 - 4.f * d1;
+                ta[j] = p + q;
+                tb[j] = p - q;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float d1 = D[PROW + j * PP], d2 = D[2 * PROW + j * PP], d3 = D[3 * PROW + j * PP], d4 = D[4 * PROW + j * PP];
+                const float r = d4 - d2, w = d3 - d1;
+                ta[j] = r + 2.f * w;
+                tb[j] = r - 2.f * w;
+            }
+        }
+        float *V = reinterpret_cast<float *>(ldsV + vbuf * R4_V) + p_out + vofs;
+        col_pass(ta, V + p_ua * 6 * 256);
+        col_pass(tb, V + p_ub * 6 * 256);
+    };
     auto transform_all = [&](int pbuf, int vbuf) {
-        if (V_SCALAR_T) {
+        if (V_PAIRS) {
+            transform_p(pbuf, vbuf, 0, 0);
+            if (two_pass) transform_p(pbuf, vbuf, PASS_DP, PASS_VP);
+        } else if (V_SCALAR_T) {
             transform_s(pbuf, vbuf, 0, 0);
             if (two_pass) transform_s(pbuf, vbuf, PASS_D, PASS_V);
         } else {
@@ -552,12 +618,14 @@ int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
     else if (fast && dbg == 36) hipLaunchKernelGGL((wino43r_kernel<true, 0, 6, 36, 5>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 37) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9, 36, 8>), grid, dim3(R4_NT), 0, s, *a);
     else if (fast && dbg == 38) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9, 36, 9>), grid, dim3(R4_NT), 0, s, *a);
+    else if (fast && dbg == 40) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9, 36, 32>), grid, dim3(R4_NT), 0, s, *a);   // row-pair input transform
+    else if (fast && dbg == 41) hipLaunchKernelGGL((wino43r_kernel<true, 0, 12, 36, 32>), grid, dim3(R4_NT), 0, s, *a);   // ... with a twelve-deep B ring (the registers it frees)
     else
 #endif
     // nine B fragments in flight (250 VGPRs) for the GroupNorm + SiLU form: 9.05 -> 9.01 ms per config-2 step over six (round 5,
     // once the per-chunk vmcnt(0) drain was gone; the depth must divide 36); the plain form sits at 247 VGPRs with six
-    if (fast) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9>), grid, dim3(R4_NT), 0, s, *a);
-    else      hipLaunchKernelGGL((wino43r_kernel<false>), grid, dim3(R4_NT), 0, s, *a);
+    if (fast) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9, 36, R4_VAR>), grid, dim3(R4_NT), 0, s, *a);
+    else      hipLaunchKernelGGL((wino43r_kernel<false, 0, 6, 36, R4_VAR>), grid, dim3(R4_NT), 0, s, *a);
     return check_launch("winograd43r");
 }
 
