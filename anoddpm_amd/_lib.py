@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ANODDPM_LIB_TAG=<tag>: load lib/libanoddpm_hip_<tag>.so instead -- a second build of the same sources with other compiler flags
 # (ANODDPM_BUILD_TAG / ANODDPM_EXTRA_FLAGS of anoddpm_amd.build), for A/B measurements of one gpurun session.  Same ABI, same checks.
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip%s.so" % ("_" + os.environ["ANODDPM_LIB_TAG"] if os.environ.get("ANODDPM_LIB_TAG") else ""))
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 (OP_WGRAD3, OP_WGRAD1, OP_GN_BWD, OP_PACK, OP_SOFTMAX_BWD, OP_TRANSPOSE, OP_LINEAR_BWD, OP_STEM_BWD, OP_HEAD_BWD,
@@ -52,7 +52,10 @@ class IgemmArgs(Structure):
                 ("tail_c1", c_int32), ("tail_groups", c_int32), ("tail_eps", c_float),
                 ("fold_stats0", c_void_p), ("fold_stats1", c_void_p), ("fold_gamma", c_void_p), ("fold_beta", c_void_p),
                 ("fold_rows0", c_int32), ("fold_rows1", c_int32), ("fold_fmt0", c_int32), ("fold_fmt1", c_int32),
-                ("fold_groups", c_int32), ("fold_eps", c_float), ("res_mode", c_int32), ("stats_csum", c_void_p)]
+                ("fold_groups", c_int32), ("fold_eps", c_float), ("res_mode", c_int32), ("stats_csum", c_void_p),
+                ("gnb_partial", c_void_p), ("gnb_x0", c_void_p), ("gnb_x1", c_void_p), ("gnb_gamma", c_void_p), ("gnb_beta", c_void_p),
+                ("gnb_mean", c_void_p), ("gnb_rstd", c_void_p), ("gnb_x0_bs", c_int64), ("gnb_x1_bs", c_int64),
+                ("gnb_c0", c_int32), ("gnb_x0_ld", c_int32), ("gnb_x1_ld", c_int32), ("gnb_groups", c_int32)]
 
 
 class GnArgs(Structure):
@@ -186,7 +189,7 @@ class GnBwdArgs(Structure):
                 ("dx0_ld", c_int32), ("dx1_ld", c_int32), ("Hs", c_int32), ("Ws", c_int32),
                 ("B", c_int32), ("groups", c_int32), ("nslab", c_int32),
                 ("act", c_int32), ("a_mode", c_int32), ("acc_dx", c_int32),
-                ("dres", c_void_p), ("dres_bs", c_int64), ("dres_ld", c_int32)]
+                ("dres", c_void_p), ("dres_bs", c_int64), ("dres_ld", c_int32), ("partial_ready", c_int32)]
 
 
 class Wgrad1Args(Structure):
@@ -258,7 +261,7 @@ SYMBOLS = [
     "anoddpm_simplex_perm_init", "anoddpm_simplex3_octaves_f64", "anoddpm_simplex3_octaves_f32",
     "anoddpm_simplex3_grid_f64", "anoddpm_simplex2_octaves_f64", "anoddpm_simplex2_grid_f64",
     "anoddpm_q_sample", "anoddpm_p_sample_update", "anoddpm_chain_advance",
-    "anoddpm_igemm", "anoddpm_smallmap_tile", "anoddpm_wino23s_tile", "anoddpm_pack_wino43_bf16x3", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
+    "anoddpm_igemm", "anoddpm_f43_channel_sliced", "anoddpm_smallmap_tile", "anoddpm_wino23s_tile", "anoddpm_pack_wino43_bf16x3", "anoddpm_gn_stats", "anoddpm_chan_stats", "anoddpm_gn_finalize", "anoddpm_softmax_rows", "anoddpm_resample2x",
     "anoddpm_linear_small", "anoddpm_posemb", "anoddpm_conv_stem", "anoddpm_stem_stats_rows", "anoddpm_conv_head", "anoddpm_nhwc_to_nchw",
     "anoddpm_run_ops", "anoddpm_prof_enable", "anoddpm_prof_active", "anoddpm_prof_collect", "anoddpm_prof_list",
     "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map", "anoddpm_vlb_terms", "anoddpm_conv3x3_wgrad", "anoddpm_gn_silu_backward", "anoddpm_pack_conv3x3",
@@ -351,6 +354,7 @@ def lib():
     L.anoddpm_loss_backward.argtypes = [POINTER(LossArgs), c_void_p]
     L.anoddpm_conv3x3_wgrad.argtypes = [POINTER(WgradArgs), c_void_p]
     L.anoddpm_wgrad43_groups.argtypes = [c_int32] * 5
+    L.anoddpm_f43_channel_sliced.argtypes = [c_int32] * 4
     L.anoddpm_wgrad43_patches.argtypes = [c_int32] * 2
     L.anoddpm_gn_silu_backward.argtypes = [POINTER(GnBwdArgs), c_void_p]
     L.anoddpm_pack_conv3x3.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]

@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(anoddpm_gn_bwd_args a
 template <int A_MODE, bool ACT>
 void launch_reduce_apply(const anoddpm_gn_bwd_args *a, hipStream_t s, int slabs, int sp)
 {
-    hipLaunchKernelGGL((gn_bwd_reduce_kernel<A_MODE, ACT>), dim3(a->nslab, a->B), dim3(256), 0, s, *a);
+    if (!a->partial_ready)                                            // else: written by the epilogue of the data-gradient launch
+        hipLaunchKernelGGL((gn_bwd_reduce_kernel<A_MODE, ACT>), dim3(a->nslab, a->B), dim3(256), 0, s, *a);
     hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(a->groups), dim3(256), 0, s, *a);
     hipLaunchKernelGGL((gn_bwd_apply_kernel<A_MODE, ACT>), dim3((unsigned)slabs, a->B), dim3(256), 0, s, *a, sp);
 }
@@ -330,6 +331,7 @@ extern "C" int anoddpm_gn_silu_backward(const anoddpm_gn_bwd_args *a, void *stre
     ANODDPM_REQUIRE(a->c0 > 0 && a->c0 % 4 == 0 && a->c1 >= 0 && a->c1 % 4 == 0 && (a->c1 == 0 || (a->x1 && a->dx1)), "gn_silu_backward: bad channel counts");
     ANODDPM_REQUIRE(a->groups > 0 && C % a->groups == 0 && C / a->groups <= 64, "gn_silu_backward: bad group size");
     ANODDPM_REQUIRE(a->B > 0 && a->B <= 65535 && a->Hs > 0 && a->Ws > 0 && a->nslab > 0 && a->nslab <= 65535, "gn_silu_backward: bad sizes");
+    ANODDPM_REQUIRE(!a->partial_ready || (a->a_mode == 0 && a->act == 1), "gn_silu_backward: partial_ready needs a_mode 0 and the SiLU form");
     ANODDPM_REQUIRE(a->a_mode >= 0 && a->a_mode <= 2 && (a->a_mode != 2 || (a->Hs % 2 == 0 && a->Ws % 2 == 0)), "gn_silu_backward: bad a_mode");
     ANODDPM_REQUIRE(!a->dres || (a->dres_ld % 4 == 0 && a->dres_bs % 4 == 0), "gn_silu_backward: dres strides must be multiples of 4 floats");
     ANODDPM_REQUIRE(a->x0_ld % 4 == 0 && a->da_ld % 4 == 0 && a->dx0_ld % 4 == 0 && (a->c1 == 0 || (a->x1_ld % 4 == 0 && a->dx1_ld % 4 == 0)),

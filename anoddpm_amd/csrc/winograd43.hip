@@ -492,6 +492,8 @@ __global__ __launch_bounds__(F4_NT, 1) void wino43_kernel(const anoddpm_igemm_ar
 
 }  // namespace
 
+extern "C" int anoddpm_f43_channel_sliced(int32_t H, int32_t W, int32_t N, int32_t B);
+
 namespace anoddpm {
 
 // Called by anoddpm_igemm for cfg == 3 (common arguments already validated there).
@@ -523,6 +525,8 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
     // (batch 5, the detection loop's five chains): one round of 128-channel workgroups, 1.0, against two rounds of halves, 1.42
     const int64_t wg128 = (int64_t)(a->H / 16) * (a->W / 16) * (a->N / 128) * a->B;
     const bool half = (a->N % 128 != 0) || ((2 * wg128 + 255) / 256) * 71 < ((wg128 + 255) / 256) * 100;
+    ANODDPM_REQUIRE(!a->gnb_partial || (a->ksplit == 1 && anoddpm_f43_channel_sliced(a->H, a->W, a->N, a->B) == 1),
+                    "winograd43: gnb_partial needs the channel-sliced 128-channel kernel (anoddpm_f43_channel_sliced) and ksplit 1");
     const int nblk = half ? 64 : 128;
     dim3 grid((unsigned)((a->H / 16) * (a->W / 16)), (unsigned)(a->N / nblk), (unsigned)a->B);
     ANODDPM_REQUIRE(a->B <= 65535, "winograd43: batch too large");
@@ -570,3 +574,15 @@ int launch_winograd43(const anoddpm_igemm_args *a, hipStream_t s)
 }
 
 }  // namespace anoddpm
+
+extern "C" int anoddpm_f43_channel_sliced(int32_t H, int32_t W, int32_t N, int32_t B)
+{
+    if (H <= 0 || W <= 0 || N <= 0 || B <= 0 || H % 16 || W % 16 || N % 128) return 0;
+    const int64_t wg128 = (int64_t)(H / 16) * (W / 16) * (N / 128) * B;      // the rule of launch_winograd43 (ksplit 1)
+    const bool half = ((2 * wg128 + 255) / 256) * 71 < ((wg128 + 255) / 256) * 100;
+    const int v5 = anoddpm::g_debug[5];                                        // ANODDPM_DEBUG5: 0 in normal operation
+#ifdef ANODDPM_ABLATE
+    if (anoddpm::g_debug[2] != 0) return 0;
+#endif
+    return ((!half && v5 == 0) || v5 == 3) ? 1 : 0;                            // 3: the op tests' selector (small shapes)
+}

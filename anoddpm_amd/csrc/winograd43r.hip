@@ -85,7 +85,10 @@ __device__ __forceinline__ void at6(const float (&m)[6], float (&o)[4])
 #define F43_PAIR_TRANSFORM 0
 #endif
 constexpr int R4_VAR = F43_PAIR_TRANSFORM ? 32 : 0;
-template <bool FAST, int DBG = 0, int R4_RING = 6, int NPOS = 36, int VAR = 0>
+// GNB (round 6, training): the launch is a data gradient and its epilogue also performs the reduction pass of the GroupNorm + SiLU
+// backward (anoddpm_igemm_args.gnb_*): the GroupNorm's input x rides in the residual slot of the epilogue (same requests, same
+// registers: a data gradient has no residual), and per stored value the lane forms dy = da * silu'(y), xhat and their two sums.
+template <bool FAST, int DBG = 0, int R4_RING = 6, int NPOS = 36, int VAR = 0, bool GNB = false>
 __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_args a)
 {
     constexpr bool V_DEPHASE = (VAR & 1) != 0, V_SCALAR_T = (VAR & 2) != 0;
@@ -458,20 +461,25 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
     const float *TE = (a.temb && !part) ? a.temb + (int64_t)b * a.temb_ld : nullptr;
     const __amdgpu_buffer_rsrc_t rO = part ? rsrc(a.ws + ((int64_t)ksi * a.B + b) * ((int64_t)H * W * N))
                                            : rsrc(a.out + (int64_t)b * a.o_bs);
-    const __amdgpu_buffer_rsrc_t rR = rsrc(a.res ? a.res + (int64_t)b * a.r_bs : a.out);
-    const bool has_res = a.res != nullptr && !part;
-    const unsigned uW = (unsigned)W, o_ld = part ? (unsigned)N : (unsigned)a.out_ld, r_ld = (unsigned)a.res_ld;
+    // GNB: this wave's 16 channels of x come from the first or the second concatenated source (gnb_c0 % 16 == 0: wave-uniform)
+    const bool gx_first = !GNB || n0 + wave * 16 < a.gnb_c0;
+    const float *gx = !GNB ? nullptr : (gx_first ? a.gnb_x0 + (int64_t)b * a.gnb_x0_bs : a.gnb_x1 + (int64_t)b * a.gnb_x1_bs);
+    const __amdgpu_buffer_rsrc_t rR = GNB ? rsrc(gx) : rsrc(a.res ? a.res + (int64_t)b * a.r_bs : a.out);
+    const bool has_res = GNB || (a.res != nullptr && !part);
+    const unsigned uW = (unsigned)W, o_ld = part ? (unsigned)N : (unsigned)a.out_ld;
+    const unsigned r_ld = GNB ? (unsigned)(gx_first ? a.gnb_x0_ld : a.gnb_x1_ld) : (unsigned)a.res_ld;
     const float alpha = part ? 1.0f : a.alpha;
     float add = 0.f;
     if (a.bias && !part) add += a.bias[nw];
     if (TE) add += TE[nw];
     // per-lane byte offset of tile (kq, 0)'s first pixel; tile r and pixel (i, j) add the wave-uniform (r*4 + i*W + j) pixels
     const unsigned pix0 = (unsigned)(y0 + kq * 4) * uW + (unsigned)x0;
-    const unsigned vo = (pix0 * o_ld + (unsigned)nw) * 4u, vr = (pix0 * r_ld + (unsigned)nw) * 4u;
+    const unsigned nwr = GNB ? (unsigned)(gx_first ? nw : nw - a.gnb_c0) : (unsigned)nw;      // channel within the residual / x source
+    const unsigned vo = (pix0 * o_ld + (unsigned)nw) * 4u, vr = (pix0 * r_ld + nwr) * 4u;
     // res_mode 1: the residual lives at half resolution (nearest x2 on the read): a 4 x 4 output tile reads its 2 x 2 source pixels
-    const bool res_up = a.res_mode == 1;
+    const bool res_up = !GNB && a.res_mode == 1;
     const unsigned hW = uW >> 1;
-    const unsigned vrh = ((((unsigned)(y0 + kq * 4) >> 1) * hW + ((unsigned)x0 >> 1)) * r_ld + (unsigned)nw) * 4u;
+    const unsigned vrh = ((((unsigned)(y0 + kq * 4) >> 1) * hW + ((unsigned)x0 >> 1)) * r_ld + nwr) * 4u;
     auto load_res = [&](int r, float (&rv)[16]) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) rv[i] = 0.f;
@@ -510,6 +518,15 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
         return;
     }
     float cs = 0.f, cq = 0.f;
+    // GNB: y = g_sc * x + g_sh (g_sc = gamma * rstd), xhat = (x - g_mu) * g_rs, as anoddpm_gn_silu_backward's chan_params
+    float g_sc = 0.f, g_sh = 0.f, g_mu = 0.f, g_rs = 0.f;
+    if (GNB) {
+        const int grp = nw / (N / a.gnb_groups);
+        g_mu = a.gnb_mean[(int64_t)b * a.gnb_groups + grp];
+        g_rs = a.gnb_rstd[(int64_t)b * a.gnb_groups + grp];
+        g_sc = a.gnb_gamma[nw] * g_rs;
+        g_sh = a.gnb_beta[nw] - g_mu * g_sc;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         if (r + 1 < 4) load_res(r + 1, rv[(r + 1) & 1]);           // the next tile's residual pixels ride behind this tile's arithmetic
@@ -531,15 +548,34 @@ __global__ __launch_bounds__(R4_NT, 1) void wino43r_kernel(const anoddpm_igemm_a
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned so = ((unsigned)(r * 4) + (unsigned)i * uW + (unsigned)j) * 4u;      // wave-uniform pixel offset (x ld below)
-                const float v = alpha * o4[j] + add + rv[r & 1][i * 4 + j];
+                const float v = GNB ? alpha * o4[j] + add : alpha * o4[j] + add + rv[r & 1][i * 4 + j];
                 if (DBG != 25 || (r == 0 && i == 0 && j == 0))      // DBG 25: one store per lane instead of 64
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rO, (int)vo, (int)(so * o_ld), STORE_AUX);
-                cs += v;
-                cq += v * v;
+                if (GNB) {                                          // v = da at this pixel, rv = x: the two sums of the reduction pass
+                    const float x = rv[r & 1][i * 4 + j];
+                    const float y = x * g_sc + g_sh;
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+                    const float dyv = v * (sg * (1.0f + y * (1.0f - sg)));
+                    cs += dyv;
+                    cq += dyv * ((x - g_mu) * g_rs);
+                } else {
+                    cs += v;
+                    cq += v * v;
+                }
             }
         }
     }
-    if ((a.stats || a.stats_csum) && !part) {
+    if (GNB) {
+        cs += __shfl_xor(cs, 16);
+        cq += __shfl_xor(cq, 16);
+        cs += __shfl_xor(cs, 32);
+        cq += __shfl_xor(cq, 32);
+        if (kq == 0) {                                              // partial[b][tile][channel] = {sum dy, sum dy * xhat}
+            double *pp = a.gnb_partial + (((int64_t)b * gridDim.x + tile) * N + nw) * 2;
+            pp[0] = (double)cs;
+            pp[1] = (double)cq;
+        }
+    } else if ((a.stats || a.stats_csum) && !part) {
         // the lane's 64 outputs of channel nw; the four kq lane groups hold the other tiles of the same channel
         cs += __shfl_xor(cs, 16);
         cq += __shfl_xor(cq, 16);
@@ -624,6 +660,17 @@ int launch_winograd43r(const anoddpm_igemm_args *a, hipStream_t s)
 #endif
     // nine B fragments in flight (250 VGPRs) for the GroupNorm + SiLU form: 9.05 -> 9.01 ms per config-2 step over six (round 5,
     // once the per-chunk vmcnt(0) drain was gone; the depth must divide 36); the plain form sits at 247 VGPRs with six
+    if (a->gnb_partial) {
+        ANODDPM_REQUIRE(!fast && !a->gn_scale && !a->fold_gamma && !a->act && a->ksplit == 1 && !a->res && !a->bias && !a->temb && !a->stats && !a->stats_csum,
+                        "winograd43r: gnb_partial needs a plain data-gradient launch (no gn / act / bias / temb / res / stats, ksplit 1)");
+        ANODDPM_REQUIRE(a->gnb_x0 && a->gnb_gamma && a->gnb_beta && a->gnb_mean && a->gnb_rstd && a->gnb_groups > 0 && a->N % a->gnb_groups == 0 &&
+                        a->gnb_c0 > 0 && a->gnb_c0 % 16 == 0 && a->gnb_c0 <= a->N && (a->gnb_c0 == a->N || a->gnb_x1),
+                        "winograd43r: gnb_partial: bad GroupNorm arguments");
+        ANODDPM_REQUIRE((int64_t)a->H * a->W * (a->gnb_x0_ld > a->gnb_x1_ld ? a->gnb_x0_ld : a->gnb_x1_ld) * 4 < ((int64_t)1 << 31),
+                        "winograd43r: gnb_partial: source slice exceeds 32-bit buffer offsets");
+        hipLaunchKernelGGL((wino43r_kernel<false, 0, 6, 36, R4_VAR, true>), grid, dim3(R4_NT), 0, s, *a);
+        return check_launch("winograd43r");
+    }
     if (fast) hipLaunchKernelGGL((wino43r_kernel<true, 0, 9, 36, R4_VAR>), grid, dim3(R4_NT), 0, s, *a);
     else      hipLaunchKernelGGL((wino43r_kernel<false, 0, 6, 36, R4_VAR>), grid, dim3(R4_NT), 0, s, *a);
     return check_launch("winograd43r");

@@ -318,14 +318,19 @@ class TrainPlan(_Plan):
         st.P, st.N, st.B, st.act, st.gn_ld, st.span, st.accumulate = P, N, B, act, K, span, 1
         self.badd(_lib.OP_WGRAD1, st)
 
-    def gn_bwd(self, srcs, Hs, da, da_P, gnp, prefix, act, a_mode, dres=None):
-        """Backward of the fused GroupNorm(+SiLU)(+resample) operand load into the gradients of its sources."""
+    def gn_bwd(self, srcs, Hs, da, da_P, gnp, prefix, act, a_mode, dres=None, fused=None):
+        """Backward of the fused GroupNorm(+SiLU)(+resample) operand load into the gradients of its sources.
+        fused = (partial buffer, rows per image) when the data-gradient launch that produced `da` already wrote the
+        reduction pass's partial sums (dgrad3(..., gnb=...)): fold + elementwise launches only."""
         B = self.B
         c0 = srcs[0][1]
         c1 = srcs[1][1] if len(srcs) > 1 else 0
         C = c0 + c1
         P = Hs * Hs
         nslab = max(1, min(int(os.environ.get("ANODDPM_GNBWD_SLABS", 256)), P // 16))     # >= 4 workgroups per CU on the large maps
+        if fused is not None:
+            assert a_mode == 0 and act == 1
+            nslab = fused[1]
         ga = GnBwdArgs()
         ga.x0 = srcs[0][0].data_ptr()
         ga.x1 = srcs[1][0].data_ptr() if c1 else None
@@ -342,9 +347,10 @@ class TrainPlan(_Plan):
         else:
             ga.dx1 = None
         ga.dgamma, ga.dbeta = self.dW(prefix + ".weight"), self.dW(prefix + ".bias")
-        part = self.buf(B * nslab * C * 2, dtype=torch.float64)
+        part = fused[0] if fused is not None else self.buf(B * nslab * C * 2, dtype=torch.float64)
         coef = self.buf(B * C * 4)
         ga.partial, ga.coef = part.data_ptr(), coef.data_ptr()
+        ga.partial_ready = 1 if fused is not None else 0
         ga.x0_bs, ga.x1_bs, ga.da_bs, ga.dx0_bs, ga.dx1_bs = P * c0, P * c1, da_P * C, P * c0, P * c1
         ga.c0, ga.c1, ga.x0_ld, ga.x1_ld, ga.da_ld, ga.dx0_ld, ga.dx1_ld = c0, c1, c0, (c1 if c1 else 4), C, c0, (c1 if c1 else 4)
         ga.Hs, ga.Ws, ga.B, ga.groups, ga.nslab = Hs, Hs, B, 32, nslab
@@ -397,12 +403,37 @@ class TrainPlan(_Plan):
                        bias=bias(bkey),
                        temb=temb_ptr, temb_ld=temb_ld, res=res, res_up=res_up, out=out, want_stats=True)
 
-        def dgrad3(dy, Hout, Kc, N, wkey):
-            """da [B][Hout^2][Kc] = conv3x3(dy, flipped / transposed weights): the forward kernels on the packed twin."""
+        fuse_gnb = os.environ.get("ANODDPM_NO_GNB_FUSE", "0") != "1"
+
+        def dgrad3(dy, Hout, Kc, N, wkey, gnb=None):
+            """da [B][Hout^2][Kc] = conv3x3(dy, flipped / transposed weights): the forward kernels on the packed twin.
+            gnb = (sources, gn_t tuple, GroupNorm prefix) of the operand a = SiLU(GroupNorm(x)) this gradient belongs to: where the
+            launch runs on the channel-sliced F(4x4,3x3) kernel its epilogue also writes the partial sums of the GroupNorm
+            backward's reduction pass (round 6: one pass over x and da less per layer); returns (da, fused) for gn_bwd."""
             da = self.buf(B, Hout * Hout, Kc)
-            self.igemm(srcs=[(dy, N)], H=Hout, W=Hout, ks=3, N=Kc, bmat=lambda: self.pack(wkey, 0, bwd=1),
-                       wino=lambda: self.pack(wkey, 1, bwd=1), wino43=lambda: self.pack(wkey, 5, bwd=1), out=da)
-            return da
+            st = self.igemm(srcs=[(dy, N)], H=Hout, W=Hout, ks=3, N=Kc, bmat=lambda: self.pack(wkey, 0, bwd=1),
+                            wino=lambda: self.pack(wkey, 1, bwd=1), wino43=lambda: self.pack(wkey, 5, bwd=1), out=da)
+            st.gnb_partial = None
+            if gnb is None:
+                return da
+            fused = None
+            xs, gnp, gprefix = gnb
+            xc0 = xs[0][1]
+            if (fuse_gnb and st.cfg == 3 and st.ksplit == 1 and xc0 % 16 == 0 and sum(x[1] for x in xs) == Kc
+                    and lib().anoddpm_f43_channel_sliced(Hout, Hout, Kc, B) == 1):
+                rows = (Hout // 16) * (Hout // 16)
+                part = self.buf(B * rows * Kc * 2, dtype=torch.float64)
+                st.gnb_partial = part.data_ptr()
+                st.gnb_x0 = xs[0][0].data_ptr()
+                st.gnb_x1 = xs[1][0].data_ptr() if len(xs) > 1 else None
+                st.gnb_gamma, st.gnb_beta = self.W(gprefix + ".weight"), self.W(gprefix + ".bias")
+                st.gnb_mean, st.gnb_rstd = gnp[2].data_ptr(), gnp[3].data_ptr()
+                P = Hout * Hout
+                xc1 = xs[1][1] if len(xs) > 1 else 0
+                st.gnb_x0_bs, st.gnb_x1_bs = P * xc0, P * xc1
+                st.gnb_c0, st.gnb_x0_ld, st.gnb_x1_ld, st.gnb_groups = xc0, xc0, (xc1 if xc1 else 4), 32
+                fused = (part, rows)
+            return da, fused
 
         def res_block(prefix, srcs, Hin, cout, resample):
             cin = sum(s[1] for s in srcs)
@@ -506,15 +537,16 @@ class TrainPlan(_Plan):
                     # 2-4. out_layers: weight gradient, data gradient, GroupNorm + SiLU backward into g(h1)
                     if a2 is not None:
                         self.wgrad3([(a2, cout)], Hout, Hout, None, 0, gh2, cout, prefix + ".out_layers.3.weight", prefix + ".out_layers.3.bias")
-                        da2 = dgrad3(gh2, Hout, cout, cout, prefix + ".out_layers.3.weight")
+                        da2, fused2 = dgrad3(gh2, Hout, cout, cout, prefix + ".out_layers.3.weight"), None
                         db = DropoutArgs()                           # d(activation) = mask / (1 - p) * d(dropped), in place
                         db.x, db.out, db.n, db.B, db.C, db.mode, db.p, db.seed = da2.data_ptr(), da2.data_ptr(), Pout * cout, B, cout, 1, self.p_drop, 0
                         self.add(_lib.OP_DROPOUT, db)
                         drop_entry[1] = db
                     else:
                         self.wgrad3([(h1, cout)], Hout, Hout, g2, 0, gh2, cout, prefix + ".out_layers.3.weight", prefix + ".out_layers.3.bias")
-                        da2 = dgrad3(gh2, Hout, cout, cout, prefix + ".out_layers.3.weight")
-                    self.gn_bwd([(h1, cout)], Hout, da2, Pout, g2, prefix + ".out_layers.0", 1, 0)
+                        da2, fused2 = dgrad3(gh2, Hout, cout, cout, prefix + ".out_layers.3.weight",
+                                             gnb=([(h1, cout)], g2, prefix + ".out_layers.0"))
+                    self.gn_bwd([(h1, cout)], Hout, da2, Pout, g2, prefix + ".out_layers.0", 1, 0, fused=fused2)
                     gh1 = self.G(h1)
                     # 5. in_layers weight gradient; its dy column sums are the conv bias and the embedding gradients
                     d_emb = self.buf(B, cout)
@@ -524,9 +556,12 @@ class TrainPlan(_Plan):
                     else:
                         self.linear_bwd(temb, prefix + ".embed_layers.1.weight", prefix + ".embed_layers.1.bias", d_emb, ted, cout, 1, g_temb)
                     # 6-7. data gradient and the fused operand load's backward into the block inputs
-                    da1 = dgrad3(gh1, Hout, cin, cout, prefix + ".in_layers.2.weight")
+                    if am == 0:
+                        da1, fused1 = dgrad3(gh1, Hout, cin, cout, prefix + ".in_layers.2.weight", gnb=(srcs, g1, prefix + ".in_layers.0"))
+                    else:                                            # a resampling sits between the activation and the convolution
+                        da1, fused1 = dgrad3(gh1, Hout, cin, cout, prefix + ".in_layers.2.weight"), None
                     self.gn_bwd(srcs, Hin, da1, Pout, g1, prefix + ".in_layers.0", 1, am,
-                                dres=(gh2 if skip_kind == "identity" else None))
+                                dres=(gh2 if skip_kind == "identity" else None), fused=fused1)
             self._bw.append(bwd)
             return h2, Hout
 

@@ -249,9 +249,27 @@ typedef struct {
      * so that no finalize launch sits between two F(4x4,3x3) layers.  fp64 sums of fp32 partials: the order of the atomic adds
      * changes the result by at most an ulp of the double. */
     double *stats_csum;
+    /* cfg 3 on the 128-channel grid (anoddpm_f43_channel_sliced(...) == 1), ksplit == 1, heads == 1, plain operand (no gn / act),
+     * no bias / temb / res (round 6, training): the launch is the DATA GRADIENT da of a 3x3 convolution whose operand was
+     * a = SiLU(GroupNorm(x)) (diffusion_training.py:102 through UNet.py:170-172, 190-193), and the epilogue -- which holds da in
+     * registers -- also performs the REDUCTION pass of anoddpm_gn_silu_backward: it reads x (the GroupNorm's input, one value per
+     * output it stores; two concatenated sources as there), forms dy = da * silu'(gamma * xhat + beta), xhat = (x - mean) * rstd,
+     * and writes gnb_partial[b][tile][c] = { sum dy, sum dy * xhat } over the workgroup's 16 x 16 pixels (fp32 sums of 256 values,
+     * stored as fp64): exactly the `partial` rows of anoddpm_gn_bwd_args with nslab = (H / 16) * (W / 16), which is then called
+     * with partial_ready = 1 and runs its fold + elementwise launches only.  One pass over x and da less per layer.
+     * N (this launch's output channels) = gnb_c0 + the second source's channels; gnb_c0 % 16 == 0. */
+    double *gnb_partial;            /* or NULL: plain launch */
+    const float *gnb_x0, *gnb_x1;   /* the GroupNorm's input sources, NHWC at the OUTPUT resolution of this launch */
+    const float *gnb_gamma, *gnb_beta;   /* [N] */
+    const float *gnb_mean, *gnb_rstd;    /* [B][gnb_groups] */
+    int64_t gnb_x0_bs, gnb_x1_bs;
+    int32_t gnb_c0, gnb_x0_ld, gnb_x1_ld, gnb_groups;
 } anoddpm_igemm_args;
 
 int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream);
+/* 1 when a cfg 3 launch of this shape (ksplit 1) runs on the channel-sliced 128-channel kernel (winograd43r.hip) -- the one that
+ * takes gnb_partial -- 0 when the launcher picks 64-channel workgroups (grids that would leave CUs idle, N % 128 != 0) */
+int anoddpm_f43_channel_sliced(int32_t H, int32_t W, int32_t N, int32_t B);
 
 /* cfg 5 of anoddpm_igemm: contractions on maps of <= 256 pixels WITHOUT split-K (smallmap.hip) -- the batch is folded into the
  * GEMM's M, a workgroup owns TM output rows x TN channels over all of K' = taps * K and its eight waves split K' (fold through
@@ -657,6 +675,7 @@ typedef struct anoddpm_gn_bwd_args {
                                        gradient -- the identity residual of a block (UNet.py:216 / :125) */
     int64_t dres_bs;
     int32_t dres_ld;
+    int32_t partial_ready;          /* 1: `partial` was written by the producer of da (anoddpm_igemm_args.gnb_partial): no reduction launch */
 } anoddpm_gn_bwd_args;
 
 int anoddpm_gn_silu_backward(const anoddpm_gn_bwd_args *a, void *stream);

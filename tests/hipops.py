@@ -108,7 +108,7 @@ _LAST_KEEP = None
 
 
 def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=None, res=None, cfg=0, ksplit=1,
-               stats_out=None, gn_tail=None, fold=None, res_up=False, csum_out=None):
+               stats_out=None, gn_tail=None, fold=None, res_up=False, csum_out=None, gnb=None):
     """srcs: NHWC sources; w: OIHW weights.  Returns NHWC [B,Hout,Hout,N].  res_up: `res` is [B,Hout/2,Hout/2,N] and is repeated
     2x2 on the read (cfg 3, res_mode 1)."""
     dev = srcs[0].device
@@ -199,6 +199,20 @@ def conv_igemm(srcs, w, bias=None, *, Hout, ks, gn=None, act=0, a_mode=0, temb=N
         stats = torch.full((B, tiles * {2: 4, 3: 1, 7: 1}.get(cfg, 2), N, 2), float("nan"), device=dev)
         st.stats = stats.data_ptr()
         stats_out.append(stats)
+    if gnb is not None:
+        # data-gradient launch that also writes the partial sums of the GroupNorm + SiLU backward's reduction pass
+        # (anoddpm_igemm_args.gnb_*): gnb = dict(srcs=[NHWC x sources], gamma, beta, mean, rstd) -> gnb["partial"] = [B, tiles, N, 2] fp64
+        xs = gnb["srcs"]
+        xc0 = xs[0].shape[3]
+        xc1 = xs[1].shape[3] if len(xs) > 1 else 0
+        part = torch.full((B, (Hout // 16) ** 2, N, 2), float("nan"), dtype=torch.float64, device=dev)
+        st.gnb_partial = part.data_ptr()
+        st.gnb_x0, st.gnb_x1 = xs[0].data_ptr(), (xs[1].data_ptr() if xc1 else None)
+        st.gnb_gamma, st.gnb_beta = gnb["gamma"].data_ptr(), gnb["beta"].data_ptr()
+        st.gnb_mean, st.gnb_rstd = gnb["mean"].data_ptr(), gnb["rstd"].data_ptr()
+        st.gnb_x0_bs, st.gnb_x1_bs = P * xc0, P * xc1
+        st.gnb_c0, st.gnb_x0_ld, st.gnb_x1_ld, st.gnb_groups = xc0, xc0, max(xc1, 4), 32
+        gnb["partial"] = part
     check(lib().anoddpm_igemm(ctypes.byref(st), current_stream()), "igemm")
     torch.cuda.synchronize()
     global LAST_IGEMM, _LAST_KEEP
@@ -364,8 +378,9 @@ def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into
     return dw
 
 
-def gn_silu_backward(srcs, da, gamma, beta, mean, rstd, *, act=1, a_mode=0, acc_into=None, nslab=None):
+def gn_silu_backward(srcs, da, gamma, beta, mean, rstd, *, act=1, a_mode=0, acc_into=None, nslab=None, partial=None):
     """anoddpm_gn_silu_backward.  srcs: 1-2 NHWC sources; da: NHWC gradient w.r.t. the tensor the conv read.
+    partial: [B, rows, C, 2] fp64 written by the data-gradient launch (conv_igemm(gnb=...)): no reduction launch.
     Returns (dx list, dgamma, dbeta)."""
     from anoddpm_amd._lib import GnBwdArgs
     dev = srcs[0].device
@@ -373,10 +388,10 @@ def gn_silu_backward(srcs, da, gamma, beta, mean, rstd, *, act=1, a_mode=0, acc_
     B, Hs, Ws, c0 = srcs[0].shape
     c1 = srcs[1].shape[3] if len(srcs) > 1 else 0
     C, P = c0 + c1, Hs * Ws
-    nslab = nslab or max(1, min(64, P // 64))
+    nslab = partial.shape[1] if partial is not None else (nslab or max(1, min(64, P // 64)))
     dx = acc_into if acc_into is not None else [torch.full_like(s_, float("nan")) for s_ in srcs]
     dgamma, dbeta = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-    part = torch.empty(B * nslab * C * 2, dtype=torch.float64, device=dev)
+    part = partial if partial is not None else torch.empty(B * nslab * C * 2, dtype=torch.float64, device=dev)
     coef = torch.empty(B * C * 4, device=dev)
     st = GnBwdArgs()
     st.x0, st.x1 = srcs[0].data_ptr(), srcs[1].data_ptr() if c1 else None
@@ -388,6 +403,7 @@ def gn_silu_backward(srcs, da, gamma, beta, mean, rstd, *, act=1, a_mode=0, acc_
     st.c0, st.c1, st.x0_ld, st.x1_ld, st.da_ld, st.dx0_ld, st.dx1_ld = c0, c1, c0, max(c1, 4), C, c0, max(c1, 4)
     st.Hs, st.Ws, st.B, st.groups, st.nslab = Hs, Ws, B, 32, nslab
     st.act, st.a_mode, st.acc_dx = act, a_mode, 3 if acc_into is not None else 0
+    st.partial_ready = 1 if partial is not None else 0
     check(lib().anoddpm_gn_silu_backward(ctypes.byref(st), current_stream()), "gn_silu_backward")
     torch.cuda.synchronize()
     return dx, dgamma, dbeta

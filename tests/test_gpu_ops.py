@@ -743,6 +743,57 @@ def test_gn_silu_backward(case):
     assert relerr(hipops.nchw(torch.cat(dx2, dim=3)), xd.grad.float() + 1.0) < 2e-5
 
 
+@pytest.mark.parametrize("case", [(2, (128, 0), 64, 32, 3), (1, (128, 128), 128, 32, 3), (3, (128, 0), 128, 128, 0), (5, (256, 128), 128, 64, 0)])
+def test_f43_data_gradient_writes_the_gn_backward_partials(case):
+    """Round 6: the data-gradient launch on the channel-sliced F(4x4,3x3) kernel with anoddpm_igemm_args.gnb_* set also performs
+    the reduction pass of anoddpm_gn_silu_backward (x read in the epilogue's residual slot).  da must not change, and the
+    GroupNorm backward fed with those partial rows (partial_ready = 1: fold + elementwise launches only) must equal the
+    three-launch form and fp64 autograd.  Selector 3 forces the kernel on the small grids; 0 is the launcher's own choice."""
+    import hipops
+    from anoddpm_amd._lib import lib
+    B, (c0, c1), N, H, sel = case
+    C = c0 + c1
+    x = rnd(B, C, H, H, seed=201)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=202), 0.1 * rnd(C, seed=203)
+    dy = rnd(B, N, H, H, seed=204)
+    wt = rnd(C, N, 3, 3, seed=205, scale=1.0 / math.sqrt(N * 9))          # the data gradient's (flipped, transposed) weights: N -> C
+    xs = hipops.nhwc(x.to(dev()))
+    srcs = [xs[..., :c0].contiguous()] + ([xs[..., c0:].contiguous()] if c1 else [])
+    stats = [hipops.chan_stats(s_, 4) for s_ in srcs]
+    _, _, mean, rstd = hipops.gn_finalize(stats, gamma.to(dev()), beta.to(dev()), H * H, want_mean_rstd=True)
+    dyn = hipops.nhwc(dy.to(dev())).contiguous()
+    g, bt = gamma.to(dev()), beta.to(dev())
+    lib().anoddpm_internal_variant(5, sel)
+    try:
+        assert lib().anoddpm_f43_channel_sliced(H, H, C, B) == 1
+        plain = hipops.conv_igemm([dyn], wt.to(dev()), None, Hout=H, ks=3, cfg=3)
+        gnb = dict(srcs=srcs, gamma=g, beta=bt, mean=mean, rstd=rstd)
+        fused = hipops.conv_igemm([dyn], wt.to(dev()), None, Hout=H, ks=3, cfg=3, gnb=gnb)
+    finally:
+        lib().anoddpm_internal_variant(5, 0)
+    assert torch.equal(plain, fused)
+    part = gnb["partial"]
+    assert part.shape == (B, (H // 16) ** 2, C, 2) and torch.isfinite(part).all()
+    dx0, dg0, db0 = hipops.gn_silu_backward(srcs, plain, g, bt, mean, rstd, act=1, a_mode=0)
+    dx1, dg1, db1 = hipops.gn_silu_backward(srcs, plain, g, bt, mean, rstd, act=1, a_mode=0, partial=part)
+    assert relerr(torch.cat(dx1, dim=3), torch.cat(dx0, dim=3)) < 1e-5
+    assert relerr(dg1, dg0) < 1e-5 and relerr(db1, db0) < 1e-5
+    # and against fp64 autograd of silu(group_norm(x)) with the same upstream gradient
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    F.silu(F.group_norm(xd, 32, gd, bd, eps=1e-5)).backward(hipops.nchw(plain).double().cpu())
+    assert relerr(hipops.nchw(torch.cat(dx1, dim=3)), xd.grad.float()) < 2e-5
+    assert relerr(dg1, gd.grad.float()) < 2e-5 and relerr(db1, bd.grad.float()) < 2e-5
+    # a launch that does not run on the channel-sliced kernel refuses the request instead of ignoring it
+    if lib().anoddpm_f43_channel_sliced(32, 32, 128, 1) == 0:
+        small = hipops.nhwc(rnd(1, 64, 32, 32, seed=206).to(dev())).contiguous()
+        xs2 = [hipops.nhwc(rnd(1, 128, 32, 32, seed=207).to(dev())).contiguous()]
+        m2, r2 = torch.zeros(1, 32, device=dev()), torch.ones(1, 32, device=dev())
+        with pytest.raises(Exception, match="gnb_partial"):
+            hipops.conv_igemm([small], rnd(128, 64, 3, 3, seed=208).to(dev()), None, Hout=32, ks=3, cfg=3,
+                              gnb=dict(srcs=xs2, gamma=g[:128].contiguous(), beta=bt[:128].contiguous(), mean=m2, rstd=r2))
+
+
 @pytest.mark.parametrize("N,K", [(64, 32), (128, 256), (96, 36)])
 def test_device_weight_packing_matches_host_packers(N, K):
     """anoddpm_pack_conv3x3 (training re-packs on the device) against the host packers used by the inference plan."""
