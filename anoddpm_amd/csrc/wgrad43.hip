@@ -20,7 +20,8 @@
 //      workgroups of the first input-channel block;
 //   3. 48 MFMAs per wave: operands are 4-byte LDS reads of V / Z [pos][tile][channel] (16 channels x 4 tiles per wave read).
 // VALU (transforms) and MFMA phases alternate -- on this hardware they share the issue port anyway -- four barriers per patch.
-// The per-workgroup dU goes to a workspace [PG][36][K][N]; two small kernels sum the PG slabs and apply G^T . G.
+// The per-workgroup gradient goes to a workspace [PG][18][K][N] with the first half of G^T . G applied (r = dU G: wave pairs meet in
+// LDS); one small kernel sums the PG slabs and applies the second half.
 #include "common.h"
 
 using anoddpm::silu_f;
@@ -395,21 +396,65 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
         // no barrier here: the next iteration only writes the staging buffers before its first barrier
     }
 
-    // ---- partial dU of this workgroup: ws[pg][pos][k][n]
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const int pos = wave * 3 + p;
-        float *dst = a.ws + (((int64_t)pg * 36 + pos) * K + k0 + 4 * kq) * N + n0 + l15;
+    // ---- partial gradient of this workgroup, with the first half of dg = G^T dU G applied: ws[pg][u * 3 + b][k][n] = r[u][b] =
+    // sum_v dU[u][v] G[v][b].  Wave w holds half a row of dU -- u = w >> 1, v = 3 (w & 1) + {0, 1, 2} -- so it forms its three partial
+    // sums in registers, the odd wave of a pair hands them to the even one through LDS (lane to lane: both map lanes to (k, n) alike),
+    // and the even wave stores 18 instead of 36 planes: half the slab traffic of this kernel and of the fold (round 6).
+    __syncthreads();                                                // every wave is past its last MFMA operand reads: LDS is scratch now
+    {
+        // G (6 x 3): rows (1/4, 0, 0), (-1/6, -1/6, -1/6), (-1/6, 1/6, -1/6), (1/24, 1/12, 1/6), (1/24, -1/12, 1/6), (0, 0, 1)
+        const bool hi = (wave & 1) != 0;                            // wave-uniform
+        const int u = wave >> 1;
+        float *xch = reinterpret_cast<float *>(lds4) + (u * 3) * 32 * 64 + lane;      // [u][b][element e = (i, j, r)][lane]
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[(int64_t)(i * 16 + r) * N + j * 16] = acc[p][i][j][r];
+                for (int r = 0; r < 4; ++r) {
+                    const float d0 = acc[0][i][j][r], d1 = acc[1][i][j][r], d2 = acc[2][i][j][r];
+                    float r0, r1, r2;
+                    if (!hi) {                                      // v = 0, 1, 2
+                        const float s12 = d1 + d2, m12 = d2 - d1;
+                        r0 = 0.25f * d0 - (1.f / 6) * s12;
+                        r1 = (1.f / 6) * m12;
+                        r2 = -(1.f / 6) * s12;
+                    } else {                                        // v = 3, 4, 5
+                        const float s01 = d0 + d1, m01 = d0 - d1;
+                        r0 = (1.f / 24) * s01;
+                        r1 = (1.f / 12) * m01;
+                        r2 = (1.f / 6) * s01 + d2;
+                    }
+                    acc[0][i][j][r] = r0; acc[1][i][j][r] = r1; acc[2][i][j][r] = r2;
+                }
+        if (hi) {
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xch[(bb * 32 + (i * 4 + j) * 4 + r) * 64] = acc[bb][i][j][r];
+        }
+        __syncthreads();
+        if (!hi) {
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) {
+                float *dst = a.ws + (((int64_t)pg * 18 + u * 3 + bb) * K + k0 + 4 * kq) * N + n0 + l15;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            dst[(int64_t)(i * 16 + r) * N + j * 16] = acc[bb][i][j][r] + xch[(bb * 32 + (i * 4 + j) * 4 + r) * 64];
+            }
+        }
     }
 }
 
-// ws[0][pos][k][n] <- sum over the PG slabs, fixed order (thread = one (pos, k, n); 16 slabs in flight)
+// ws[0][plane][k][n] <- sum over the PG slabs, fixed order (thread = one (plane, k, n); 16 slabs in flight)
 __global__ __launch_bounds__(256) void wgrad43_sum_kernel(float *ws, const int64_t slab, const int PG)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -428,29 +473,21 @@ __global__ __launch_bounds__(256) void wgrad43_sum_kernel(float *ws, const int64
     ws[idx] = s;
 }
 
-// dw[n][k][a][b] (+)= sum_u sum_v G[u][a] dU[u][v][k][n] G[v][b]   (thread = one (k, n))
+__constant__ float G63[6][3] = {{1.f / 4, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                                {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+
+// dw[n][k][a][b] (+)= sum_u G[u][a] r[u][b]   (thread = one (k, n); the second half of G^T dU G)
 __global__ __launch_bounds__(256) void wgrad43_out_kernel(const anoddpm_wgrad_args a)
 {
     const int K = a.c0 + a.c1, N = a.N;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)K * N) return;
     const int n = (int)(idx % N), k = (int)(idx / N);
-    const float G[6][3] = {{1.f / 4, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
-                           {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
     float r[6][3];
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
-        float d[6];
+    for (int u = 0; u < 6; ++u)
 #pragma unroll
-        for (int v = 0; v < 6; ++v) d[v] = a.ws[((int64_t)(u * 6 + v) * K + k) * N + n];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            float s = 0.f;
-#pragma unroll
-            for (int v = 0; v < 6; ++v) s += d[v] * G[v][b];
-            r[u][b] = s;
-        }
-    }
+        for (int b = 0; b < 3; ++b) r[u][b] = a.ws[((int64_t)(u * 3 + b) * K + k) * N + n];
     float *o = a.dw + ((int64_t)n * K + k) * 9;
 #pragma unroll
     for (int aa = 0; aa < 3; ++aa)
@@ -458,30 +495,25 @@ __global__ __launch_bounds__(256) void wgrad43_out_kernel(const anoddpm_wgrad_ar
         for (int b = 0; b < 3; ++b) {
             float s = 0.f;
 #pragma unroll
-            for (int u = 0; u < 6; ++u) s += G[u][aa] * r[u][b];
+            for (int u = 0; u < 6; ++u) s += G63[u][aa] * r[u][b];
             o[aa * 3 + b] = a.accumulate ? o[aa * 3 + b] + s : s;
         }
 }
 
-// Both steps in one launch: workgroup = one input channel k x 32 output channels, 288 threads.  Thread (position pos = 0..35, lane
-// quad q) folds four output channels of its position over the PG slabs (slab order; sixteen 16-byte loads in flight), the 36 x 32
-// sums meet in LDS, then the column transform (18 x 32 items) and the row transform (9 x 32 items, writing dw[n][k][3][3]).
-// Same order of every sum as wgrad43_sum_kernel + wgrad43_out_kernel (bit-identical), one launch and one pass over the slabs
-// instead of two launches and a round trip of the folded slab.
-__constant__ float G63[6][3] = {{1.f / 4, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
-                                {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
-
+// Both steps in one launch: workgroup = one input channel k x 64 output channels, 288 threads.  Thread (plane = u * 3 + b, lane
+// quad q) folds four output channels of its plane over the PG slabs (slab order; sixteen 16-byte loads in flight), the 18 x 64
+// sums meet in LDS, then the row transform (9 x 64 items, writing dw[n][k][3][3]).  Same order of every sum as
+// wgrad43_sum_kernel + wgrad43_out_kernel (bit-identical), one launch and one pass over the slabs.
 __global__ __launch_bounds__(288) void wgrad43_fold_kernel(const anoddpm_wgrad_args a, const int PG)
 {
-    __shared__ __attribute__((aligned(16))) float dd[36][32];
-    __shared__ float rr[6][3][32];
+    __shared__ __attribute__((aligned(16))) float rr[18][64];
     const int K = a.c0 + a.c1, N = a.N;
-    const int tiles_n = N >> 5;
-    const int k = blockIdx.x / tiles_n, n0 = (blockIdx.x % tiles_n) * 32;
-    const int pos = threadIdx.x >> 3, q = threadIdx.x & 7;
-    const int64_t plane = (int64_t)K * N, slab = 36 * plane;
+    const int tiles_n = N >> 6;
+    const int k = blockIdx.x / tiles_n, n0 = (blockIdx.x % tiles_n) * 64;
+    const int plane = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const int64_t slab = (int64_t)18 * K * N;
     {
-        const float *p = a.ws + ((int64_t)pos * K + k) * N + n0 + 4 * q;
+        const float *p = a.ws + ((int64_t)plane * K + k) * N + n0 + 4 * q;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         int g = 0;
         for (; g + 16 <= PG; g += 16) {
@@ -492,23 +524,14 @@ __global__ __launch_bounds__(288) void wgrad43_fold_kernel(const anoddpm_wgrad_a
             for (int i = 0; i < 16; ++i) s += x[i];
         }
         for (; g < PG; ++g) s += *reinterpret_cast<const f32x4 *>(p + (int64_t)g * slab);
-        *reinterpret_cast<f32x4 *>(&dd[pos][4 * q]) = s;
+        *reinterpret_cast<f32x4 *>(&rr[plane][4 * q]) = s;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 18 * 32; i += 288) {              // r[u][b] = sum_v d[u][v] G[v][b]
-        const int ub = i >> 5, nl = i & 31, u = ub / 3, b = ub - u * 3;
-        float s = 0.f;
-#pragma unroll
-        for (int v = 0; v < 6; ++v) s += dd[u * 6 + v][nl] * G63[v][b];
-        rr[u][b][nl] = s;
-    }
-    __syncthreads();
-    {
-        const int i = threadIdx.x;                                  // 288 = 32 x 9 outputs
+    for (int i = threadIdx.x; i < 9 * 64; i += 288) {                // 64 x 9 outputs
         const int n = i / 9, ab = i - n * 9, aa = ab / 3, b = ab - aa * 3;
         float s = 0.f;
 #pragma unroll
-        for (int uu = 0; uu < 6; ++uu) s += G63[uu][aa] * rr[uu][b][n];
+        for (int uu = 0; uu < 6; ++uu) s += G63[uu][aa] * rr[uu * 3 + b][n];
         float *o = a.dw + ((int64_t)(n0 + n) * K + k) * 9 + ab;
         *o = a.accumulate ? *o + s : s;
     }
@@ -546,12 +569,12 @@ int launch_wgrad43(const anoddpm_wgrad_args *a, hipStream_t s)
                     (int64_t)a->B * a->a0_bs * 4 < ((int64_t)1 << 31) && (int64_t)a->B * a->dy_bs * 4 < ((int64_t)1 << 31),
                     "wgrad (Winograd): tensors must stay below 2 GB (32-bit buffer offsets)");
     const int pg = wgrad43_groups(K, a->N, a->B, a->H, a->W);
-    const int64_t slab = (int64_t)36 * K * a->N;
+    const int64_t slab = (int64_t)18 * K * a->N;                     // the kernel stores r = dU G: 18 planes per (k, n)
     ANODDPM_REQUIRE(a->ws_floats >= (int64_t)pg * slab, "wgrad (Winograd): workspace too small");
     const dim3 grid((unsigned)pg, (unsigned)((K / G4_KB) * (a->N / G4_NB)));
     hipLaunchKernelGGL(wgrad43_kernel, grid, dim3(G4_NT), 0, s, *a, pg, a->W / 16, a->H / 8, 1.0f / (float)(a->W / 16));
     if (g_debug[8] != 1) {                                           // ANODDPM_DEBUG8=1: the two-launch fold
-        hipLaunchKernelGGL(wgrad43_fold_kernel, dim3((unsigned)((int64_t)K * (a->N / 32))), dim3(288), 0, s, *a, pg);
+        hipLaunchKernelGGL(wgrad43_fold_kernel, dim3((unsigned)((int64_t)K * (a->N / 64))), dim3(288), 0, s, *a, pg);
         return check_launch("conv3x3_wgrad (Winograd)");
     }
     if (pg > 1) hipLaunchKernelGGL(wgrad43_sum_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, a->ws, slab, pg);
