@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ANODDPM_LIB_TAG=<tag>: load lib/libanoddpm_hip_<tag>.so instead -- a second build of the same sources with other compiler flags
 # (ANODDPM_BUILD_TAG / ANODDPM_EXTRA_FLAGS of anoddpm_amd.build), for A/B measurements of one gpurun session.  Same ABI, same checks.
 SO_PATH = os.path.join(_HERE, "lib", "libanoddpm_hip%s.so" % ("_" + os.environ["ANODDPM_LIB_TAG"] if os.environ.get("ANODDPM_LIB_TAG") else ""))
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 OP_IGEMM, OP_GN_STATS, OP_SOFTMAX, OP_RESAMPLE, OP_LINEAR, OP_POSEMB, OP_STEM, OP_LAYOUT, OP_CHAN_STATS, OP_GN_FINALIZE, OP_HEAD = range(1, 12)
 (OP_WGRAD3, OP_WGRAD1, OP_GN_BWD, OP_PACK, OP_SOFTMAX_BWD, OP_TRANSPOSE, OP_LINEAR_BWD, OP_STEM_BWD, OP_HEAD_BWD,
@@ -177,7 +177,7 @@ class WgradArgs(Structure):
                 ("c0", c_int32), ("c1", c_int32), ("a0_ld", c_int32), ("a1_ld", c_int32), ("dy_ld", c_int32),
                 ("H", c_int32), ("W", c_int32), ("N", c_int32), ("B", c_int32),
                 ("a_mode", c_int32), ("act", c_int32), ("gn_ld", c_int32), ("band", c_int32), ("accumulate", c_int32),
-                ("colsum", c_void_p), ("algo", c_int32)]
+                ("colsum", c_void_p), ("algo", c_int32), ("dimg", c_void_p), ("dbias", c_void_p)]
 
 
 class GnBwdArgs(Structure):
@@ -267,7 +267,7 @@ SYMBOLS = [
     "anoddpm_adamw_ema", "anoddpm_sumsq", "anoddpm_anomaly_map", "anoddpm_vlb_terms", "anoddpm_conv3x3_wgrad", "anoddpm_gn_silu_backward", "anoddpm_pack_conv3x3",
     "anoddpm_wgrad_pointwise", "anoddpm_pack_weights", "anoddpm_softmax_rows_backward", "anoddpm_transpose_square",
     "anoddpm_linear_small_backward", "anoddpm_conv_stem_backward", "anoddpm_conv_head_backward", "anoddpm_colsum_fold",
-    "anoddpm_volume_normalise", "anoddpm_mri_slice_prepare", "anoddpm_resize_bilinear_pil", "anoddpm_attention", "anoddpm_wgrad43_groups", "anoddpm_wgrad43_patches", "anoddpm_pack_batch", "anoddpm_pack_job_blocks", "anoddpm_linear_small_backward_batch",
+    "anoddpm_volume_normalise", "anoddpm_mri_slice_prepare", "anoddpm_resize_bilinear_pil", "anoddpm_attention", "anoddpm_wgrad43_groups", "anoddpm_wgrad43_colsum_items", "anoddpm_pack_batch", "anoddpm_pack_job_blocks", "anoddpm_linear_small_backward_batch",
     "anoddpm_loss_forward", "anoddpm_loss_backward", "anoddpm_dropout",
 ]
 
@@ -355,7 +355,7 @@ def lib():
     L.anoddpm_conv3x3_wgrad.argtypes = [POINTER(WgradArgs), c_void_p]
     L.anoddpm_wgrad43_groups.argtypes = [c_int32] * 5
     L.anoddpm_f43_channel_sliced.argtypes = [c_int32] * 4
-    L.anoddpm_wgrad43_patches.argtypes = [c_int32] * 2
+    L.anoddpm_wgrad43_colsum_items.argtypes = [c_int32] * 5
     L.anoddpm_gn_silu_backward.argtypes = [POINTER(GnBwdArgs), c_void_p]
     L.anoddpm_pack_conv3x3.argtypes = [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]
     L.anoddpm_wgrad_pointwise.argtypes = [POINTER(Wgrad1Args), c_void_p]

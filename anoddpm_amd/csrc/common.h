@@ -58,7 +58,7 @@ int launch_winograd43b(const anoddpm_igemm_args *a, hipStream_t s);      // wino
 int wino23s_tile(int H, int W, int K, int c0, int N, int B, int a_mode);
 int launch_wgrad43(const anoddpm_wgrad_args *a, hipStream_t s);      // wgrad43.hip (algo == 1 of anoddpm_conv3x3_wgrad)
 int wgrad43_groups(int K, int N, int B, int H, int W);
-int wgrad43_patches(int H, int W);                               // column-sum items per image of algo 1
+int wgrad43_colsum_items(int K, int N, int B, int H, int W);      // column-sum rows per image of algo 1
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -93,7 +93,7 @@ extern "C" int anoddpm_ablate_build(void)
 #endif
 }
 
-extern "C" int anoddpm_abi_version(void) { return 23; }
+extern "C" int anoddpm_abi_version(void) { return 24; }
 
 extern "C" const char *anoddpm_last_error(void) { return g_err; }
 

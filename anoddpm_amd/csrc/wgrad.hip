@@ -330,9 +330,9 @@ extern "C" int anoddpm_wgrad43_groups(int32_t K, int32_t N, int32_t B, int32_t H
     return anoddpm::wgrad43_groups(K, N, B, H, W);
 }
 
-extern "C" int anoddpm_wgrad43_patches(int32_t H, int32_t W)
+extern "C" int anoddpm_wgrad43_colsum_items(int32_t K, int32_t N, int32_t B, int32_t H, int32_t W)
 {
-    return anoddpm::wgrad43_patches(H, W);
+    return anoddpm::wgrad43_colsum_items(K, N, B, H, W);
 }
 
 extern "C" int anoddpm_pack_conv3x3(const float *w, float *out, int32_t N, int32_t K, int32_t mode, int32_t bwd, void *stream)

@@ -40,12 +40,6 @@ __device__ __forceinline__ f32x4 bld4g(__amdgpu_buffer_rsrc_t r, unsigned lane_b
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_bytes, (int)wave_bytes, 0));
 }
 
-// WG43_LEGACY=1 (measurement builds, `ANODDPM_EXTRA_FLAGS="wgrad43.hip:-DWG43_LEGACY=1"`): the round 2-5 form of the transforms (one
-// row of B^T d / A dY per item on packed channel pairs, the next patch requested before the last transform) for A/B runs against the
-// round-6 form (row-pair items on single channels, next patch requested behind the last transform: profiles/r6_wgrad43_ab.txt)
-#ifndef WG43_LEGACY
-#define WG43_LEGACY 0
-#endif
 constexpr int G4_NT = 768;
 constexpr int G4_PW = 18;                          // input patch: 18 x 10 pixels (16 x 8 outputs + halo)
 constexpr int G4_PPIX = 180;
@@ -152,76 +146,12 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
         }
     };
 
-    // ---- transform roles: wave -> (row u = wave % 6, chunk slot = wave / 6); lane -> (channel pair = lane & 7, tile = lane >> 3)
-    const int tu = wave % 6, tslot = wave / 6;
-    const int tpair = lane & 7, ttile = lane >> 3;
-    // V = B^T d B: row u of B^T as (patch row, coefficient) pairs (see winograd43.hip)
-    const int tr0 = (tu == 0) ? 0 : 1, tr1 = (tu == 5) ? 3 : 2, tr2 = (tu == 0) ? 4 : ((tu == 5) ? 5 : 3), tr3 = 4;
-    const float tc0 = (tu == 0) ? 4.f : (tu == 1 ? -4.f : (tu == 2 ? 4.f : (tu == 3 ? -2.f : (tu == 4 ? 2.f : 4.f))));
-    const float tc1 = (tu == 0 || tu == 5) ? -5.f : ((tu == 1 || tu == 2) ? -4.f : -1.f);
-    const float tc2 = (tu == 0 || tu == 5) ? 1.f : (tu == 1 ? 1.f : (tu == 2 ? -1.f : (tu == 3 ? 2.f : -2.f)));
-    const float tc3 = (tu == 0 || tu == 5) ? 0.f : 1.f;
-    const int vin2 = ((4 * (ttile >> 2)) * G4_PW + 4 * (ttile & 3)) * G4_PITCH * 2 + tpair;       // float2 index of the tile corner
-    const int vrow = G4_PW * G4_PITCH * 2;
-    auto transform_v = [&]() {
-        const f32x2 *D = reinterpret_cast<const f32x2 *>(ldsPin + tslot * G4_PIN) + vin2;
-        f32x2 t[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            t[j] = tc0 * D[tr0 * vrow + j * G4_PITCH * 2] + tc1 * D[tr1 * vrow + j * G4_PITCH * 2] + tc2 * D[tr2 * vrow + j * G4_PITCH * 2] +
-                   tc3 * D[tr3 * vrow + j * G4_PITCH * 2];
-            __builtin_amdgcn_sched_barrier(0);   // one column of reads in flight: the registers belong to the accumulators
-        }
-        const f32x2 p = t[4] - 4.f * t[2], q = t[3] - 4.f * t[1], r = t[4] - t[2], s = t[3] - t[1];
-        f32x2 *V = reinterpret_cast<f32x2 *>(ldsV + tslot * G4_V) + ((tu * 6) * G4_TILES + ttile) * 8 + tpair;
-        V[0 * 64] = 4.f * t[0] - 5.f * t[2] + t[4];
-        V[1 * 64] = p + q;
-        V[2 * 64] = p - q;
-        V[3 * 64] = r + 2.f * s;
-        V[4 * 64] = r - 2.f * s;
-        V[5 * 64] = 4.f * t[1] - 5.f * t[3] + t[5];
-    };
-    // Z = A dY A^T: row u of A (6 x 4): u0 (1,0,0,0) u1 (1,1,1,1) u2 (1,-1,1,-1) u3 (1,2,4,8) u4 (1,-2,4,-8) u5 (0,0,0,1)
-    const float zc0 = (tu == 5) ? 0.f : 1.f;
-    const float zc1 = (tu == 1) ? 1.f : (tu == 2 ? -1.f : (tu == 3 ? 2.f : (tu == 4 ? -2.f : 0.f)));
-    const float zc2 = (tu == 1 || tu == 2) ? 1.f : ((tu == 3 || tu == 4) ? 4.f : 0.f);
-    const float zc3 = (tu == 1) ? 1.f : (tu == 2 ? -1.f : (tu == 3 ? 8.f : (tu == 4 ? -8.f : (tu == 5 ? 1.f : 0.f))));
-    const int zin2 = ((4 * (ttile >> 2)) * 16 + 4 * (ttile & 3)) * G4_PITCH * 2 + tpair;
-    const int zrow = 16 * G4_PITCH * 2;
-    const bool want_cs = a.colsum != nullptr && kb == 0 && tu == 1;
     const __amdgpu_buffer_rsrc_t rCS = rsrc_g(a.colsum ? a.colsum : a.dy);
-    auto transform_z = [&](int round, const Geo &g) {
-        const f32x2 *D = reinterpret_cast<const f32x2 *>(ldsPdy + tslot * G4_PDY) + zin2;
-        f32x2 t[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t[j] = zc0 * D[j * G4_PITCH * 2] + zc1 * D[zrow + j * G4_PITCH * 2] + zc2 * D[2 * zrow + j * G4_PITCH * 2] + zc3 * D[3 * zrow + j * G4_PITCH * 2];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const int zc = 2 * round + tslot;
-        f32x2 *Z = reinterpret_cast<f32x2 *>(ldsZ + zc * G4_V) + ((tu * 6) * G4_TILES + ttile) * 8 + tpair;
-        const f32x2 e02 = t[0] + t[2], o13 = t[1] + t[3], e024 = t[0] + 4.f * t[2], o138 = 2.f * t[1] + 8.f * t[3];
-        Z[0 * 64] = t[0];
-        Z[1 * 64] = e02 + o13;
-        Z[2 * 64] = e02 - o13;
-        Z[3 * 64] = e024 + o138;
-        Z[4 * 64] = e024 - o138;
-        Z[5 * 64] = t[3];
-        if (want_cs) {                                              // row role u = 1: t[j] are the column sums of the tile
-            f32x2 cs2 = e02 + o13;                                  // sum over the patch's 8 tiles: lanes differ in bits 3..5
-#pragma unroll
-            for (int o = 8; o <= 32; o <<= 1) {
-                cs2[0] += __shfl_xor(cs2[0], o);
-                cs2[1] += __shfl_xor(cs2[1], o);
-            }
-            if (ttile == 0) {
-                const unsigned wave_off = (((unsigned)g.b * (unsigned)ppi + (unsigned)g.r) * (unsigned)N + (unsigned)(n0 + zc * 16)) * 4u;
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, cs2), rCS, (int)(tpair * 8), (int)wave_off, 0);
-            }
-        }
-    };
-
+    // Column sums of dY (bias / embedding gradients): the waves of row pair 1 of the first input-channel block sum their tile row
+    // over the workgroup's patches of an image and store ONE row per image: colsum[b][pg * 2 + tile row][n] (2 PG rows per image
+    // instead of one per tile row of every patch: 64 instead of 1 024 at 256^2); images the workgroup has no patch in get zeros.
+    const bool cs_role = a.colsum != nullptr && kb == 0 && (wave % 3) == 1;       // wave-uniform
+    float cs_acc0 = 0.f, cs_acc1 = 0.f;
     // ---- round 6: transform items that form TWO rows of B^T d / A dY from one set of reads, on SINGLE channels.  The row pairs (1,2)
     // and (3,4) share their partial sums (u1, u2 = p +- q; u3, u4 = r +- 2 s), (0,5) read disjoint rows: 4 instead of 8 operations and
     // half the LDS reads per column and row pair, with coefficients that are literals instead of per-wave registers.
@@ -316,16 +246,14 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
         float *Z = reinterpret_cast<float *>(ldsZ + zc * G4_V) + s_out;
         col_pass_z1(ta, Z + s_ua * 6 * 128);
         col_pass_z1(tb, Z + s_ub * 6 * 128);
-        if (a.colsum != nullptr && kb == 0 && s_up == 1) {          // row (1,1,1,1): ta[j] are the column sums of the lane's tile
+        if (cs_role) {                                              // row (1,1,1,1): ta[j] are the column sums of the lane's tile
             float cs = (ta[0] + ta[2]) + (ta[1] + ta[3]);
-            cs += __shfl_xor(cs, 16);                                // the wave's four tiles (one tile row of the patch): a column-sum item
+            cs += __shfl_xor(cs, 16);                                // the wave's four tiles (one tile row of the patch)
             cs += __shfl_xor(cs, 32);
-            if (s_tx == 0) {
-                const unsigned wave_off = ((((unsigned)g.b * (unsigned)ppi + (unsigned)g.r) * 2u + (unsigned)s_trow) * (unsigned)N + (unsigned)(n0 + zc * 16)) * 4u;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cs), rCS, (int)(s_ch * 4), (int)wave_off, 0);
-            }
+            if (round == 0) cs_acc0 += cs; else cs_acc1 += cs;      // summed over the workgroup's patches of an image (cs_flush)
         }
     };
+
     // ---- accumulators: positions 3*wave + p, 2 input-channel tiles x 4 output-channel tiles of 16 x 16
     f32x4 acc[3][2][4];
 #pragma unroll
@@ -337,6 +265,13 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
     const int l15 = lane & 15, kq = lane >> 4;
     const float *Vf = reinterpret_cast<const float *>(ldsV), *Zf = reinterpret_cast<const float *>(ldsZ);
 
+    auto cs_store = [&](const int b, const float v0, const float v1) {
+        if (s_tx == 0) {
+            const unsigned row = ((unsigned)b * 2u * (unsigned)PG + (unsigned)pg * 2u + (unsigned)s_trow) * (unsigned)N + (unsigned)n0;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rCS, (int)(s_ch * 4), (int)((row + (unsigned)(s_slot * 16)) * 4u), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), rCS, (int)(s_ch * 4), (int)((row + (unsigned)((2 + s_slot) * 16)) * 4u), 0);
+        }
+    };
     Geo cur;
     cur.b = pg / ppi;
     cur.r = pg - cur.b * ppi;
@@ -345,33 +280,29 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
     load_in(cur);
     load_dy(cur, 0);
     __syncthreads();                                                // affine table
+    int cs_b = cur.b;
+    if (cs_role)
+        for (int bb = 0; bb < cs_b; ++bb) cs_store(bb, 0.f, 0.f);
     for (int it = 0; it < iters; ++it) {
+        if (cs_role && cur.b != cs_b) {                             // the walk reached another image: its predecessor's sums are final
+            cs_store(cs_b, cs_acc0, cs_acc1);
+            for (int bb = cs_b + 1; bb < cur.b; ++bb) cs_store(bb, 0.f, 0.f);
+            cs_b = cur.b;
+            cs_acc0 = cs_acc1 = 0.f;
+        }
         store_dy();
         load_dy(cur, 1);                                            // requested BEFORE the input staging: its GroupNorm + SiLU pass covers the latency
         store_in(cur);
         __syncthreads();
-        if (WG43_LEGACY) {
-            transform_v();
-            transform_z(0, cur);
-        } else {
-            transform_v_s();
-            transform_z_s(0, cur);
-        }
+        transform_v_s();
+        transform_z_s(0, cur);
         __syncthreads();
         store_dy();
         const Geo nxt = advance(cur);                               // prefetch of the next patch
-        if (WG43_LEGACY) {
-            load_in(nxt);
-            load_dy(nxt, 0);
-        }
         __syncthreads();
-        if (WG43_LEGACY) {
-            transform_z(1, cur);
-        } else {
-            transform_z_s(1, cur);
-            load_in(nxt);                                           // requested behind the last transform (no request registers live across
-            load_dy(nxt, 0);                                        // it); the MFMA phase covers the latency: -2.3 % against requesting before it
-        }
+        transform_z_s(1, cur);
+        load_in(nxt);                                               // requested behind the last transform (no request registers live across
+        load_dy(nxt, 0);                                            // it); the MFMA phase covers the latency: -2.3 % against requesting before it
         cur = nxt;
         __syncthreads();
         // (round 6, measured and dropped: the twelve operand reads of position p + 1 issued before the sixteen MFMAs of position p --
@@ -396,6 +327,10 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
         // no barrier here: the next iteration only writes the staging buffers before its first barrier
     }
 
+    if (cs_role) {
+        cs_store(cs_b, cs_acc0, cs_acc1);
+        for (int bb = cs_b + 1; bb < a.B; ++bb) cs_store(bb, 0.f, 0.f);
+    }
     // ---- partial gradient of this workgroup, with the first half of dg = G^T dU G applied: ws[pg][u * 3 + b][k][n] = r[u][b] =
     // sum_v dU[u][v] G[v][b].  Wave w holds half a row of dU -- u = w >> 1, v = 3 (w & 1) + {0, 1, 2} -- so it forms its three partial
     // sums in registers, the odd wave of a pair hands them to the even one through LDS (lane to lane: both map lanes to (k, n) alike),
@@ -504,12 +439,40 @@ __global__ __launch_bounds__(256) void wgrad43_out_kernel(const anoddpm_wgrad_ar
 // quad q) folds four output channels of its plane over the PG slabs (slab order; sixteen 16-byte loads in flight), the 18 x 64
 // sums meet in LDS, then the row transform (9 x 64 items, writing dw[n][k][3][3]).  Same order of every sum as
 // wgrad43_sum_kernel + wgrad43_out_kernel (bit-identical), one launch and one pass over the slabs.
-__global__ __launch_bounds__(288) void wgrad43_fold_kernel(const anoddpm_wgrad_args a, const int PG)
+__global__ __launch_bounds__(288) void wgrad43_fold_kernel(const anoddpm_wgrad_args a, const int PG, const int blk0)
 {
+    const int bid = (int)blockIdx.x + blk0;
     __shared__ __attribute__((aligned(16))) float rr[18][64];
     const int K = a.c0 + a.c1, N = a.N;
     const int tiles_n = N >> 6;
-    const int k = blockIdx.x / tiles_n, n0 = (blockIdx.x % tiles_n) * 64;
+    if (bid >= K * tiles_n) {
+        // the N / 32 blocks behind the weight blocks fold the kernel's column sums (2 PG rows per image): dimg[b][n] = the image's
+        // sum of dy (embedding gradient), dbias[n] += their sum over the images in index order -- what anoddpm_colsum_fold does in
+        // a launch of its own.  32 channels x 9 row lanes.
+        float (*red)[32] = reinterpret_cast<float (*)[32]>(&rr[0][0]);
+        const int l = threadIdx.x & 31, il = threadIdx.x >> 5;
+        const int n = (bid - K * tiles_n) * 32 + l;
+        const int rows = 2 * PG;
+        float tot = 0.f;
+        for (int b = 0; b < a.B; ++b) {
+            float sacc = 0.f;
+            const float *p = a.colsum + ((int64_t)b * rows) * N + n;
+            for (int i = il; i < rows; i += 9) sacc += p[(int64_t)i * N];
+            red[il][l] = sacc;
+            __syncthreads();
+            if (il == 0) {
+                float t = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 9; ++kk) t += red[kk][l];
+                a.dimg[(int64_t)b * N + n] = t;
+                tot += t;
+            }
+            __syncthreads();
+        }
+        if (il == 0 && a.dbias) a.dbias[n] += tot;
+        return;
+    }
+    const int k = bid / tiles_n, n0 = (bid % tiles_n) * 64;
     const int plane = threadIdx.x >> 4, q = threadIdx.x & 15;
     const int64_t slab = (int64_t)18 * K * N;
     {
@@ -543,10 +506,6 @@ namespace anoddpm {
 
 // Patch groups of the Winograd-domain weight gradient: one workgroup per CU in total (shared with the host side through
 // anoddpm_wgrad43_groups so that the caller can size the workspace: PG * 36 * K * N floats).
-// column-sum items per image (exported so that callers do not hard-code the item shape)
-// (one item per tile row of a patch, 16 x 4 pixels: a wave of the dY transform holds one tile row; WG43_LEGACY: per 16 x 8 patch)
-int wgrad43_patches(int H, int W) { return (WG43_LEGACY ? H / 8 : H / 4) * (W / 16); }
-
 int wgrad43_groups(int K, int N, int B, int H, int W)
 {
     const int blocks = (K / G4_KB) * (N / G4_NB);
@@ -556,6 +515,9 @@ int wgrad43_groups(int K, int N, int B, int H, int W)
     if (pg > patches) pg = patches;
     return pg;
 }
+
+// column-sum rows per image the kernel writes: one per patch group and tile row (exported: callers size colsum with it)
+int wgrad43_colsum_items(int K, int N, int B, int H, int W) { return 2 * wgrad43_groups(K, N, B, H, W); }
 
 int launch_wgrad43(const anoddpm_wgrad_args *a, hipStream_t s)
 {
@@ -569,16 +531,20 @@ int launch_wgrad43(const anoddpm_wgrad_args *a, hipStream_t s)
                     (int64_t)a->B * a->a0_bs * 4 < ((int64_t)1 << 31) && (int64_t)a->B * a->dy_bs * 4 < ((int64_t)1 << 31),
                     "wgrad (Winograd): tensors must stay below 2 GB (32-bit buffer offsets)");
     const int pg = wgrad43_groups(K, a->N, a->B, a->H, a->W);
+    ANODDPM_REQUIRE(!a->dimg || a->colsum, "wgrad (Winograd): dimg / dbias are folded from colsum");
+    ANODDPM_REQUIRE(!a->dbias || a->dimg, "wgrad (Winograd): dbias needs dimg (the per-image sums it adds up)");
+    ANODDPM_REQUIRE((int64_t)a->B * 2 * pg * a->N * 4 < ((int64_t)1 << 31), "wgrad (Winograd): colsum exceeds 32-bit buffer offsets");
     const int64_t slab = (int64_t)18 * K * a->N;                     // the kernel stores r = dU G: 18 planes per (k, n)
     ANODDPM_REQUIRE(a->ws_floats >= (int64_t)pg * slab, "wgrad (Winograd): workspace too small");
     const dim3 grid((unsigned)pg, (unsigned)((K / G4_KB) * (a->N / G4_NB)));
     hipLaunchKernelGGL(wgrad43_kernel, grid, dim3(G4_NT), 0, s, *a, pg, a->W / 16, a->H / 8, 1.0f / (float)(a->W / 16));
     if (g_debug[8] != 1) {                                           // ANODDPM_DEBUG8=1: the two-launch fold
-        hipLaunchKernelGGL(wgrad43_fold_kernel, dim3((unsigned)((int64_t)K * (a->N / 64))), dim3(288), 0, s, *a, pg);
+        hipLaunchKernelGGL(wgrad43_fold_kernel, dim3((unsigned)((int64_t)K * (a->N / 64) + (a->dimg ? a->N / 32 : 0))), dim3(288), 0, s, *a, pg, 0);
         return check_launch("conv3x3_wgrad (Winograd)");
     }
     if (pg > 1) hipLaunchKernelGGL(wgrad43_sum_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, a->ws, slab, pg);
     hipLaunchKernelGGL(wgrad43_out_kernel, dim3((unsigned)(((int64_t)K * a->N + 255) / 256)), dim3(256), 0, s, *a);
+    if (a->dimg) hipLaunchKernelGGL(wgrad43_fold_kernel, dim3((unsigned)(a->N / 32)), dim3(288), 0, s, *a, pg, K * (a->N / 64));   // column sums only
     return check_launch("conv3x3_wgrad (Winograd)");
 }
 

@@ -276,7 +276,7 @@ class TrainPlan(_Plan):
         wa.algo = algo
         if algo:
             wa.ws_floats = lib().anoddpm_wgrad43_groups(K, N, B, H, W) * 18 * K * N
-            ipb = lib().anoddpm_wgrad43_patches(H, W)            # column sums per output patch of the kernel
+            ipb = lib().anoddpm_wgrad43_colsum_items(K, N, B, H, W)   # column-sum rows per image: one per workgroup set and tile row
         else:
             wa.ws_floats = nitems * 9 * K * N
         self.tws(wa, "ws", wa.ws_floats)
@@ -287,10 +287,16 @@ class TrainPlan(_Plan):
         wa.a_mode, wa.act, wa.gn_ld, wa.band, wa.accumulate = a_mode, (1 if gn is not None else 0), K, band, 1
         colsum = self.buf(B, ipb, N)
         wa.colsum = colsum.data_ptr()
-        self.badd(_lib.OP_WGRAD3, wa)
-        cf = ColsumFoldArgs()
         if d_emb is None:
             d_emb = self.buf(B, N)                               # per-image sums: scratch when only the bias gradient is wanted
+        wa.dimg = wa.dbias = None
+        if algo:
+            # the fold launch of the Winograd-domain kernel also folds the column sums (round 6: 64 colsum_fold launches less per step)
+            wa.dimg, wa.dbias = d_emb.data_ptr(), self.dW(bkey)
+            self.badd(_lib.OP_WGRAD3, wa)
+            return
+        self.badd(_lib.OP_WGRAD3, wa)
+        cf = ColsumFoldArgs()
         cf.colsum, cf.dimg, cf.dbias = colsum.data_ptr(), d_emb.data_ptr(), self.dW(bkey)
         cf.B, cf.ipb, cf.N = B, ipb, N
         self.badd(_lib.OP_COLSUM_FOLD, cf)

@@ -631,13 +631,17 @@ typedef struct anoddpm_wgrad_args {
     int32_t algo;                   /* 0: direct (nine-tap MFMA tiles, any shape above); 1: Winograd F(4x4,3x3) domain (wgrad43.hip),
                                        the adjoint of the cfg-3 forward kernel: dU = sum_tiles V (.) Z, dg = G^T dU G -- needs
                                        gn + act == 1, a_mode 0 / 1, H % 8 == 0, W % 16 == 0, K % 32 == 0, N % 64 == 0,
-                                       c0 % 16 == 0, B <= 15; ws: anoddpm_wgrad43_groups(...) * 18 * K * N floats; colsum items =
-                                       the kernel's output patches, [B][anoddpm_wgrad43_patches(H, W)][N]; `band` is ignored */
+                                       c0 % 16 == 0, B <= 15; ws: anoddpm_wgrad43_groups(...) * 18 * K * N floats; colsum:
+                                       [B][anoddpm_wgrad43_colsum_items(...)][N], one row per workgroup set and tile row (the
+                                       kernel sums over its patches of an image); `band` is ignored */
+    float *dimg, *dbias;            /* algo 1 only, optional (need colsum): dimg[B][N] = per-image sums of dy (embedding gradient),
+                                       dbias[N] += their sum over the images -- anoddpm_colsum_fold done by N / 32 extra
+                                       workgroups of the fold launch instead of a launch of its own (round 6) */
 } anoddpm_wgrad_args;
 
 int anoddpm_conv3x3_wgrad(const anoddpm_wgrad_args *a, void *stream);
 int anoddpm_wgrad43_groups(int32_t K, int32_t N, int32_t B, int32_t H, int32_t W);   /* workgroup sets (workspace slabs) of algo 1 */
-int anoddpm_wgrad43_patches(int32_t H, int32_t W);                                    /* column-sum items per image of algo 1 */
+int anoddpm_wgrad43_colsum_items(int32_t K, int32_t N, int32_t B, int32_t H, int32_t W);   /* column-sum rows per image of algo 1 */
 
 /* Device-side weight packing for the 3x3 kernels (training re-packs after every optimizer step).  w: OIHW [N][K][3][3].
  * mode 0: direct layout [9][I/4][O][4]; mode 1: Winograd F(2x2,3x3) U = G g G^T as [16][I/4][O][4]; mode 2: Winograd

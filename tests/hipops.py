@@ -339,7 +339,7 @@ def head(x, w, b, scale, shift):
     return out
 
 
-def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into=None, colsum_out=None, algo=0):
+def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into=None, colsum_out=None, algo=0, bias_out=None):
     """dW (OIHW) of a 3x3 conv whose input is the fused operand load of `conv_igemm` (anoddpm_conv3x3_wgrad).
     srcs: NHWC sources; dy: NHWC [B,H,W,N]."""
     from anoddpm_amd._lib import WgradArgs
@@ -354,7 +354,7 @@ def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into
     nitems = B * (W // TW) * (-(-H // band))
     if algo == 1:                       # Winograd-domain weight gradient: PG slabs of [36][K][N]; column sums per 16x8 output patch
         ws = torch.empty(lib().anoddpm_wgrad43_groups(K, N, B, H, W) * 18 * K * N, device=dev)
-        nitems = B * lib().anoddpm_wgrad43_patches(H, W)
+        nitems = B * lib().anoddpm_wgrad43_colsum_items(K, N, B, H, W)
     else:
         ws = torch.empty(nitems * 9 * K * N, device=dev)
     dw = accumulate_into if accumulate_into is not None else torch.full((N, K, 3, 3), float("nan"), device=dev)
@@ -373,6 +373,12 @@ def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into
         cs = torch.full((B, nitems // B, N), float("nan"), device=dev)
         st.colsum = cs.data_ptr()
         colsum_out.append(cs)
+    if bias_out is not None:
+        # algo 1: the fold launch also folds the column sums -> bias_out = {"dimg": [B, N] per-image sums of dy, "dbias": [N] += their sum}
+        assert algo == 1 and colsum_out is not None
+        bias_out["dimg"] = torch.full((B, N), float("nan"), device=dev)
+        bias_out.setdefault("dbias", torch.zeros(N, device=dev))
+        st.dimg, st.dbias = bias_out["dimg"].data_ptr(), bias_out["dbias"].data_ptr()
     check(lib().anoddpm_conv3x3_wgrad(ctypes.byref(st), current_stream()), "conv3x3_wgrad")
     torch.cuda.synchronize()
     return dw

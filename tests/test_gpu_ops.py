@@ -656,16 +656,20 @@ def test_conv3x3_wgrad_winograd_domain(case):
     assert relerr(got, dw_ref) < 1e-4, relerr(got, dw_ref)
     direct = hipops.conv_wgrad(srcs, dyn, gn=gn, act=1, a_mode=a_mode)
     assert relerr(got, direct) < 1e-4
-    # column sums of dY per column-sum item of the kernel (a 16-pixel-wide strip of its output patch; the item height is the
-    # kernel's business, anoddpm_wgrad43_patches reports the count) -> per image sums over pixels (bias / embedding gradients)
+    # column sums of dY: one row per workgroup set and tile row of the kernel (it sums over its patches of an image; sets without a
+    # patch in an image write zeros) -> per image sums over pixels (embedding gradient) and, over the batch, the bias gradient
     from anoddpm_amd._lib import lib
-    items = lib().anoddpm_wgrad43_patches(Hout, Hout)
-    assert cs[0].shape == (B, items, N) and items % (Hout // 16) == 0
-    ih = Hout // (items // (Hout // 16))                                  # item height in pixels
-    assert ih in (4, 8)
+    K = c0 + c1
+    items = lib().anoddpm_wgrad43_colsum_items(K, N, B, Hout, Hout)
+    assert items == 2 * lib().anoddpm_wgrad43_groups(K, N, B, Hout, Hout)
+    assert cs[0].shape == (B, items, N) and torch.isfinite(cs[0]).all()
     assert relerr(cs[0].sum(dim=1), dy.sum(dim=(2, 3))) < 1e-5
-    last = dy[:, :, Hout - ih:, Hout - 16:].sum(dim=(2, 3))             # the last item (bottom right)
-    assert relerr(cs[0][:, -1, :], last) < 1e-5
+    # the same sums folded by the extra workgroups of the fold launch (dimg / dbias): no anoddpm_colsum_fold launch
+    bo = {"dbias": torch.ones(N, device=dev())}
+    got2 = hipops.conv_wgrad(srcs, dyn, gn=gn, act=1, a_mode=a_mode, colsum_out=[], algo=1, bias_out=bo)
+    assert torch.equal(got2, got)
+    assert relerr(bo["dimg"], dy.sum(dim=(2, 3))) < 1e-5
+    assert relerr(bo["dbias"], 1.0 + dy.sum(dim=(0, 2, 3))) < 1e-5
     acc = got.clone()
     hipops.conv_wgrad(srcs, dyn, gn=gn, act=1, a_mode=a_mode, accumulate_into=acc, algo=1)
     assert relerr(acc, 2 * dw_ref) < 1e-4

@@ -284,8 +284,8 @@ def test_host_side_shape_helpers_of_the_library():
     for (H, C) in ((256, 128), (512, 128), (64, 64), (16, 1024)):
         rows = L.anoddpm_stem_stats_rows(H, H, 1, C)
         assert rows > 0 and (H * H) % rows == 0 and (H * H // rows) % (8 * (256 // (C // 4))) == 0     # whole workgroup trips
-    # weight gradient, algo 1: column-sum items per image (a tile row of a 16 x 8 patch each); groups x blocks fill the 256 CUs
-    assert L.anoddpm_wgrad43_patches(256, 256) == 1024 and L.anoddpm_wgrad43_patches(32, 32) == 16      # one item per 16 x 4 tile row
+    # weight gradient, algo 1: groups x blocks fill the 256 CUs; column-sum rows per image = one per group and tile row of its patches
+    assert L.anoddpm_wgrad43_colsum_items(128, 128, 4, 256, 256) == 64 and L.anoddpm_wgrad43_colsum_items(512, 512, 4, 32, 32) == 4   # 2 rows per set
     assert L.anoddpm_wgrad43_groups(128, 128, 4, 256, 256) == 32 and L.anoddpm_wgrad43_groups(512, 512, 4, 32, 32) == 2
     assert L.anoddpm_wgrad43_groups(32, 64, 1, 16, 16) == 2                                       # fewer patches than groups
 

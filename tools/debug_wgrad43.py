@@ -51,7 +51,7 @@ st.a_mode, st.act, st.gn_ld, st.band, st.accumulate, st.algo = 0, 1, K, 4, 0, 1
 check(lib().anoddpm_conv3x3_wgrad(ctypes.byref(st), current_stream()), "wgrad")
 torch.cuda.synchronize()
 got = ws.view(pg, 18, K, N).double().sum(0).cpu()
-print("pg", pg, "patches/img", lib().anoddpm_wgrad43_patches(H, H))
+print("pg", pg, "colsum rows per image", lib().anoddpm_wgrad43_colsum_items(K, N, B, H, H))
 err = (got - dU).abs().amax(dim=(1, 2)) / dU.abs().amax()
 print("per-plane relative error (6 rows u x 3 columns b):")
 print(np.array2string(err.view(6, 3).numpy(), precision=3, suppress_small=True))
