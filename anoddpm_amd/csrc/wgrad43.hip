@@ -20,8 +20,8 @@
 //      workgroups of the first input-channel block;
 //   3. 48 MFMAs per wave: operands are 4-byte LDS reads of V / Z [pos][tile][channel] (16 channels x 4 tiles per wave read).
 // VALU (transforms) and MFMA phases alternate -- on this hardware they share the issue port anyway -- four barriers per patch.
-// The per-workgroup gradient goes to a workspace [PG][18][K][N] with the first half of G^T . G applied (r = dU G: wave pairs meet in
-// LDS); one small kernel sums the PG slabs and applies the second half.
+// The per-workgroup gradient goes to a workspace [PG][9][K][N] with dg = G^T dU G applied in the epilogue (two exchanges through LDS);
+// one small kernel sums the PG slabs into dw.
 #include "common.h"
 
 using anoddpm::silu_f;
@@ -331,10 +331,10 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
         cs_store(cs_b, cs_acc0, cs_acc1);
         for (int bb = cs_b + 1; bb < a.B; ++bb) cs_store(bb, 0.f, 0.f);
     }
-    // ---- partial gradient of this workgroup, with the first half of dg = G^T dU G applied: ws[pg][u * 3 + b][k][n] = r[u][b] =
-    // sum_v dU[u][v] G[v][b].  Wave w holds half a row of dU -- u = w >> 1, v = 3 (w & 1) + {0, 1, 2} -- so it forms its three partial
-    // sums in registers, the odd wave of a pair hands them to the even one through LDS (lane to lane: both map lanes to (k, n) alike),
-    // and the even wave stores 18 instead of 36 planes: half the slab traffic of this kernel and of the fold (round 6).
+    // ---- partial gradient of this workgroup with dg = G^T dU G applied (round 6; until then the 36 planes of dU went to the workspace).
+    // First half, r[u][b] = sum_v dU[u][v] G[v][b]: wave w holds half a row of dU -- u = w >> 1, v = 3 (w & 1) + {0, 1, 2} -- so it forms
+    // its three partial sums in registers and the odd wave of a pair hands them to the even one through LDS (lane to lane: both map
+    // lanes to (k, n) alike).
     __syncthreads();                                                // every wave is past its last MFMA operand reads: LDS is scratch now
     {
         // G (6 x 3): rows (1/4, 0, 0), (-1/6, -1/6, -1/6), (-1/6, 1/6, -1/6), (1/24, 1/12, 1/6), (1/24, -1/12, 1/6), (0, 0, 1)
@@ -373,23 +373,44 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
                         for (int r = 0; r < 4; ++r) xch[(bb * 32 + (i * 4 + j) * 4 + r) * 64] = acc[bb][i][j][r];
         }
         __syncthreads();
-        if (!hi) {
+        if (!hi) {                                                  // r[u][b] complete, back into the exchange buffer (same lane, same address)
 #pragma unroll
-            for (int bb = 0; bb < 3; ++bb) {
-                float *dst = a.ws + (((int64_t)pg * 18 + u * 3 + bb) * K + k0 + 4 * kq) * N + n0 + l15;
+            for (int bb = 0; bb < 3; ++bb)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int e = 0; e < 32; ++e) {
+                    float *q = xch + (bb * 32 + e) * 64;
+                    *q = acc[bb][e >> 4][(e >> 2) & 3][e & 3] + *q;
+                }
+        }
+        __syncthreads();
+        // second half: dg[a][b] = sum_u G[u][a] r[u][b].  All twelve waves: wave = (column b = w % 3, eight of the 32 elements e = (i, j, r)
+        // per lane: group w / 3); six LDS reads -> three stores.  ws[pg][a * 3 + b][k][n]: NINE planes per (k, n), a quarter of the
+        // round-5 slab traffic of this kernel and of the fold (which only sums the PG slabs now).
+        {
+            const int b2 = wave % 3, eg = wave / 3;
+            const float *R = reinterpret_cast<const float *>(lds4) + lane;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+            for (int ee = 0; ee < 8; ++ee) {
+                const int e = eg * 8 + ee;                          // = (i * 4 + j) * 4 + r
+                const int i = e >> 4, j = (e >> 2) & 3, r = e & 3;
+                float ru[6];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            dst[(int64_t)(i * 16 + r) * N + j * 16] = acc[bb][i][j][r] + xch[(bb * 32 + (i * 4 + j) * 4 + r) * 64];
+                for (int uu = 0; uu < 6; ++uu) ru[uu] = R[((uu * 3 + b2) * 32 + e) * 64];
+                const float s12 = ru[1] + ru[2], m12 = ru[2] - ru[1], s34 = ru[3] + ru[4], m34 = ru[3] - ru[4];
+                const float g0 = 0.25f * ru[0] - (1.f / 6) * s12 + (1.f / 24) * s34;
+                const float g1 = (1.f / 6) * m12 + (1.f / 12) * m34;
+                const float g2 = -(1.f / 6) * s12 + (1.f / 6) * s34 + ru[5];
+                float *dst = a.ws + (((int64_t)pg * 9 + b2) * K + k0 + 4 * kq + i * 16 + r) * N + n0 + l15 + j * 16;
+                const int64_t plane3 = (int64_t)3 * K * N;          // a -> a + 1: three planes further
+                dst[0] = g0;
+                dst[plane3] = g1;
+                dst[2 * plane3] = g2;
             }
         }
     }
 }
 
-// ws[0][plane][k][n] <- sum over the PG slabs, fixed order (thread = one (plane, k, n); 16 slabs in flight)
+// ws[0][ab][k][n] <- sum over the PG slabs, fixed order (thread = one (ab, k, n); 16 slabs in flight)
 __global__ __launch_bounds__(256) void wgrad43_sum_kernel(float *ws, const int64_t slab, const int PG)
 {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -408,50 +429,38 @@ __global__ __launch_bounds__(256) void wgrad43_sum_kernel(float *ws, const int64
     ws[idx] = s;
 }
 
-__constant__ float G63[6][3] = {{1.f / 4, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
-                                {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
-
-// dw[n][k][a][b] (+)= sum_u G[u][a] r[u][b]   (thread = one (k, n); the second half of G^T dU G)
+// dw[n][k][a][b] (+)= ws[0][a * 3 + b][k][n]   (thread = one (k, n))
 __global__ __launch_bounds__(256) void wgrad43_out_kernel(const anoddpm_wgrad_args a)
 {
     const int K = a.c0 + a.c1, N = a.N;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)K * N) return;
     const int n = (int)(idx % N), k = (int)(idx / N);
-    float r[6][3];
-#pragma unroll
-    for (int u = 0; u < 6; ++u)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) r[u][b] = a.ws[((int64_t)(u * 3 + b) * K + k) * N + n];
     float *o = a.dw + ((int64_t)n * K + k) * 9;
 #pragma unroll
-    for (int aa = 0; aa < 3; ++aa)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            float s = 0.f;
-#pragma unroll
-            for (int u = 0; u < 6; ++u) s += G63[u][aa] * r[u][b];
-            o[aa * 3 + b] = a.accumulate ? o[aa * 3 + b] + s : s;
-        }
+    for (int ab = 0; ab < 9; ++ab) {
+        const float s = a.ws[((int64_t)ab * K + k) * N + n];
+        o[ab] = a.accumulate ? o[ab] + s : s;
+    }
 }
 
-// Both steps in one launch: workgroup = one input channel k x 64 output channels, 288 threads.  Thread (plane = u * 3 + b, lane
-// quad q) folds four output channels of its plane over the PG slabs (slab order; sixteen 16-byte loads in flight), the 18 x 64
-// sums meet in LDS, then the row transform (9 x 64 items, writing dw[n][k][3][3]).  Same order of every sum as
-// wgrad43_sum_kernel + wgrad43_out_kernel (bit-identical), one launch and one pass over the slabs.
+// Both steps in one launch: workgroup = two input channels k x 64 output channels, 288 threads.  Thread (k of the pair, plane ab,
+// lane quad q) folds four output channels of its plane over the PG slabs (slab order; sixteen 16-byte loads in flight), the
+// 2 x 9 x 64 sums meet in LDS and leave as dw[n][k][3][3] (36-byte runs per (n, k)).  Same order of every sum as wgrad43_sum_kernel +
+// wgrad43_out_kernel (bit-identical), one launch and one pass over the slabs.  blk0: block offset (the column-sum blocks alone).
 __global__ __launch_bounds__(288) void wgrad43_fold_kernel(const anoddpm_wgrad_args a, const int PG, const int blk0)
 {
     const int bid = (int)blockIdx.x + blk0;
-    __shared__ __attribute__((aligned(16))) float rr[18][64];
+    __shared__ __attribute__((aligned(16))) float rr[2][9][64];
     const int K = a.c0 + a.c1, N = a.N;
     const int tiles_n = N >> 6;
-    if (bid >= K * tiles_n) {
+    if (bid >= (K >> 1) * tiles_n) {
         // the N / 32 blocks behind the weight blocks fold the kernel's column sums (2 PG rows per image): dimg[b][n] = the image's
         // sum of dy (embedding gradient), dbias[n] += their sum over the images in index order -- what anoddpm_colsum_fold does in
         // a launch of its own.  32 channels x 9 row lanes.
-        float (*red)[32] = reinterpret_cast<float (*)[32]>(&rr[0][0]);
+        float (*red)[32] = reinterpret_cast<float (*)[32]>(&rr[0][0][0]);
         const int l = threadIdx.x & 31, il = threadIdx.x >> 5;
-        const int n = (bid - K * tiles_n) * 32 + l;
+        const int n = (bid - (K >> 1) * tiles_n) * 32 + l;
         const int rows = 2 * PG;
         float tot = 0.f;
         for (int b = 0; b < a.B; ++b) {
@@ -472,11 +481,12 @@ __global__ __launch_bounds__(288) void wgrad43_fold_kernel(const anoddpm_wgrad_a
         if (il == 0 && a.dbias) a.dbias[n] += tot;
         return;
     }
-    const int k = bid / tiles_n, n0 = (bid % tiles_n) * 64;
-    const int plane = threadIdx.x >> 4, q = threadIdx.x & 15;
-    const int64_t slab = (int64_t)18 * K * N;
+    const int k0 = (bid / tiles_n) * 2, n0 = (bid % tiles_n) * 64;
+    const int kk = threadIdx.x / 144, rem = threadIdx.x - kk * 144;
+    const int plane = rem >> 4, q = rem & 15;
+    const int64_t slab = (int64_t)9 * K * N;
     {
-        const float *p = a.ws + ((int64_t)plane * K + k) * N + n0 + 4 * q;
+        const float *p = a.ws + ((int64_t)plane * K + k0 + kk) * N + n0 + 4 * q;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         int g = 0;
         for (; g + 16 <= PG; g += 16) {
@@ -487,16 +497,14 @@ __global__ __launch_bounds__(288) void wgrad43_fold_kernel(const anoddpm_wgrad_a
             for (int i = 0; i < 16; ++i) s += x[i];
         }
         for (; g < PG; ++g) s += *reinterpret_cast<const f32x4 *>(p + (int64_t)g * slab);
-        *reinterpret_cast<f32x4 *>(&rr[plane][4 * q]) = s;
+        *reinterpret_cast<f32x4 *>(&rr[kk][plane][4 * q]) = s;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 9 * 64; i += 288) {                // 64 x 9 outputs
-        const int n = i / 9, ab = i - n * 9, aa = ab / 3, b = ab - aa * 3;
-        float s = 0.f;
-#pragma unroll
-        for (int uu = 0; uu < 6; ++uu) s += G63[uu][aa] * rr[uu * 3 + b][n];
-        float *o = a.dw + ((int64_t)(n0 + n) * K + k) * 9 + ab;
-        *o = a.accumulate ? *o + s : s;
+    for (int i = threadIdx.x; i < 2 * 9 * 64; i += 288) {            // (n, k of the pair, ab): 18 consecutive floats of dw per n
+        const int n = i / 18, r18 = i - n * 18, k2 = r18 / 9, ab = r18 - k2 * 9;
+        const float v = rr[k2][ab][n];
+        float *o = a.dw + ((int64_t)(n0 + n) * K + k0 + k2) * 9 + ab;
+        *o = a.accumulate ? *o + v : v;
     }
 }
 
@@ -534,17 +542,17 @@ int launch_wgrad43(const anoddpm_wgrad_args *a, hipStream_t s)
     ANODDPM_REQUIRE(!a->dimg || a->colsum, "wgrad (Winograd): dimg / dbias are folded from colsum");
     ANODDPM_REQUIRE(!a->dbias || a->dimg, "wgrad (Winograd): dbias needs dimg (the per-image sums it adds up)");
     ANODDPM_REQUIRE((int64_t)a->B * 2 * pg * a->N * 4 < ((int64_t)1 << 31), "wgrad (Winograd): colsum exceeds 32-bit buffer offsets");
-    const int64_t slab = (int64_t)18 * K * a->N;                     // the kernel stores r = dU G: 18 planes per (k, n)
+    const int64_t slab = (int64_t)9 * K * a->N;                      // the kernel stores dg = G^T dU G of its patches: 9 planes per (k, n)
     ANODDPM_REQUIRE(a->ws_floats >= (int64_t)pg * slab, "wgrad (Winograd): workspace too small");
     const dim3 grid((unsigned)pg, (unsigned)((K / G4_KB) * (a->N / G4_NB)));
     hipLaunchKernelGGL(wgrad43_kernel, grid, dim3(G4_NT), 0, s, *a, pg, a->W / 16, a->H / 8, 1.0f / (float)(a->W / 16));
     if (g_debug[8] != 1) {                                           // ANODDPM_DEBUG8=1: the two-launch fold
-        hipLaunchKernelGGL(wgrad43_fold_kernel, dim3((unsigned)((int64_t)K * (a->N / 64) + (a->dimg ? a->N / 32 : 0))), dim3(288), 0, s, *a, pg, 0);
+        hipLaunchKernelGGL(wgrad43_fold_kernel, dim3((unsigned)((int64_t)(K / 2) * (a->N / 64) + (a->dimg ? a->N / 32 : 0))), dim3(288), 0, s, *a, pg, 0);
         return check_launch("conv3x3_wgrad (Winograd)");
     }
     if (pg > 1) hipLaunchKernelGGL(wgrad43_sum_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, a->ws, slab, pg);
     hipLaunchKernelGGL(wgrad43_out_kernel, dim3((unsigned)(((int64_t)K * a->N + 255) / 256)), dim3(256), 0, s, *a);
-    if (a->dimg) hipLaunchKernelGGL(wgrad43_fold_kernel, dim3((unsigned)(a->N / 32)), dim3(288), 0, s, *a, pg, K * (a->N / 64));   // column sums only
+    if (a->dimg) hipLaunchKernelGGL(wgrad43_fold_kernel, dim3((unsigned)(a->N / 32)), dim3(288), 0, s, *a, pg, (K / 2) * (a->N / 64));   // column sums only
     return check_launch("conv3x3_wgrad (Winograd)");
 }
 

@@ -275,7 +275,7 @@ class TrainPlan(_Plan):
         wa.dy, wa.dw = dy.data_ptr(), self.dW(wkey)
         wa.algo = algo
         if algo:
-            wa.ws_floats = lib().anoddpm_wgrad43_groups(K, N, B, H, W) * 18 * K * N
+            wa.ws_floats = lib().anoddpm_wgrad43_groups(K, N, B, H, W) * 9 * K * N
             ipb = lib().anoddpm_wgrad43_colsum_items(K, N, B, H, W)   # column-sum rows per image: one per workgroup set and tile row
         else:
             wa.ws_floats = nitems * 9 * K * N

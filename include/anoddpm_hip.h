@@ -631,7 +631,7 @@ typedef struct anoddpm_wgrad_args {
     int32_t algo;                   /* 0: direct (nine-tap MFMA tiles, any shape above); 1: Winograd F(4x4,3x3) domain (wgrad43.hip),
                                        the adjoint of the cfg-3 forward kernel: dU = sum_tiles V (.) Z, dg = G^T dU G -- needs
                                        gn + act == 1, a_mode 0 / 1, H % 8 == 0, W % 16 == 0, K % 32 == 0, N % 64 == 0,
-                                       c0 % 16 == 0, B <= 15; ws: anoddpm_wgrad43_groups(...) * 18 * K * N floats; colsum:
+                                       c0 % 16 == 0, B <= 15; ws: anoddpm_wgrad43_groups(...) * 9 * K * N floats; colsum:
                                        [B][anoddpm_wgrad43_colsum_items(...)][N], one row per workgroup set and tile row (the
                                        kernel sums over its patches of an image); `band` is ignored */
     float *dimg, *dbias;            /* algo 1 only, optional (need colsum): dimg[B][N] = per-image sums of dy (embedding gradient),

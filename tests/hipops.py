@@ -353,7 +353,7 @@ def conv_wgrad(srcs, dy, *, gn=None, act=0, a_mode=0, band=None, accumulate_into
     band = band or max(1, H // 4)
     nitems = B * (W // TW) * (-(-H // band))
     if algo == 1:                       # Winograd-domain weight gradient: PG slabs of [36][K][N]; column sums per 16x8 output patch
-        ws = torch.empty(lib().anoddpm_wgrad43_groups(K, N, B, H, W) * 18 * K * N, device=dev)
+        ws = torch.empty(lib().anoddpm_wgrad43_groups(K, N, B, H, W) * 9 * K * N, device=dev)
         nitems = B * lib().anoddpm_wgrad43_colsum_items(K, N, B, H, W)
     else:
         ws = torch.empty(nitems * 9 * K * N, device=dev)

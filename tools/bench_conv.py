@@ -85,7 +85,7 @@ if os.environ.get("WG"):                                 # WG=1: 3x3 weight grad
             nband = max(1, min(H, round(512 / per_band)))
             band = -(-H // nband)
             nitems = B * (H // TW) * -(-H // band)
-            nws = lib().anoddpm_wgrad43_groups(K, N, B, H, H) * 18 * K * N if algo else nitems * 9 * K * N
+            nws = lib().anoddpm_wgrad43_groups(K, N, B, H, H) * 9 * K * N if algo else nitems * 9 * K * N
             ws = torch.empty(nws, device=dev)
             dw = torch.zeros(N, K, 3, 3, device=dev)
             st = WgradArgs()

@@ -1,5 +1,5 @@
-"""Debug: Winograd-domain weight gradient workspace of anoddpm_conv3x3_wgrad algo 1 (r[u][b] = sum_v dU[u][v] G[v][b]: the kernel
-stores 18 planes per (k, n) since round 6) vs an fp64 torch evaluation."""
+"""Debug: Winograd-domain weight gradient workspace of anoddpm_conv3x3_wgrad algo 1 (dg[a][b] = sum_uv G[u][a] dU[u][v] G[v][b] of the workgroup's patches: the kernel
+stores 9 planes per (k, n) since round 6) vs an fp64 torch evaluation."""
 import ctypes, sys, os
 import torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
@@ -35,10 +35,10 @@ for b in range(B):
 K = c0
 pg = lib().anoddpm_wgrad43_groups(K, N, B, H, H)
 G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
-def half_g(t):                                             # [36, ...] -> [18, ...]: r[u][b] = sum_v t[u][v] G[v][b]
-    return torch.einsum("uv...,vb->ub...", t.reshape(6, 6, *t.shape[1:]), G).reshape(18, *t.shape[1:])
+def half_g(t):                                             # [36, ...] -> [9, ...]: dg[a][b] = sum_uv G[u][a] t[u][v] G[v][b]
+    return torch.einsum("uv...,ua,vb->ab...", t.reshape(6, 6, *t.shape[1:]), G, G).reshape(9, *t.shape[1:])
 dU = half_g(dU)
-ws = torch.zeros(pg * 18 * K * N, device=dev)
+ws = torch.zeros(pg * 9 * K * N, device=dev)
 dw = torch.zeros(N, K, 3, 3, device=dev)
 st = WgradArgs()
 st.a0, st.a1 = xs.data_ptr(), None
@@ -50,11 +50,11 @@ st.H, st.W, st.N, st.B = H, H, N, B
 st.a_mode, st.act, st.gn_ld, st.band, st.accumulate, st.algo = 0, 1, K, 4, 0, 1
 check(lib().anoddpm_conv3x3_wgrad(ctypes.byref(st), current_stream()), "wgrad")
 torch.cuda.synchronize()
-got = ws.view(pg, 18, K, N).double().sum(0).cpu()
+got = ws.view(pg, 9, K, N).double().sum(0).cpu()
 print("pg", pg, "colsum rows per image", lib().anoddpm_wgrad43_colsum_items(K, N, B, H, H))
 err = (got - dU).abs().amax(dim=(1, 2)) / dU.abs().amax()
-print("per-plane relative error (6 rows u x 3 columns b):")
-print(np.array2string(err.view(6, 3).numpy(), precision=3, suppress_small=True))
+print("per-plane relative error (3 x 3 taps):")
+print(np.array2string(err.view(3, 3).numpy(), precision=3, suppress_small=True))
 e_k = (got - dU).abs().amax(dim=(0, 2)) / dU.abs().amax()
 print("per input channel:", np.array2string(e_k.numpy(), precision=2))
 e_n = (got - dU).abs().amax(dim=(0, 1)) / dU.abs().amax()
@@ -62,9 +62,9 @@ print("per output channel:", np.array2string(e_n.numpy(), precision=2))
 print("ratio got/ref where ref large:", (got / dU)[dU.abs() > dU.abs().amax() * 0.3][:10])
 
 # which (V tile, Z tile) products does each workgroup's slab contain?  least squares over all 16 x 16 tile pairs
-slabs = ws.view(pg, 18, K, N).double().cpu()
+slabs = ws.view(pg, 9, K, N).double().cpu()
 keys = sorted(Vs)
-basis = torch.stack([half_g(torch.einsum("cuv,nuv->uvcn", Vs[a], Zs[b]).reshape(36, c0, N)).reshape(-1) for a in keys for b in keys], 1)    # [18*K*N, 256]
+basis = torch.stack([half_g(torch.einsum("cuv,nuv->uvcn", Vs[a], Zs[b]).reshape(36, c0, N)).reshape(-1) for a in keys for b in keys], 1)    # [9*K*N, 256]
 for g in range(pg):
     sol = torch.linalg.lstsq(basis, slabs[g].reshape(-1, 1)).solution.view(len(keys), len(keys))
     big = [(keys[i], keys[j], round(float(sol[i, j]), 3)) for i in range(len(keys)) for j in range(len(keys)) if abs(sol[i, j]) > 0.05]
