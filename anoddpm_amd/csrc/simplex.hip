@@ -36,7 +36,7 @@ __constant__ signed char kGrad3[72] = {
 //           32), which cuts the bank conflicts of these random lookups -- the kernel is LDS-conflict bound as much as VALU bound.
 //   grad[g] = {gx, gy, gz} as doubles (components +-4 / +-11 of GRADIENTS3, simplex.py:116-127) in 48-byte rows: only rows g and
 //           g + 16 share banks (32-byte rows: g, g + 8, g + 16)
-// plus the two generated tables of simplex_tables.h: which two extra vertices a region decision selects, and each vertex's
+// plus the two generated tables of simplex_tables.h: which two extra vertices the region's comparison bits select, and each vertex's
 // displacement recipe / hash offsets.
 struct Tables {
     uint2 PG[512];
@@ -50,7 +50,7 @@ __device__ __forceinline__ void load_tables(Tables &T, const int16_t *src)
     for (int i = threadIdx.x; i < 512; i += blockDim.x)
         T.PG[i] = make_uint2(8u * (unsigned)(src[i & 255] & 0xFF), 48u * (unsigned)(src[256 + (i & 255)] / 3));
     for (int i = threadIdx.x; i < 72; i += blockDim.x) T.grad[i / 3][i % 3] = (double)kGrad3[i];
-    for (int i = threadIdx.x; i < 384; i += blockDim.x) T.lut[i] = kExtraLut[i];
+    for (int i = threadIdx.x; i < 384; i += blockDim.x) T.lut[i] = kRegionLut[i];
     for (int i = threadIdx.x; i < 128 * 9; i += blockDim.x) {
         const int e = i / 9, w = i - e * 9;                          // 72-byte source entries -> 80-byte LDS rows
         unsigned long long v = reinterpret_cast<const unsigned long long *>(&kVertex[e])[w];
@@ -117,49 +117,30 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
     const double in_sum = xins + yins + zins;
     const double dx0 = x - xb, dy0 = y - yb, dz0 = z - zb;
 
-    // ---- region decisions of simplex.py:354-798, branch-free: all three candidates are formed and the one that applies indexes
-    // kExtraLut (the reference's if / elif chains become selects; an `elif` arm is gated by the negation of the arm before it)
+    // ---- region decisions of simplex.py:354-798, branch-free.  The reference's if / elif chains depend on nineteen comparisons of the
+    // inside coordinates only; their results are gathered into a 7-bit index per candidate region and ONE table lookup (kRegionLut,
+    // generated from the chains themselves by tools/gen_simplex_tables.py) yields the two extra vertices -- no score is materialised,
+    // no decision code is built from selects (round 6: 106 -> 65 VALU instructions for this block).
     const bool regA = in_sum <= 1, regB = in_sum >= 2;
     unsigned idx;
     if (ABL == 2) {
-        idx = 128 + (3 | 5 << 3 | 1 << 6 | 1 << 7);
+        idx = 256 + (1 | 2 | 4);
     } else {
-        // Only comparisons and integer selects: a selected score (`a_score = z if ... else x`) is never materialised -- the
-        // comparison it feeds is taken from the comparisons of its candidates, so the branch structure turns into wave-mask
-        // logic on the scalar unit.  (An `elif` arm is gated by the negation of the arm before it.)
-        const bool x_ge_y = xins >= yins, x_lt_y = xins < yins, z_gt_y = zins > yins, z_gt_x = zins > xins;
-        // tetrahedron at (0,0,0): a = x|z, b = y|z (never both z)
-        const bool a1 = x_ge_y && z_gt_y;                            // b := z
-        const bool a2 = !a1 && (x_lt_y && z_gt_x);                   // a := z
+        const bool x_ge_y = xins >= yins, x_le_y = xins <= yins, z_gt_y = zins > yins, z_lt_y = zins < yins, z_gt_x = zins > xins, z_lt_x = zins < xins;
+        // tetrahedron at (0,0,0): w = 1 - in_sum against x, y, z
         const double winsA = 1 - in_sum;
-        const bool wAx = winsA > xins, wAy = winsA > yins, wAz = winsA > zins;
-        const bool sA = (a2 ? wAz : wAx) || (a1 ? wAz : wAy);
-        const bool b_gt_a = a1 ? z_gt_x : (a2 ? (yins > zins) : (yins > xins));        // b_score > a_score
-        const unsigned apA = a2 ? 4u : 1u, bpA = a1 ? 4u : 2u;
-        const unsigned cA = sA ? (b_gt_a ? bpA : apA) : (apA | bpA);
-        const unsigned idxA = (sA ? 8u : 0u) | cA;
-        // tetrahedron at (1,1,1)
-        const bool x_le_y = xins <= yins, x_gt_y = xins > yins, z_lt_y = zins < yins, z_lt_x = zins < xins;
-        const bool b1 = x_le_y && z_lt_y;
-        const bool b2 = !b1 && (x_gt_y && z_lt_x);
+        const unsigned iA = (x_ge_y ? 1u : 0u) | (z_gt_y ? 2u : 0u) | (z_gt_x ? 4u : 0u) | (z_lt_y ? 8u : 0u) |
+                            (winsA > xins ? 16u : 0u) | (winsA > yins ? 32u : 0u) | (winsA > zins ? 64u : 0u);
+        // tetrahedron at (1,1,1): w = 3 - in_sum
         const double winsB = 3 - in_sum;
-        const bool wBx = winsB < xins, wBy = winsB < yins, wBz = winsB < zins;
-        const bool sB = (b2 ? wBz : wBx) || (b1 ? wBz : wBy);
-        const bool b_lt_a = b1 ? z_lt_x : (b2 ? (yins < zins) : (yins < xins));        // b_score < a_score
-        const unsigned apB = b2 ? 3u : 6u, bpB = b1 ? 3u : 5u;
-        const unsigned cB = sB ? (b_lt_a ? bpB : apB) : (apB & bpB);
-        const unsigned idxB = 16u + ((sB ? 8u : 0u) | cB);
+        const unsigned iB = 128u + ((x_le_y ? 1u : 0u) | (z_lt_y ? 2u : 0u) | (z_lt_x ? 4u : 0u) | (z_gt_y ? 8u : 0u) |
+                                    (winsB < xins ? 16u : 0u) | (winsB < yins ? 32u : 0u) | (winsB < zins ? 64u : 0u));
         // octahedron: score = p - 1 or 1 - p, whichever is positive -- the two differences are exact negatives of each other
         const double p1 = xins + yins, p2 = xins + zins, p3 = yins + zins;
-        const bool f1 = p1 > 1, f2 = p2 > 1, f3 = p3 > 1;
         const double asC = fabs(p1 - 1), bsC = fabs(p2 - 1), scC = fabs(p3 - 1);
-        const bool t1 = asC <= bsC && asC < scC;
-        const bool t2 = !t1 && (asC > bsC && bsC < scC);
-        const unsigned p3c = f3 ? 6u : 1u;
-        const unsigned apC = t1 ? p3c : (f1 ? 3u : 4u), bpC = t2 ? p3c : (f2 ? 5u : 2u);
-        const bool afC = t1 ? f3 : f1, bfC = t2 ? f3 : f2;
-        const unsigned idxC = 128u + (apC | bpC << 3 | (afC ? 64u : 0u) | (bfC ? 128u : 0u));
-        idx = regA ? idxA : (regB ? idxB : idxC);
+        const unsigned iC = 256u + ((p1 > 1 ? 1u : 0u) | (p2 > 1 ? 2u : 0u) | (p3 > 1 ? 4u : 0u) | (asC <= bsC ? 8u : 0u) | (asC < scC ? 16u : 0u) |
+                                    (asC > bsC ? 32u : 0u) | (bsC < scC ? 64u : 0u));
+        idx = regA ? iA : (regB ? iB : iC);
     }
     const unsigned pair = lds_u16(T.lut, idx * 2);
 

@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
 """Generate anoddpm_amd/csrc/simplex_tables.h: the two lookup tables of the OpenSimplex-3D kernel (csrc/simplex.hip).
 
-  kExtraLut[384]   the two "extra" lattice vertices of an evaluation as a function of the region decisions of _noise3
-                   (simplex.py:354-798): u16 = id(e0) | id(e1) << 8.  Index:
-                       tetrahedron at (0,0,0):  (single << 3) | c                    single = (wins > a_score || wins > b_score)
-                       tetrahedron at (1,1,1):  16 + ((single << 3) | c)             single = (wins < a_score || wins < b_score)
-                       octahedron:              128 + (a_point | b_point << 3 | a_further << 6 | b_further << 7)
+  kRegionLut[384]  the two "extra" lattice vertices of an evaluation, u16 = id(e0) | id(e1) << 8, indexed DIRECTLY BY THE COMPARISON
+                   BITS of _noise3's region decisions (simplex.py:354-798; round 6 -- until then the kernel reduced the comparisons to
+                   a decision code with ~45 selects first):
+                       tetrahedron at (0,0,0):  [0, 128):   x>=y | z>y << 1 | z>x << 2 | z<y << 3 | w>x << 4 | w>y << 5 | w>z << 6      (w = 1 - in_sum)
+                       tetrahedron at (1,1,1):  [128, 256): x<=y | z<y << 1 | z<x << 2 | z>y << 3 | w<x << 4 | w<y << 5 | w<z << 6      (w = 3 - in_sum)
+                       octahedron:              [256, 384): p1>1 | p2>1 << 1 | p3>1 << 2 | |p1-1|<=|p2-1| << 3 | |p1-1|<|p3-1| << 4 |
+                                                            |p1-1|>|p2-1| << 5 | |p2-1|<|p3-1| << 6
+                   Every entry is the old decision code's entry (lut[] below: (single << 3) | c, 16 + ..., 128 + (a_point | b_point << 3 |
+                   a_further << 6 | b_further << 7)) for the code the reference's if / elif chains reach from those comparison results.
   kVertex[128]     per vertex id = (i+1) | (j+1) << 2 | (k+1) << 4 | late << 6 the displacement recipe
                        d = ((d0 - A) - n*SQUISH) - C            per axis (n = i + j + k)
                    as doubles {Ax, Ay, Az, n*SQUISH, Cx, Cy, Cz} + the hash offsets {2i, 2j, 2k}.  `late` marks the five vertices the
@@ -117,11 +121,43 @@ def main():
                 for bf in (0, 1):
                     e0, e1 = extras_octa(ap, bp, af, bf)
                     lut[128 + (ap | bp << 3 | af << 6 | bf << 7)] = e0 | e1 << 8
+    region = [0] * 384
+    for m in range(128):
+        bit = [(m >> k) & 1 for k in range(7)]
+        # tetrahedron at (0,0,0) -- the kernel's former select chain, verbatim
+        x_ge_y, z_gt_y, z_gt_x, z_lt_y, wx, wy, wz = bit
+        a1 = x_ge_y and z_gt_y
+        a2 = (not a1) and ((not x_ge_y) and z_gt_x)
+        s = (wz if a2 else wx) or (wz if a1 else wy)
+        b_gt_a = z_gt_x if a1 else (z_lt_y if a2 else (not x_ge_y))
+        ap, bp = (4 if a2 else 1), (4 if a1 else 2)
+        c = (bp if b_gt_a else ap) if s else (ap | bp)
+        region[m] = lut[(8 if s else 0) | c]
+        # tetrahedron at (1,1,1)
+        x_le_y, z_lt_y, z_lt_x, z_gt_y, wx, wy, wz = bit
+        b1 = x_le_y and z_lt_y
+        b2 = (not b1) and ((not x_le_y) and z_lt_x)
+        s = (wz if b2 else wx) or (wz if b1 else wy)
+        b_lt_a = z_lt_x if b1 else (z_gt_y if b2 else (not x_le_y))
+        ap, bp = (3 if b2 else 6), (3 if b1 else 5)
+        c = (bp if b_lt_a else ap) if s else (ap & bp)
+        region[128 + m] = lut[16 + ((8 if s else 0) | c)]
+        # octahedron
+        f1, f2, f3, le_ab, lt_ac, gt_ab, lt_bc = bit
+        t1 = le_ab and lt_ac
+        t2 = (not t1) and (gt_ab and lt_bc)
+        p3c = 6 if f3 else 1
+        ap = p3c if t1 else (3 if f1 else 4)
+        bp = p3c if t2 else (5 if f2 else 2)
+        af = f3 if t1 else f1
+        bf = f3 if t2 else f2
+        region[256 + m] = lut[128 + (ap | bp << 3 | (64 if af else 0) | (128 if bf else 0))]
+    lut = region
     out = ["// GENERATED by tools/gen_simplex_tables.py -- do not edit.  Lookup tables of csrc/simplex.hip (see the generator's docstring).",
            "#pragma once", "#include <stdint.h>", "",
            "struct SimplexVertex {", "    double ax, ay, az, sq, cx, cy, cz;", "    int32_t i2, j2, k2, pad;", "};",
            "static_assert(sizeof(SimplexVertex) == 72, \"SimplexVertex layout\");", "",
-           "__device__ const uint16_t kExtraLut[384] = {"]
+           "__device__ const uint16_t kRegionLut[384] = {"]
     for r in range(0, 384, 16):
         out.append("    " + ", ".join(f"0x{v:04x}" for v in lut[r:r + 16]) + ",")
     out += ["};", "", "__device__ const SimplexVertex kVertex[128] = {"]
