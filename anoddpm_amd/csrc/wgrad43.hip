@@ -53,8 +53,19 @@ constexpr int G4_AFF = 240;                        // float4: GroupNorm affine o
 constexpr int G4_LDS4 = 6 * G4_V + 2 * G4_PIN + 2 * G4_PDY + G4_AFF;      // 10,232 float4 = 163,712 B of the CU's 163,840
 static_assert(G4_LDS4 * 16 <= 160 * 1024, "wgrad43: LDS budget");
 
+// PROBE (measurement builds, ANODDPM_DEBUG12=1; tools/wgrad_phases.py): wave 0 sums s_memtime over the five phases of every patch and
+// leaves { stage, V + Z0 transforms, dY round 1, Z1 transform + requests, MFMAs, patches } behind the workspace slabs.
+template <bool PROBE>
 __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_args a, const int PG, const int tiles_x, const int tiles_y, const float inv_tx)
 {
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tprev = 0;
+    auto mark = [&](const int k) {
+        if (PROBE) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            ph[k] += t - tprev;
+            tprev = t;
+        }
+    };
     __shared__ __attribute__((aligned(16))) f32x4 lds4[G4_LDS4];
     f32x4 *ldsV = lds4, *ldsZ = lds4 + 2 * G4_V, *ldsPin = ldsZ + 4 * G4_V, *ldsPdy = ldsPin + 2 * G4_PIN, *ldsAff = ldsPdy + 2 * G4_PDY;
 
@@ -283,6 +294,7 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
     int cs_b = cur.b;
     if (cs_role)
         for (int bb = 0; bb < cs_b; ++bb) cs_store(bb, 0.f, 0.f);
+    if (PROBE) tprev = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
         if (cs_role && cur.b != cs_b) {                             // the walk reached another image: its predecessor's sums are final
             cs_store(cs_b, cs_acc0, cs_acc1);
@@ -294,17 +306,21 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
         load_dy(cur, 1);                                            // requested BEFORE the input staging: its GroupNorm + SiLU pass covers the latency
         store_in(cur);
         __syncthreads();
+        mark(0);
         transform_v_s();
         transform_z_s(0, cur);
         __syncthreads();
+        mark(1);
         store_dy();
         const Geo nxt = advance(cur);                               // prefetch of the next patch
         __syncthreads();
+        mark(2);
         transform_z_s(1, cur);
         load_in(nxt);                                               // requested behind the last transform (no request registers live across
         load_dy(nxt, 0);                                            // it); the MFMA phase covers the latency: -2.3 % against requesting before it
         cur = nxt;
         __syncthreads();
+        mark(3);
         // (round 6, measured and dropped: the twelve operand reads of position p + 1 issued before the sixteen MFMAs of position p --
         // 164 VGPRs, no spill -- 10.10-10.12 against 10.00 ms of weight-gradient ops per step; the compiler's own order stays)
 #pragma unroll
@@ -324,7 +340,14 @@ __global__ __launch_bounds__(G4_NT, 1) void wgrad43_kernel(const anoddpm_wgrad_a
                     for (int j = 0; j < 4; ++j) acc[p][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[i], zb[j], acc[p][i][j], 0, 0, 0);
             }
         }
+        mark(4);
         // no barrier here: the next iteration only writes the staging buffers before its first barrier
+    }
+    if (PROBE && tid == 0) {
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(a.ws + (int64_t)PG * 9 * K * N) + ((int64_t)blockIdx.y * PG + pg) * 8;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) d[k] = ph[k];
+        d[5] = (unsigned long long)iters;
     }
 
     if (cs_role) {
@@ -545,7 +568,13 @@ int launch_wgrad43(const anoddpm_wgrad_args *a, hipStream_t s)
     const int64_t slab = (int64_t)9 * K * a->N;                      // the kernel stores dg = G^T dU G of its patches: 9 planes per (k, n)
     ANODDPM_REQUIRE(a->ws_floats >= (int64_t)pg * slab, "wgrad (Winograd): workspace too small");
     const dim3 grid((unsigned)pg, (unsigned)((K / G4_KB) * (a->N / G4_NB)));
-    hipLaunchKernelGGL(wgrad43_kernel, grid, dim3(G4_NT), 0, s, *a, pg, a->W / 16, a->H / 8, 1.0f / (float)(a->W / 16));
+#ifdef ANODDPM_ABLATE
+    if (g_debug[12] == 1) {                                          // phase probe: the caller sized ws with 8 x 8 bytes per workgroup behind the slabs
+        ANODDPM_REQUIRE(a->ws_floats >= (int64_t)pg * slab + (int64_t)grid.x * grid.y * 16, "wgrad (Winograd): probe needs 16 floats per workgroup behind the slabs");
+        hipLaunchKernelGGL(wgrad43_kernel<true>, grid, dim3(G4_NT), 0, s, *a, pg, a->W / 16, a->H / 8, 1.0f / (float)(a->W / 16));
+    } else
+#endif
+    hipLaunchKernelGGL(wgrad43_kernel<false>, grid, dim3(G4_NT), 0, s, *a, pg, a->W / 16, a->H / 8, 1.0f / (float)(a->W / 16));
     if (g_debug[8] != 1) {                                           // ANODDPM_DEBUG8=1: the two-launch fold
         hipLaunchKernelGGL(wgrad43_fold_kernel, dim3((unsigned)((int64_t)(K / 2) * (a->N / 64) + (a->dimg ? a->N / 32 : 0))), dim3(288), 0, s, *a, pg, 0);
         return check_launch("conv3x3_wgrad (Winograd)");
