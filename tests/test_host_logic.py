@@ -288,6 +288,12 @@ def test_host_side_shape_helpers_of_the_library():
     assert L.anoddpm_wgrad43_colsum_items(128, 128, 4, 256, 256) == 64 and L.anoddpm_wgrad43_colsum_items(512, 512, 4, 32, 32) == 4   # 2 rows per set
     assert L.anoddpm_wgrad43_groups(128, 128, 4, 256, 256) == 32 and L.anoddpm_wgrad43_groups(512, 512, 4, 32, 32) == 2
     assert L.anoddpm_wgrad43_groups(32, 64, 1, 16, 16) == 2                                       # fewer patches than groups
+    # which cfg-3 launches run on the channel-sliced 128-channel kernel (the one whose epilogue can carry the GroupNorm-backward
+    # reduction, anoddpm_igemm_args.gnb_*): grids that fill the chip with 128-channel workgroups; 64-channel workgroups otherwise
+    assert L.anoddpm_f43_channel_sliced(256, 256, 128, 4) == 1 and L.anoddpm_f43_channel_sliced(128, 128, 128, 4) == 1
+    assert L.anoddpm_f43_channel_sliced(128, 128, 256, 4) == 1 and L.anoddpm_f43_channel_sliced(64, 64, 256, 4) == 0      # 128 workgroups: halves
+    assert L.anoddpm_f43_channel_sliced(64, 64, 256, 5) == 1 and L.anoddpm_f43_channel_sliced(64, 64, 192, 8) == 0        # N % 128
+    assert L.anoddpm_f43_channel_sliced(60, 64, 128, 4) == 0 and L.anoddpm_f43_channel_sliced(0, 64, 128, 4) == 0
 
 
 def test_reverse_chain_reuse_keys():
