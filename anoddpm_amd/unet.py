@@ -484,6 +484,16 @@ def choose_conv_cfg(H, W, K, N, Z, *, ks=3, a_mode=0, b_mode=0, heads=1, c0=None
         wg128 = (H // 16) * (W // 16) * (N // 128) * Z if N % 128 == 0 else 0
         if 100 <= wg128 < 200 and K // 16 >= 8 and os.environ.get("ANODDPM_F43_SPLITK", "0") == "1":
             return 3, 2
+        if 0 < wg128 <= 64 and os.environ.get("ANODDPM_F43_DEEP_SPLITK", "1") == "1":
+            # a quarter of the chip or less in 128-channel workgroups and a deep K (batch 1: the 64x64 512 -> 512 layers of config 5,
+            # 64 workgroups of 32 chunks): K slices of >= 4 chunks on the channel-sliced kernel + the split-K tail, as on the deep
+            # 32x32 layers above, when that fills the chip (round 6, alternating runs: config-5 step 9.61 / 9.59 -> 9.51 / 9.49 ms;
+            # configs at batch >= 4 have no such grid).  ANODDPM_F43_DEEP_SPLITK=0 restores the 64-channel workgroups there
+            ks43 = int(min(max(1, (K // 16) // 4), -(-256 // wg128)))
+            cps = -(-(K // 16) // ks43)
+            ks43 = -(-(K // 16) // cps)
+            if ks43 > 1 and wg128 * ks43 >= 200:
+                return 3, ks43
         return 3, 1
     if wino_ok:
         return 2, wino_ksplit
