@@ -630,6 +630,7 @@ extern "C" int anoddpm_igemm(const anoddpm_igemm_args *a, void *stream)
     ANODDPM_REQUIRE(a->cfg >= 0 && a->cfg <= 7, "igemm: cfg must be 0 (128x128), 1 (64x64), 2 (Winograd F(2x2,3x3)), 3 (Winograd F(4x4,3x3)), 4 (streaming 1x1), 5 (small maps, no split-K), 6 (F(2x2,3x3) on 16x16 / 32x32 maps, no split-K) or 7 (F(4x4,3x3) with split-bf16 products)");
     ANODDPM_REQUIRE(a->cfg == 5 || a->cfg == 6 || a->cfg == 3 || !a->fold_gamma, "igemm: the GroupNorm fold of the operand (fold_*) is a cfg 3 / 5 / 6 feature");
     ANODDPM_REQUIRE(a->cfg == 3 || !a->stats_csum, "igemm: stats_csum (atomically accumulated fp64 sums) is a cfg 3 feature");
+    ANODDPM_REQUIRE(a->cfg == 3 || !a->gnb_partial, "igemm: gnb_partial (GroupNorm-backward sums from the data-gradient epilogue) is a cfg 3 feature");
     ANODDPM_REQUIRE(a->res_mode == 0 || (a->res_mode == 1 && a->cfg == 3 && a->res && a->H % 2 == 0 && a->W % 2 == 0),
                     "igemm: res_mode 1 (half-resolution residual, nearest x2 on the read) is a cfg 3 feature");
     const int BM = a->cfg == 0 ? 128 : 64, BN = BM;
