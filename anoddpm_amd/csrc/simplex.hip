@@ -31,15 +31,15 @@ __constant__ signed char kGrad3[72] = {
 };
 
 // LDS tables.  Everything the hash chain touches is stored as BYTE OFFSETS so that an LDS address is one integer add:
-//   PG[m] = {8 * perm[m & 255], 48 * (perm-gradient index of m & 255)}   m < 512: a hash value plus a masked lattice coordinate
-//           never wraps.  One 8-byte entry serves both tables: ds_read_b64 is serviced over 64 banks (the 2- and 4-byte reads over
+//   PG[m] = {8 * perm[m & 255], 48 * (perm-gradient index of m & 255)}   m = -1 .. 514: a hash value plus a masked lattice coordinate
+//           plus a lattice offset of -1 .. 2 never wraps.  One 8-byte entry serves both tables: ds_read_b64 is serviced over 64 banks (the 2- and 4-byte reads over
 //           32), which cuts the bank conflicts of these random lookups -- the kernel is LDS-conflict bound as much as VALU bound.
 //   grad[g] = {gx, gy, gz} as doubles (components +-4 / +-11 of GRADIENTS3, simplex.py:116-127) in 48-byte rows: only rows g and
 //           g + 16 share banks (32-byte rows: g, g + 8, g + 16)
 // plus the two generated tables of simplex_tables.h: which two extra vertices the region's comparison bits select, and each vertex's
 // displacement recipe / hash offsets.
 struct Tables {
-    uint2 PG[512];
+    uint2 PG[516];                   // entry m (m = -1 .. 514) at PG[m + 1]: the extra vertices' offsets -1 .. 2 need no wrap-around mask
     double grad[24][6];
     unsigned short lut[384];
     double vtx[128][10];             // {ax, ay, az, sq, cx, cy, cz, (i8 | j8 << 32), (k8), -}
@@ -47,8 +47,10 @@ struct Tables {
 
 __device__ __forceinline__ void load_tables(Tables &T, const int16_t *src)
 {
-    for (int i = threadIdx.x; i < 512; i += blockDim.x)
-        T.PG[i] = make_uint2(8u * (unsigned)(src[i & 255] & 0xFF), 48u * (unsigned)(src[256 + (i & 255)] / 3));
+    for (int i = threadIdx.x; i < 516; i += blockDim.x) {
+        const int m = (i - 1) & 255;
+        T.PG[i] = make_uint2(8u * (unsigned)(src[m] & 0xFF), 48u * (unsigned)(src[256 + m] / 3));
+    }
     for (int i = threadIdx.x; i < 72; i += blockDim.x) T.grad[i / 3][i % 3] = (double)kGrad3[i];
     for (int i = threadIdx.x; i < 384; i += blockDim.x) T.lut[i] = kRegionLut[i];
     for (int i = threadIdx.x; i < 128 * 9; i += blockDim.x) {
@@ -81,7 +83,7 @@ __device__ __forceinline__ unsigned lds_u16(const void *base, unsigned byte_off)
 }
 __device__ __forceinline__ uint2 lds_pg(const Tables &T, unsigned byte_off)
 {
-    return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(T.PG) + byte_off);
+    return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(T.PG) + 8 + byte_off);    // (+ 8: entry -1 sits at PG[0])
 }
 
 // attn^4 * (g . d) of one vertex whose displacement and gradient byte offset are known (simplex.py:202-208 + the kernel term)
@@ -160,7 +162,7 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
     const double SQ[4] = {0.0, 1.0 * SQUISH3, 2.0 * SQUISH3, 3.0 * SQUISH3};
     const unsigned xb2 = ((unsigned)xsb & 0xFFu) * 8u, yb2 = ((unsigned)ysb & 0xFFu) * 8u, zb2 = ((unsigned)zsb & 0xFFu) * 8u;
     // Round 4: the hash rows of a lattice-corner PAIR are neighbours in the table -- coordinate c and c + 1 of the same chain
-    // level are entries m and m + 1, and m + 1 <= 511 never wraps (PG holds 512 entries: 255 (hash) + 256 (coordinate + 1)) -- so
+    // level are entries m and m + 1, and m + 1 never wraps (PG holds entries -1 .. 514: 255 (hash) + 256 (coordinate + 1) and the extra vertices' offsets) -- so
     // every pair is ONE ds_read2_b64 instead of two masked reads: 1 + 2 + 4 pair reads for the cube's 2 + 4 + 8 entries.
     unsigned h0[2], h1[2][2], gz[2][2][2];
     h0[0] = lds_pg(T, xb2).x;
@@ -180,7 +182,11 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
             gz[i][j][1] = lds_pg(T, base + 8u).y;
         }
     // shared slot: corner 0 (region A) or corner 7 (otherwise)
-    const double sx = regA ? X[0] : X[1] - SQ[3], sy = regA ? Y[0] : Y[1] - SQ[3], sz = regA ? Z[0] : Z[1] - SQ[3];
+    // corner 0: d0; corner 7: (d0 - 1) - 3 SQUISH, and 3 SQUISH rounds to exactly 1.0 -- so both are (d0 - w) - w with w = 0.0 or 1.0 (subtracting
+    // +0.0 is exact and keeps the sign of a zero): one select of w's high word instead of six on the components
+    static_assert(3.0 * SQUISH3 == 1.0, "corner 7's squish term is exactly 1.0");
+    const double w07 = __hiloint2double(regA ? 0 : 0x3FF00000, 0);
+    const double sx = (dx0 - w07) - w07, sy = (dy0 - w07) - w07, sz = (dz0 - w07) - w07;
     const double slot = kernel_term(T, two07, sx, sy, sz, regA ? gz[0][0][0] : gz[1][1][1]);
     double value = regA ? 0.0 + slot : 0.0;                         // tetra0: corner 0 is the first term (0.0 + t: a -0.0 term gives +0.0)
     constexpr int ORDER[6] = {1, 2, 4, 3, 5, 6};
@@ -206,9 +212,11 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
             const double dx = ((dx0 - a01.x) - a23.y) - c01.x;
             const double dy = ((dy0 - a01.y) - a23.y) - c01.y;
             const double dz = ((dz0 - a23.x) - a23.y) - cz;
-            const unsigned e0h = lds_pg(T, (xb2 + (unsigned)ij.x) & 0x7F8u).x;
-            const unsigned e1h = lds_pg(T, e0h + ((yb2 + (unsigned)ij.y) & 0x7F8u)).x;
-            const unsigned goff = lds_pg(T, e1h + ((zb2 + (unsigned)k2) & 0x7F8u)).y;
+            // masked coordinate (0 .. 255) + lattice offset (-1 .. 2) [+ hash value (0 .. 255)]: entries -1 .. 512 of the extended table,
+            // whose entry m holds the permutation row of m & 255 -- the sums need no wrap-around mask (round 6: six v_and less)
+            const unsigned e0h = lds_pg(T, xb2 + (unsigned)ij.x).x;
+            const unsigned e1h = lds_pg(T, e0h + yb2 + (unsigned)ij.y).x;
+            const unsigned goff = lds_pg(T, e1h + zb2 + (unsigned)k2).y;
             value += kernel_term(T, 2.0, dx, dy, dz, goff);
         }
     }
