@@ -30,29 +30,52 @@ __constant__ signed char kGrad3[72] = {
     -11,-4,-4,  -4,-11,-4,  -4,-4,-11,   11,-4,-4,   4,-11,-4,   4,-4,-11,
 };
 
-// LDS tables.  Everything the hash chain touches is stored as BYTE OFFSETS so that an LDS address is one integer add:
-//   PG[m] = {8 * perm[m & 255], 48 * (perm-gradient index of m & 255)}   m = -1 .. 514: a hash value plus a masked lattice coordinate
-//           plus a lattice offset of -1 .. 2 never wraps.  One 8-byte entry serves both tables: ds_read_b64 is serviced over 64 banks (the 2- and 4-byte reads over
-//           32), which cuts the bank conflicts of these random lookups -- the kernel is LDS-conflict bound as much as VALU bound.
-//   grad[g] = {gx, gy, gz} as doubles (components +-4 / +-11 of GRADIENTS3, simplex.py:116-127) in 48-byte rows: only rows g and
-//           g + 16 share banks (32-byte rows: g, g + 8, g + 16)
-// plus the two generated tables of simplex_tables.h: which two extra vertices the region's comparison bits select, and each vertex's
-// displacement recipe / hash offsets.
+// LDS tables.  Everything the hash chain touches is stored as BYTE ADDRESSES inside this struct (the kernel's only LDS object, at LDS
+// address 0) so that an LDS address is one integer add and every table is reached through an instruction's immediate offset.
+// The kernel is LDS-bound as much as VALU-bound (round 6 counters: SQ_LDS_IDX_ACTIVE 92 % of the launch, 45 % of it conflict cycles), so the
+// tables are shaped for the LDS-array cycles of each read (guide: ds_read_b64 2 cycles over 64 banks, ds_read_b128 4, ds_read2_b32 4 over
+// 32 banks, ds_read2_b64 8):
+//   grad[g] = {gx, gy, gz} as doubles (components +-4 / +-11 of GRADIENTS3, simplex.py:116-127) in 48-byte rows at offset 0: a gradient
+//           byte offset 48 g IS its address; rows are 16-byte aligned: one ds_read_b128 (gx, gy) + one ds_read_b64 (gz) = 6 cycles
+//           (the former ds_read2_b64 + ds_read_b64: 10)
+//   H[m]  = {h(m), h(m + 1)},  h(m) = H_ENTRY0 + 8 * perm[m & 255]          m = -1 .. 514: a hash value plus a masked lattice coordinate
+//   G[m]  = {48 * pgi(m), 48 * pgi(m + 1)},  pgi = perm-gradient index      plus a lattice offset of -1 .. 2 never wraps.
+//           The rows of a lattice-corner PAIR (coordinate c and c + 1 of one chain level) are entries m and m + 1: each table holds
+//           the pair in ONE 8-byte entry, so a pair is one ds_read_b64 (2 cycles, 64 banks) instead of a ds_read2_b32 (4 cycles, 32
+//           banks).  Entry 0 of H sits at byte H_ENTRY0 = 2048 and entry 0 of G at H_ENTRY0 + G_DELTA, both multiples of 2048: the x
+//           coordinate's masked offset takes H's base and the z coordinate's takes G_DELTA with the same bit-field insert that masks
+//           them, and every hash VALUE carries H's base -- the chain's next address is hash + masked coordinate.
+//   lut[idx] = byte addresses of the two extra vertices' rows (lo / hi half) for the region index the comparison bits form
+//   vtx[id] = displacement recipe / hash offsets of a vertex: {ax, ay, az, sq, cx, cy, cz, (i8 | j8 << 32), (k8), -}
+// (lut / vtx: from the generated tables of simplex_tables.h.)
+constexpr unsigned H_ENTRY0 = 2048, G_DELTA = 6144;
 struct Tables {
-    uint2 PG[516];                   // entry m (m = -1 .. 514) at PG[m + 1]: the extra vertices' offsets -1 .. 2 need no wrap-around mask
-    double grad[24][6];
-    unsigned short lut[384];
-    double vtx[128][10];             // {ax, ay, az, sq, cx, cy, cz, (i8 | j8 << 32), (k8), -}
+    double grad[24][6];              // 1152 B at offset 0
+    unsigned char pad0[H_ENTRY0 - 8 - 24 * 48];
+    uint2 H[516];                    // entry m (m = -1 .. 514) at H[m + 1]: the extra vertices' offsets -1 .. 2 need no wrap-around mask
+    unsigned lut[REGION_LUT_SIZE];
+    unsigned char pad1[G_DELTA - 516 * 8 - REGION_LUT_SIZE * 4];
+    uint2 G[516];
+    alignas(16) double vtx[128][10];   // rows are read with ds_read_b128: 16-byte aligned (an 8-byte-aligned base halves the kernel's speed)
 };
+static_assert(offsetof(Tables, vtx) % 16 == 0, "vertex rows 16-byte aligned");
+static_assert(offsetof(Tables, H) == H_ENTRY0 - 8, "H entry 0 at byte 2048");
+static_assert(offsetof(Tables, G) == H_ENTRY0 - 8 + G_DELTA, "G entry 0 at byte 2048 + 6144");
+static_assert((H_ENTRY0 & 0x7F8u) == 0 && (G_DELTA & 0x7F8u) == 0, "bases outside the coordinate mask");
+static_assert(offsetof(Tables, vtx) + 128 * 80 < 65536, "vertex row addresses fit 16 bits");
 
 __device__ __forceinline__ void load_tables(Tables &T, const int16_t *src)
 {
     for (int i = threadIdx.x; i < 516; i += blockDim.x) {
-        const int m = (i - 1) & 255;
-        T.PG[i] = make_uint2(8u * (unsigned)(src[m] & 0xFF), 48u * (unsigned)(src[256 + m] / 3));
+        const int m = (i - 1) & 255, m1 = i & 255;
+        T.H[i] = make_uint2(H_ENTRY0 + 8u * (unsigned)(src[m] & 0xFF), H_ENTRY0 + 8u * (unsigned)(src[m1] & 0xFF));
+        T.G[i] = make_uint2(48u * (unsigned)(src[256 + m] / 3), 48u * (unsigned)(src[256 + m1] / 3));
     }
     for (int i = threadIdx.x; i < 72; i += blockDim.x) T.grad[i / 3][i % 3] = (double)kGrad3[i];
-    for (int i = threadIdx.x; i < 384; i += blockDim.x) T.lut[i] = kRegionLut[i];
+    for (int i = threadIdx.x; i < REGION_LUT_SIZE; i += blockDim.x) {
+        const unsigned v = kRegionLut[i], vb = (unsigned)offsetof(Tables, vtx);
+        T.lut[i] = (vb + 80u * (v & 0x7Fu)) | ((vb + 80u * (v >> 8)) << 16);
+    }
     for (int i = threadIdx.x; i < 128 * 9; i += blockDim.x) {
         const int e = i / 9, w = i - e * 9;                          // 72-byte source entries -> 80-byte LDS rows
         unsigned long long v = reinterpret_cast<const unsigned long long *>(&kVertex[e])[w];
@@ -66,31 +89,35 @@ __device__ __forceinline__ void load_tables(Tables &T, const int16_t *src)
 }
 
 // x / 103 with IEEE rounding from the correctly rounded reciprocal and two FMAs (Markstein): q = x*r, q' = q + (x - 103 q) r.
-// Exact for every normal-range quotient (checked against hardware division on 4e8 samples, incl. random bit patterns); values
-// near the under / overflow thresholds take the plain division.
+// Exact for every normal-range quotient (checked against hardware division on 4e8 samples, incl. random bit patterns) and for
+// +-0 (q = q' = the zero).  A noise value is 0 or a sum of terms attn^4 (g . d) with attn >= 2^-52 and |sum| < 1e4, far inside
+// the range where the residual x - 103 q is exact; NaN / inf / subnormal inputs (coordinates beyond the double range) take the
+// plain division -- one v_cmp_class_f64 instead of two range comparisons.
 __device__ __forceinline__ double div_norm3(double v)
 {
-    const double av = fabs(v);
-    if (!(av > 1e-280 && av < 1e280)) return v / NORM3;
+    // classes: signaling / quiet NaN (0, 1), -inf (2), -subnormal (4), +subnormal (7), +inf (9)
+    if (__builtin_amdgcn_class(v, 0x1 | 0x2 | 0x4 | 0x10 | 0x80 | 0x200)) return v / NORM3;
     const double r = 1.0 / NORM3;
     const double q = v * r;
     return fma(fma(-NORM3, q, v), r, q);
 }
 
-__device__ __forceinline__ unsigned lds_u16(const void *base, unsigned byte_off)
+// LDS accesses by byte address inside the Tables struct (LDS address 0: the compiler folds `&T`)
+__device__ __forceinline__ uint2 lds_pair(const Tables &T, unsigned addr)      // {entry m, entry m + 1} of H or G: one ds_read_b64
 {
-    return *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(base) + byte_off);
+    return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(&T) + addr);
 }
-__device__ __forceinline__ uint2 lds_pg(const Tables &T, unsigned byte_off)
+__device__ __forceinline__ unsigned lds_one(const Tables &T, unsigned addr)      // entry m alone (the extra vertices)
 {
-    return *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(T.PG) + 8 + byte_off);    // (+ 8: entry -1 sits at PG[0])
+    return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(&T) + addr);
 }
 
 // attn^4 * (g . d) of one vertex whose displacement and gradient byte offset are known (simplex.py:202-208 + the kernel term)
 __device__ __forceinline__ double kernel_term(const Tables &T, double two, double dx, double dy, double dz, unsigned goff)
 {
-    const double *g = reinterpret_cast<const double *>(reinterpret_cast<const char *>(T.grad) + goff);
-    const double gx = g[0], gy = g[1], gz = g[2];
+    const char *g = reinterpret_cast<const char *>(&T) + goff;     // grad rows start at address 0; 48-byte rows: 16-byte aligned
+    const double2 gxy = *reinterpret_cast<const double2 *>(g);
+    const double gx = gxy.x, gy = gxy.y, gz = *reinterpret_cast<const double *>(g + 16);
     double attn = two - dx * dx - dy * dy - dz * dz;                 // `two` = 2.0, or -inf for a corner outside the region's list
     attn = fmax(attn, 0.0);                                         // out of radius / unlisted: +0.0, the term is a signed zero
     attn *= attn;
@@ -105,13 +132,26 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
     const double stretch = (x + y + z) * STRETCH3;
     const double xs = x + stretch, ys = y + stretch, zs = z + stretch;
     const double fx = floor(xs), fy = floor(ys), fz = floor(zs);
-    // lattice base: only (xsb + i) & 0xFF reaches the hash, and (double)(xsb + ysb + zsb) == fx + fy + fz exactly while the
-    // floors stay below 2^50; beyond 2^31 (never in practice) the low bits come from the 64-bit conversion
-    int xsb, ysb, zsb;
-    if (SAFE || (fabs(fx) < 2147483000.0 && fabs(fy) < 2147483000.0 && fabs(fz) < 2147483000.0)) {
-        xsb = (int)fx; ysb = (int)fy; zsb = (int)fz;
+    // lattice base: only (xsb + i) & 0xFF reaches the hash, as the byte offset 8 * ((xsb + i) & 0xFF) of a table entry.  SAFE (floors below
+    // 2^31): floor + 1.5 * 2^49 has an ulp of 1/8, so the low word of the sum IS 8 * xsb in two's complement -- one exact fp64 add
+    // replaces convert + shift (round 6).  Beyond 2^31 (never in practice) the low bits come from the 64-bit conversion.  The
+    // x offset takes H's base address and the z offset the distance from H to G with the mask (v_bfi_b32); the y offset is added to hash values that carry H's base.
+    unsigned xb2, yb2, zb2;
+    if (SAFE) {
+        constexpr double MAGIC = 844424930131968.0;                // 1.5 * 2^49
+        // (lo & 0x7F8) | 0x800 as ONE bit-field insert (hipcc turns the plain expression into v_and + v_add)
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(xb2) : "s"(0x7F8u), "v"(__double2loint(fx + MAGIC)), "v"(H_ENTRY0));
+        // (as asm: hipcc's SLP pass packs the two 16-bit masks into one register -- v_perm + two ands + a shift for two ands)
+        asm("v_and_b32 %0, %1, %2" : "=v"(yb2) : "s"(0x7F8u), "v"(__double2loint(fy + MAGIC)));
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(zb2) : "s"(0x7F8u), "v"(__double2loint(fz + MAGIC)), "v"(G_DELTA));
     } else {
-        xsb = (int)((long long)fx & 0xFF); ysb = (int)((long long)fy & 0xFF); zsb = (int)((long long)fz & 0xFF);
+        int xsb, ysb, zsb;
+        if (fabs(fx) < 2147483000.0 && fabs(fy) < 2147483000.0 && fabs(fz) < 2147483000.0) {
+            xsb = (int)fx; ysb = (int)fy; zsb = (int)fz;
+        } else {
+            xsb = (int)((long long)fx & 0xFF); ysb = (int)((long long)fy & 0xFF); zsb = (int)((long long)fz & 0xFF);
+        }
+        xb2 = (((unsigned)xsb & 0xFFu) * 8u) | H_ENTRY0; yb2 = ((unsigned)ysb & 0xFFu) * 8u; zb2 = (((unsigned)zsb & 0xFFu) * 8u) | G_DELTA;
     }
     const double squish = ((fx + fy) + fz) * SQUISH3;
     const double xb = fx + squish, yb = fy + squish, zb = fz + squish;
@@ -120,31 +160,46 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
     const double dx0 = x - xb, dy0 = y - yb, dz0 = z - zb;
 
     // ---- region decisions of simplex.py:354-798, branch-free.  The reference's if / elif chains depend on nineteen comparisons of the
-    // inside coordinates only; their results are gathered into a 7-bit index per candidate region and ONE table lookup (kRegionLut,
-    // generated from the chains themselves by tools/gen_simplex_tables.py) yields the two extra vertices -- no score is materialised,
-    // no decision code is built from selects (round 6: 106 -> 65 VALU instructions for this block).
+    // inside coordinates only; their results are gathered into a region index and ONE table lookup (kRegionLut, generated from the
+    // chains themselves by tools/gen_simplex_tables.py) yields the two extra vertices -- no score is materialised, no decision code is
+    // built from selects.  Round 6, second form: a comparison a < b IS the sign bit of the fp64 difference a - b (the difference of two
+    // distinct doubles is never zero, a - a is +0.0), and one v_alignbit_b32 shifts that bit into the index -- two instructions per
+    // comparison instead of compare + select + or through an SGPR pair (106 -> 65 -> 40 VALU instructions for this block).
+    //   * The tetrahedron at (1,1,1) asks the MIRRORED questions of the tetrahedron at (0,0,0) (x <= y for x >= y, w < x for w > x, ...):
+    //     with every operand negated -- an exact sign flip -- they are the same seven differences, so both share one chain; its seed is the region bit.
+    //   * Octahedron: the scores |p - 1| come from r = 1 - p (the exact negative of p - 1; p > 1 is r's sign); "<=" is the complement of
+    //     ">" on the same pair and needs no bit of its own.
     const bool regA = in_sum <= 1, regB = in_sum >= 2;
     unsigned idx;
     if (ABL == 2) {
-        idx = 256 + (1 | 2 | 4);
+        idx = 256;
     } else {
-        const bool x_ge_y = xins >= yins, x_le_y = xins <= yins, z_gt_y = zins > yins, z_lt_y = zins < yins, z_gt_x = zins > xins, z_lt_x = zins < xins;
-        // tetrahedron at (0,0,0): w = 1 - in_sum against x, y, z
-        const double winsA = 1 - in_sum;
-        const unsigned iA = (x_ge_y ? 1u : 0u) | (z_gt_y ? 2u : 0u) | (z_gt_x ? 4u : 0u) | (z_lt_y ? 8u : 0u) |
-                            (winsA > xins ? 16u : 0u) | (winsA > yins ? 32u : 0u) | (winsA > zins ? 64u : 0u);
-        // tetrahedron at (1,1,1): w = 3 - in_sum
-        const double winsB = 3 - in_sum;
-        const unsigned iB = 128u + ((x_le_y ? 1u : 0u) | (z_lt_y ? 2u : 0u) | (z_lt_x ? 4u : 0u) | (z_gt_y ? 8u : 0u) |
-                                    (winsB < xins ? 16u : 0u) | (winsB < yins ? 32u : 0u) | (winsB < zins ? 64u : 0u));
-        // octahedron: score = p - 1 or 1 - p, whichever is positive -- the two differences are exact negatives of each other
-        const double p1 = xins + yins, p2 = xins + zins, p3 = yins + zins;
-        const double asC = fabs(p1 - 1), bsC = fabs(p2 - 1), scC = fabs(p3 - 1);
-        const unsigned iC = 256u + ((p1 > 1 ? 1u : 0u) | (p2 > 1 ? 2u : 0u) | (p3 > 1 ? 4u : 0u) | (asC <= bsC ? 8u : 0u) | (asC < scC ? 16u : 0u) |
-                                    (asC > bsC ? 32u : 0u) | (bsC < scC ? 64u : 0u));
-        idx = regA ? iA : (regB ? iB : iC);
+        auto push = [](unsigned acc, double d) { return __builtin_amdgcn_alignbit(acc, (unsigned)__double2hiint(d), 31u); };
+        // mirror = times -1.0 (exact; one v_mul_f64 -- a sign flip through the high word costs an extra move per 64-bit operand)
+        const double sgn = __hiloint2double(regB ? (int)0xBFF00000 : 0x3FF00000, 0);
+        const double xm = xins * sgn, ym = yins * sgn, zm = zins * sgn;
+        // w = 1 - in_sum (tetrahedron at the origin) / the negative of w = 3 - in_sum.  in_sum * sgn is exact, so the explicit fma
+        // rounds once, exactly like the subtraction it stands for: -3 + in_sum == -(3 - in_sum)
+        const double wm = fma(in_sum, -sgn, __hiloint2double(regB ? (int)0xC0080000 : 0x3FF00000, 0));
+        unsigned iT = regB ? 1u : 0u;
+        iT = push(iT, xm - ym);                                     // x < y   (origin: the complement of x >= y; far corner: of x <= y)
+        iT = push(iT, ym - zm);                                     // z > y   (far corner: z < y)
+        iT = push(iT, xm - zm);                                     // z > x   (z < x)
+        iT = push(iT, zm - ym);                                     // z < y   (z > y)
+        iT = push(iT, xm - wm);                                     // w > x   (w < x)
+        iT = push(iT, ym - wm);                                     // w > y   (w < y)
+        iT = push(iT, zm - wm);                                     // w > z   (w < z)
+        const double r1 = 1 - (xins + yins), r2 = 1 - (xins + zins), r3 = 1 - (yins + zins);
+        unsigned iO = 4u;                                           // 4 << 6 = 256: the octahedron's entries follow the two tetrahedra's
+        iO = push(iO, r1);                                          // p1 > 1
+        iO = push(iO, r2);                                          // p2 > 1
+        iO = push(iO, r3);                                          // p3 > 1
+        iO = push(iO, fabs(r2) - fabs(r1));                         // |p1 - 1| >  |p2 - 1|   (complement: <=)
+        iO = push(iO, fabs(r1) - fabs(r3));                         // |p1 - 1| <  |p3 - 1|
+        iO = push(iO, fabs(r2) - fabs(r3));                         // |p2 - 1| <  |p3 - 1|
+        idx = (regA || regB) ? iT : iO;
     }
-    const unsigned pair = lds_u16(T.lut, idx * 2);
+    const unsigned pair = T.lut[idx];                               // byte addresses of the two extra vertices' rows
 
     // ---- the unit cube's corners.  Every region's vertex list is a subset of the eight corners taken in the order
     // 0,1,2,4,3,5,6,7 (tetra0: 0 1 2 4; octahedron: 1 2 4 3 5 6; tetra1: 3 5 6 7), so all eight are evaluated with COMPILE-TIME
@@ -160,26 +215,21 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
     const double two07 = __hiloint2double((regA || regB) ? TWO : NINF, 0);       // the shared slot
     const double X[2] = {dx0, dx0 - 1.0}, Y[2] = {dy0, dy0 - 1.0}, Z[2] = {dz0, dz0 - 1.0};
     const double SQ[4] = {0.0, 1.0 * SQUISH3, 2.0 * SQUISH3, 3.0 * SQUISH3};
-    const unsigned xb2 = ((unsigned)xsb & 0xFFu) * 8u, yb2 = ((unsigned)ysb & 0xFFu) * 8u, zb2 = ((unsigned)zsb & 0xFFu) * 8u;
-    // Round 4: the hash rows of a lattice-corner PAIR are neighbours in the table -- coordinate c and c + 1 of the same chain
-    // level are entries m and m + 1, and m + 1 never wraps (PG holds entries -1 .. 514: 255 (hash) + 256 (coordinate + 1) and the extra vertices' offsets) -- so
-    // every pair is ONE ds_read2_b64 instead of two masked reads: 1 + 2 + 4 pair reads for the cube's 2 + 4 + 8 entries.
-    unsigned h0[2], h1[2][2], gz[2][2][2];
-    h0[0] = lds_pg(T, xb2).x;
-    h0[1] = lds_pg(T, xb2 + 8u).x;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const unsigned base = h0[i] + yb2;
-        h1[i][0] = lds_pg(T, base).x;
-        h1[i][1] = lds_pg(T, base + 8u).x;
+    // The hash rows of a lattice-corner PAIR (coordinate c and c + 1 of the same chain level) sit in one 8-byte entry (Tables): 1 + 2 + 4
+    // ds_read_b64 for the cube's 2 + 4 + 8 entries; h(m + 1) never wraps (entries -1 .. 514: 255 (hash) + 256 (coordinate + 1) and the
+    // extra vertices' offsets).
+    unsigned h1[2][2], gz[2][2][2];
+    const uint2 h0 = lds_pair(T, xb2);
+    {
+        const uint2 a = lds_pair(T, h0.x + yb2), b = lds_pair(T, h0.y + yb2);
+        h1[0][0] = a.x; h1[0][1] = a.y; h1[1][0] = b.x; h1[1][1] = b.y;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const unsigned base = h1[i][j] + zb2;
-            gz[i][j][0] = lds_pg(T, base).y;
-            gz[i][j][1] = lds_pg(T, base + 8u).y;
+            const uint2 g = lds_pair(T, h1[i][j] + zb2);            // zb2 carries the distance from H to G
+            gz[i][j][0] = g.x; gz[i][j][1] = g.y;
         }
     // shared slot: corner 0 (region A) or corner 7 (otherwise)
     // corner 0: d0; corner 7: (d0 - 1) - 3 SQUISH, and 3 SQUISH rounds to exactly 1.0 -- so both are (d0 - w) - w with w = 0.0 or 1.0 (subtracting
@@ -188,7 +238,11 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
     const double w07 = __hiloint2double(regA ? 0 : 0x3FF00000, 0);
     const double sx = (dx0 - w07) - w07, sy = (dy0 - w07) - w07, sz = (dz0 - w07) - w07;
     const double slot = kernel_term(T, two07, sx, sy, sz, regA ? gz[0][0][0] : gz[1][1][1]);
-    double value = regA ? 0.0 + slot : 0.0;                         // tetra0: corner 0 is the first term (0.0 + t: a -0.0 term gives +0.0)
+    // tetra0: corner 0 is the first term (0.0 + t: a -0.0 term gives +0.0); otherwise the slot is the last cube term.  Both positions as
+    // ONE explicit fma each with a 1.0 / 0.0 factor: t * 1 and t * 0 = +-0 are exact, so the fma rounds once exactly like the add it
+    // replaces, and adding +-0 to a sum that started at +0.0 changes nothing (round 6: two instead of six instructions)
+    const double mA = __hiloint2double(regA ? 0x3FF00000 : 0, 0), mB = __hiloint2double(regA ? 0 : 0x3FF00000, 0);
+    double value = fma(slot, mA, 0.0);
     constexpr int ORDER[6] = {1, 2, 4, 3, 5, 6};
 #pragma unroll
     for (int s = 0; s < (ABL == 3 ? 3 : 6); ++s) {
@@ -197,26 +251,26 @@ __device__ __forceinline__ double noise3(const Tables &T, double x, double y, do
         const double dx = X[i] - SQ[n], dy = Y[j] - SQ[n], dz = Z[k] - SQ[n];
         value += kernel_term(T, n == 1 ? two1 : two2, dx, dy, dz, gz[i][j][k]);
     }
-    value += regA ? 0.0 : slot;                                     // tetra1: corner 7 is the last cube term; octahedron: +0.0
+    value = fma(slot, mB, value);                                   // tetra1: corner 7 is the last cube term; octahedron: +-0.0
     // ---- the two extra vertices: displacement recipe and hash offsets from the vertex table (simplex_tables.h)
     if (ABL != 1) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const unsigned id = e == 0 ? (pair & 0x7Fu) : (pair >> 8);
-            const char *row = reinterpret_cast<const char *>(T.vtx) + id * 80u;
+            const char *row = reinterpret_cast<const char *>(&T) + (e == 0 ? (pair & 0xFFFFu) : (pair >> 16));
             const double2 a01 = *reinterpret_cast<const double2 *>(row), a23 = *reinterpret_cast<const double2 *>(row + 16);
             const double2 c01 = *reinterpret_cast<const double2 *>(row + 32);
-            const double cz = *reinterpret_cast<const double *>(row + 48);
-            const int2 ij = *reinterpret_cast<const int2 *>(row + 56);
+            const double2 czij = *reinterpret_cast<const double2 *>(row + 48);      // {cz, (i8 | j8 << 32)}: one ds_read_b128
+            const double cz = czij.x;
+            const int2 ij = make_int2(__double2loint(czij.y), __double2hiint(czij.y));
             const int k2 = *reinterpret_cast<const int *>(row + 64);
             const double dx = ((dx0 - a01.x) - a23.y) - c01.x;
             const double dy = ((dy0 - a01.y) - a23.y) - c01.y;
             const double dz = ((dz0 - a23.x) - a23.y) - cz;
             // masked coordinate (0 .. 255) + lattice offset (-1 .. 2) [+ hash value (0 .. 255)]: entries -1 .. 512 of the extended table,
             // whose entry m holds the permutation row of m & 255 -- the sums need no wrap-around mask (round 6: six v_and less)
-            const unsigned e0h = lds_pg(T, xb2 + (unsigned)ij.x).x;
-            const unsigned e1h = lds_pg(T, e0h + yb2 + (unsigned)ij.y).x;
-            const unsigned goff = lds_pg(T, e1h + zb2 + (unsigned)k2).y;
+            const unsigned e0h = lds_one(T, xb2 + (unsigned)ij.x);
+            const unsigned e1h = lds_one(T, e0h + yb2 + (unsigned)ij.y);
+            const unsigned goff = lds_one(T, e1h + zb2 + (unsigned)k2);
             value += kernel_term(T, 2.0, dx, dy, dz, goff);
         }
     }
@@ -228,23 +282,34 @@ template <int ABL, bool SAFE>
 __device__ __forceinline__ double octave_sum(const Tables &T, double xd, double yd, double zd, double f0, bool pow2, int octaves,
                                              double persistence)
 {
-    double acc = 0.0, amp = 1.0, f = f0;
-    double rf = pow2 ? 1.0 / f0 : 0.0;
-    for (int o = 0; o < octaves; ++o) {
-        double cx, cy, cz;
-        if (pow2) { cx = xd * rf; cy = yd * rf; cz = zd * rf; }
-        else      { cx = xd / f; cy = yd / f; cz = zd / f; }
-        const double n = noise3<ABL, SAFE>(T, cx, cy, cz);
-        acc = acc + amp * n;            // noise += amplitude * field, octave 0 first (simplex.py:90)
-        f = f / 2;
-        rf = rf * 2.0;
-        amp = amp * persistence;
+    double acc = 0.0, amp = 1.0;
+    if (pow2) {                                     // x / f == x * (1 / f) bit for bit, and 1 / f doubles exactly per octave
+        double rf = 1.0 / f0;
+        for (int o = 0; o < octaves; ++o) {
+            const double n = noise3<ABL, SAFE>(T, xd * rf, yd * rf, zd * rf);
+            acc = acc + amp * n;        // noise += amplitude * field, octave 0 first (simplex.py:90)
+            rf = rf * 2.0;
+            amp = amp * persistence;
+        }
+    } else {
+        double f = f0;
+        for (int o = 0; o < octaves; ++o) {
+            const double n = noise3<ABL, SAFE>(T, xd / f, yd / f, zd / f);
+            acc = acc + amp * n;
+            f = f / 2;
+            amp = amp * persistence;
+        }
     }
     return acc;
 }
 
+// five waves per SIMD (96 registers): the kernel is VALU-issue bound and five cover its LDS latency; the compiler's own choice drifts
+// to 97-104 registers = four waves.  -DSIMPLEX_WAVES=n for measurement builds.
+#ifndef SIMPLEX_WAVES
+#define SIMPLEX_WAVES 5
+#endif
 template <typename OutT, int ABL = 0>
-__global__ __launch_bounds__(256) void simplex3_octaves_kernel(anoddpm_simplex_args a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIMPLEX_WAVES))) void simplex3_octaves_kernel(anoddpm_simplex_args a)
 {
     __shared__ Tables T;
     const int s = blockIdx.z;

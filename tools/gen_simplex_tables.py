@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Generate anoddpm_amd/csrc/simplex_tables.h: the two lookup tables of the OpenSimplex-3D kernel (csrc/simplex.hip).
 
-  kRegionLut[384]  the two "extra" lattice vertices of an evaluation, u16 = id(e0) | id(e1) << 8, indexed DIRECTLY BY THE COMPARISON
+  kRegionLut[320]  the two "extra" lattice vertices of an evaluation, u16 = id(e0) | id(e1) << 8, indexed DIRECTLY BY THE COMPARISON
                    BITS of _noise3's region decisions (simplex.py:354-798; round 6 -- until then the kernel reduced the comparisons to
-                   a decision code with ~45 selects first):
+                   a decision code with ~45 selects first).  The kernel's index is built from sign bits (layout in main() below); it
+                   is a permutation of the comparison-bit table `region` that main() derives first:
                        tetrahedron at (0,0,0):  [0, 128):   x>=y | z>y << 1 | z>x << 2 | z<y << 3 | w>x << 4 | w>y << 5 | w>z << 6      (w = 1 - in_sum)
                        tetrahedron at (1,1,1):  [128, 256): x<=y | z<y << 1 | z<x << 2 | z>y << 3 | w<x << 4 | w<y << 5 | w<z << 6      (w = 3 - in_sum)
                        octahedron:              [256, 384): p1>1 | p2>1 << 1 | p3>1 << 2 | |p1-1|<=|p2-1| << 3 | |p1-1|<|p3-1| << 4 |
@@ -152,13 +153,29 @@ def main():
         af = f3 if t1 else f1
         bf = f3 if t2 else f2
         region[256 + m] = lut[128 + (ap | bp << 3 | (64 if af else 0) | (128 if bf else 0))]
-    lut = region
+    # Round 6, second form: the kernel shifts the SIGN BITS of fp64 differences into the index (first pushed = highest bit):
+    #   tetrahedra [0, 256): regB << 7 | (x<y) << 6 | (z>y) << 5 | (z>x) << 4 | (z<y) << 3 | (w>x) << 2 | (w>y) << 1 | (w>z)
+    #                        -- for the tetrahedron at (1,1,1) on NEGATED operands, i.e. (y<x), (z<y), (z<x), (z>y), (w<x), (w<y), (w<z)
+    #   octahedron [256, 320): (p1>1) << 5 | (p2>1) << 4 | (p3>1) << 3 | (|p1-1|>|p2-1|) << 2 | (|p1-1|<|p3-1|) << 1 | (|p2-1|<|p3-1|)
+    # mapped onto the comparison-bit table above (`region`, the kernel's former index).
+    lut = [0] * 320
+    for n in range(256):
+        reg_b = n >> 7
+        lt_xy, z_gt_y, z_gt_x, z_lt_y, wx, wy, wz = [(n >> k) & 1 for k in (6, 5, 4, 3, 2, 1, 0)]
+        # x >= y is the complement of x < y (far corner, on negated operands: x <= y the complement of y < x)
+        m = (1 - lt_xy) | z_gt_y << 1 | z_gt_x << 2 | z_lt_y << 3 | wx << 4 | wy << 5 | wz << 6
+        lut[n] = region[128 * reg_b + m]
+    for n in range(64):
+        f1, f2, f3, gt_ab, lt_ac, lt_bc = [(n >> k) & 1 for k in (5, 4, 3, 2, 1, 0)]
+        m = f1 | f2 << 1 | f3 << 2 | (1 - gt_ab) << 3 | lt_ac << 4 | gt_ab << 5 | lt_bc << 6
+        lut[256 + n] = region[256 + m]
     out = ["// GENERATED by tools/gen_simplex_tables.py -- do not edit.  Lookup tables of csrc/simplex.hip (see the generator's docstring).",
            "#pragma once", "#include <stdint.h>", "",
            "struct SimplexVertex {", "    double ax, ay, az, sq, cx, cy, cz;", "    int32_t i2, j2, k2, pad;", "};",
            "static_assert(sizeof(SimplexVertex) == 72, \"SimplexVertex layout\");", "",
-           "__device__ const uint16_t kRegionLut[384] = {"]
-    for r in range(0, 384, 16):
+           f"constexpr int REGION_LUT_SIZE = {len(lut)};",
+           "__device__ const uint16_t kRegionLut[REGION_LUT_SIZE] = {"]
+    for r in range(0, len(lut), 16):
         out.append("    " + ", ".join(f"0x{v:04x}" for v in lut[r:r + 16]) + ",")
     out += ["};", "", "__device__ const SimplexVertex kVertex[128] = {"]
     for idx in range(128):
