@@ -23,12 +23,6 @@ constexpr double STRETCH3 = -1.0 / 6;
 constexpr double SQUISH3 = 1.0 / 3;
 constexpr double NORM3 = 103.0;
 
-__constant__ signed char kGrad3[72] = {
-    -11, 4, 4,  -4, 11, 4,  -4, 4, 11,   11, 4, 4,   4, 11, 4,   4, 4, 11,
-    -11,-4, 4,  -4,-11, 4,  -4,-4, 11,   11,-4, 4,   4,-11, 4,   4,-4, 11,
-    -11, 4,-4,  -4, 11,-4,  -4, 4,-11,   11, 4,-4,   4, 11,-4,   4, 4,-11,
-    -11,-4,-4,  -4,-11,-4,  -4,-4,-11,   11,-4,-4,   4,-11,-4,   4,-4,-11,
-};
 
 // LDS tables.  Everything the hash chain touches is stored as BYTE ADDRESSES inside this struct (the kernel's only LDS object, at LDS
 // address 0) so that an LDS address is one integer add and every table is reached through an instruction's immediate offset.
@@ -59,6 +53,8 @@ struct Tables {
     alignas(16) double vtx[128][10];   // rows are read with ds_read_b128: 16-byte aligned (an 8-byte-aligned base halves the kernel's speed)
 };
 static_assert(offsetof(Tables, vtx) % 16 == 0, "vertex rows 16-byte aligned");
+static_assert(offsetof(Tables, vtx) == VTX_LDS_BASE, "kRegionLutAddr holds addresses relative to this base");
+static_assert(offsetof(Tables, lut) % 8 == 0 && REGION_LUT_SIZE % 2 == 0, "lut copied as 8-byte words");
 static_assert(offsetof(Tables, H) == H_ENTRY0 - 8, "H entry 0 at byte 2048");
 static_assert(offsetof(Tables, G) == H_ENTRY0 - 8 + G_DELTA, "G entry 0 at byte 2048 + 6144");
 static_assert((H_ENTRY0 & 0x7F8u) == 0 && (G_DELTA & 0x7F8u) == 0, "bases outside the coordinate mask");
@@ -69,22 +65,15 @@ __device__ __forceinline__ void load_tables(Tables &T, const int16_t *src)
     for (int i = threadIdx.x; i < 516; i += blockDim.x) {
         const int m = (i - 1) & 255, m1 = i & 255;
         T.H[i] = make_uint2(H_ENTRY0 + 8u * (unsigned)(src[m] & 0xFF), H_ENTRY0 + 8u * (unsigned)(src[m1] & 0xFF));
-        T.G[i] = make_uint2(48u * (unsigned)(src[256 + m] / 3), 48u * (unsigned)(src[256 + m1] / 3));
+        T.G[i] = make_uint2(16u * (unsigned)src[256 + m], 16u * (unsigned)src[256 + m1]);     // 48 * (pgi3 / 3): pgi3 is a multiple of 3
     }
-    for (int i = threadIdx.x; i < 72; i += blockDim.x) T.grad[i / 3][i % 3] = (double)kGrad3[i];
-    for (int i = threadIdx.x; i < REGION_LUT_SIZE; i += blockDim.x) {
-        const unsigned v = kRegionLut[i], vb = (unsigned)offsetof(Tables, vtx);
-        T.lut[i] = (vb + 80u * (v & 0x7Fu)) | ((vb + 80u * (v >> 8)) << 16);
-    }
-    for (int i = threadIdx.x; i < 128 * 9; i += blockDim.x) {
-        const int e = i / 9, w = i - e * 9;                          // 72-byte source entries -> 80-byte LDS rows
-        unsigned long long v = reinterpret_cast<const unsigned long long *>(&kVertex[e])[w];
-        if (w >= 7) {                                                // {2i, 2j} / {2k, 0} -> the 8-byte entry offsets {8i, 8j} / {8k, 0}
-            const int lo = (int)(v & 0xFFFFFFFFull) * 4, hi = (int)(v >> 32) * 4;
-            v = (unsigned long long)(unsigned)lo | ((unsigned long long)(unsigned)hi << 32);
-        }
-        reinterpret_cast<unsigned long long *>(T.vtx[e])[w] = v;
-    }
+    // the seed-independent tables come from simplex_tables.h in exactly this layout: plain copies
+    for (int i = threadIdx.x; i < 24 * 48 / 16; i += blockDim.x)
+        reinterpret_cast<uint4 *>(T.grad)[i] = reinterpret_cast<const uint4 *>(kGradRows)[i];
+    for (int i = threadIdx.x; i < REGION_LUT_SIZE / 2; i += blockDim.x)
+        reinterpret_cast<uint2 *>(T.lut)[i] = reinterpret_cast<const uint2 *>(kRegionLutAddr)[i];
+    for (int i = threadIdx.x; i < 128 * 80 / 16; i += blockDim.x)
+        reinterpret_cast<uint4 *>(T.vtx)[i] = reinterpret_cast<const uint4 *>(kVertexRows)[i];
     __syncthreads();
 }
 
@@ -303,10 +292,11 @@ __device__ __forceinline__ double octave_sum(const Tables &T, double xd, double 
     return acc;
 }
 
-// five waves per SIMD (96 registers): the kernel is VALU-issue bound and five cover its LDS latency; the compiler's own choice drifts
+// six waves per SIMD (80 registers): the kernel is VALU-issue bound with the LDS close behind (round 6: five waves 4.25 ms, six / seven 4.20,
+// eight 4.27); the compiler's own choice drifts
 // to 97-104 registers = four waves.  -DSIMPLEX_WAVES=n for measurement builds.
 #ifndef SIMPLEX_WAVES
-#define SIMPLEX_WAVES 5
+#define SIMPLEX_WAVES 6
 #endif
 template <typename OutT, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIMPLEX_WAVES))) void simplex3_octaves_kernel(anoddpm_simplex_args a)

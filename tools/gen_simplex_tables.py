@@ -11,7 +11,7 @@
                                                             |p1-1|>|p2-1| << 5 | |p2-1|<|p3-1| << 6
                    Every entry is the old decision code's entry (lut[] below: (single << 3) | c, 16 + ..., 128 + (a_point | b_point << 3 |
                    a_further << 6 | b_further << 7)) for the code the reference's if / elif chains reach from those comparison results.
-  kVertex[128]     per vertex id = (i+1) | (j+1) << 2 | (k+1) << 4 | late << 6 the displacement recipe
+  kVertexRows[128] per vertex id = (i+1) | (j+1) << 2 | (k+1) << 4 | late << 6 the displacement recipe
                        d = ((d0 - A) - n*SQUISH) - C            per axis (n = i + j + k)
                    as doubles {Ax, Ay, Az, n*SQUISH, Cx, Cy, Cz} + the hash offsets {2i, 2j, 2k}.  `late` marks the five vertices the
                    reference displaces in a different operation order ((d0 - 1 - 3*SQUISH) - 1 at simplex.py:503,506; (d0 - 2*SQUISH) - 2
@@ -169,19 +169,40 @@ def main():
         f1, f2, f3, gt_ab, lt_ac, lt_bc = [(n >> k) & 1 for k in (5, 4, 3, 2, 1, 0)]
         m = f1 | f2 << 1 | f3 << 2 | (1 - gt_ab) << 3 | lt_ac << 4 | gt_ab << 5 | lt_bc << 6
         lut[256 + n] = region[256 + m]
-    out = ["// GENERATED by tools/gen_simplex_tables.py -- do not edit.  Lookup tables of csrc/simplex.hip (see the generator's docstring).",
-           "#pragma once", "#include <stdint.h>", "",
-           "struct SimplexVertex {", "    double ax, ay, az, sq, cx, cy, cz;", "    int32_t i2, j2, k2, pad;", "};",
-           "static_assert(sizeof(SimplexVertex) == 72, \"SimplexVertex layout\");", "",
+    import struct
+
+    def u64(v):
+        return struct.unpack("<Q", struct.pack("<d", v))[0]
+
+    # Everything below is emitted IN THE KERNEL'S LDS LAYOUT (struct Tables of csrc/simplex.hip), so that a workgroup loads the
+    # seed-independent tables with plain 16-byte copies (round 6: building them per workgroup cost ~130 VALU instructions per thread,
+    # 5 % of the kernel):
+    #   kRegionLutAddr[n] = LDS byte addresses of the two extra vertices' rows, lo / hi half (row id at VTX_LDS_BASE + 80 id)
+    #   kVertexRows[id]   = 80-byte rows {ax, ay, az, n*SQUISH, cx, cy, cz} as doubles, (8i | 8j << 32), (8k), 0
+    #   kGradRows[g]      = 48-byte rows {gx, gy, gz, 0, 0, 0} as doubles (GRADIENTS3, simplex.py:116-127)
+    VTX_LDS_BASE = 12320
+    grads = [(-11, 4, 4), (-4, 11, 4), (-4, 4, 11), (11, 4, 4), (4, 11, 4), (4, 4, 11),
+             (-11, -4, 4), (-4, -11, 4), (-4, -4, 11), (11, -4, 4), (4, -11, 4), (4, -4, 11),
+             (-11, 4, -4), (-4, 11, -4), (-4, 4, -11), (11, 4, -4), (4, 11, -4), (4, 4, -11),
+             (-11, -4, -4), (-4, -11, -4), (-4, -4, -11), (11, -4, -4), (4, -11, -4), (4, -4, -11)]
+    out = ["// GENERATED by tools/gen_simplex_tables.py -- do not edit.  Lookup tables of csrc/simplex.hip in the kernel's LDS layout (see the",
+           "// generator's docstring).", "#pragma once", "#include <stdint.h>", "",
            f"constexpr int REGION_LUT_SIZE = {len(lut)};",
-           "__device__ const uint16_t kRegionLut[REGION_LUT_SIZE] = {"]
-    for r in range(0, len(lut), 16):
-        out.append("    " + ", ".join(f"0x{v:04x}" for v in lut[r:r + 16]) + ",")
-    out += ["};", "", "__device__ const SimplexVertex kVertex[128] = {"]
+           f"constexpr unsigned VTX_LDS_BASE = {VTX_LDS_BASE};      // offsetof(Tables, vtx), asserted in simplex.hip",
+           "__device__ alignas(16) const uint32_t kRegionLutAddr[REGION_LUT_SIZE] = {"]
+    for r in range(0, len(lut), 8):
+        out.append("    " + ", ".join(f"0x{(VTX_LDS_BASE + 80 * (v & 0x7f)) | ((VTX_LDS_BASE + 80 * (v >> 8)) << 16):08x}" for v in lut[r:r + 8]) + ",")
+    out += ["};", "", "__device__ alignas(16) const uint64_t kVertexRows[128 * 10] = {"]
     for idx in range(128):
         A, sq, C, h = vertex(idx)
-        f = ", ".join(float.hex(v) for v in (A[0], A[1], A[2], sq, C[0], C[1], C[2]))
-        out.append(f"    {{{f}, {h[0]}, {h[1]}, {h[2]}, 0}},")
+        w = [u64(v) for v in (A[0], A[1], A[2], sq, C[0], C[1], C[2])]
+        w.append(((4 * h[0]) & 0xFFFFFFFF) | (((4 * h[1]) & 0xFFFFFFFF) << 32))
+        w.append((4 * h[2]) & 0xFFFFFFFF)
+        w.append(0)
+        out.append("    " + ", ".join(f"0x{v:016x}ull" for v in w) + ",")
+    out += ["};", "", "__device__ alignas(16) const uint64_t kGradRows[24 * 6] = {"]
+    for g in grads:
+        out.append("    " + ", ".join(f"0x{u64(float(v)):016x}ull" for v in g) + ", 0, 0, 0,")
     out += ["};", ""]
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "anoddpm_amd", "csrc", "simplex_tables.h")
     with open(path, "w") as fh:
