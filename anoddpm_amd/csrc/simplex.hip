@@ -299,7 +299,7 @@ __device__ __forceinline__ double octave_sum(const Tables &T, double xd, double 
 #define SIMPLEX_WAVES 6
 #endif
 template <typename OutT, int ABL = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIMPLEX_WAVES))) void simplex3_octaves_kernel(anoddpm_simplex_args a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIMPLEX_WAVES))) void simplex3_octaves_kernel(anoddpm_simplex_args a, int rows_per_block)
 {
     __shared__ Tables T;
     const int s = blockIdx.z;
@@ -308,8 +308,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIMPLEX_WAV
     load_tables(T, a.tables + tab * 512);
 
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= a.W || y >= a.H) return;
+    if (x >= a.W) return;
     const long long zi = a.zvals ? a.zvals[s] : a.z0 + s;
 
     // x / f: when f is a power of two (every frequency the reference uses: 64, 2^i, and their halvings) the quotient is an
@@ -318,16 +317,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SIMPLEX_WAV
     const double f0 = a.frequency;
     int fe;
     const bool pow2 = (frexp(f0, &fe) == 0.5) && fe > -900 && fe - a.octaves > -900 && fe < 900;
-    const double xd = (double)x, yd = (double)y, zd = (double)zi;
+    const double xd = (double)x, zd = (double)zi;
     // largest |coordinate| of any octave (the last one: f0 / 2^(octaves-1)), with room for the stretch term: below 2^31 the lattice
     // base converts with a plain 32-bit conversion
     const double fmin = ldexp(f0, -(a.octaves > 0 ? a.octaves - 1 : 0));
-    const bool safe = fmin > 0.0 && fmax(fmax(fabs(xd), fabs(yd)), fabs(zd)) * 2.0 < 2147483000.0 * fmin;
-    double acc = 0.0;
-    if (safe) acc = octave_sum<ABL, true>(T, xd, yd, zd, f0, pow2, a.octaves, a.persistence);
-    else      acc = octave_sum<ABL, false>(T, xd, yd, zd, f0, pow2, a.octaves, a.persistence);
-    OutT *out = reinterpret_cast<OutT *>(a.out) + (long long)s * a.out_slice_stride + (long long)y * a.W + x;
-    *out = (OutT)acc;
+    // a workgroup walks rows_per_block four-row tiles with one copy of the tables (launch_simplex: only when the grid stays many
+    // rounds deep): loading and building them is ~150 VALU instructions per thread against ~2 400 per pixel
+    for (int ty = 0; ty < rows_per_block; ++ty) {
+        const int y = (blockIdx.y * rows_per_block + ty) * 4 + (threadIdx.x >> 6);
+        if (y >= a.H) break;
+        const double yd = (double)y;
+        const bool safe = fmin > 0.0 && fmax(fmax(fabs(xd), fabs(yd)), fabs(zd)) * 2.0 < 2147483000.0 * fmin;
+        double acc = 0.0;
+        if (safe) acc = octave_sum<ABL, true>(T, xd, yd, zd, f0, pow2, a.octaves, a.persistence);
+        else      acc = octave_sum<ABL, false>(T, xd, yd, zd, f0, pow2, a.octaves, a.persistence);
+        OutT *out = reinterpret_cast<OutT *>(a.out) + (long long)s * a.out_slice_stride + (long long)y * a.W + x;
+        *out = (OutT)acc;
+    }
 }
 
 // simplex.py:833-840 (_noise3a): arbitrary coordinate vectors, out[z][y][x] = noise3(X[x], Y[y], Z[z]).
@@ -482,16 +488,20 @@ static int launch_simplex(const anoddpm_simplex_args *a, void *stream)
     ANODDPM_REQUIRE(a->nslices <= 65535, "simplex3_octaves: nslices > 65535 (split the launch)");
     ANODDPM_REQUIRE(a->out_slice_stride >= (int64_t)a->H * a->W, "simplex3_octaves: slice stride < H*W");
     if (a->nslices == 0 || a->H == 0 || a->W == 0) return ANODDPM_OK;
-    dim3 grid((a->W + 63) / 64, (a->H + 3) / 4, a->nslices);
+    // four-row tiles per workgroup: 4 / 2 while the grid stays at least eight rounds of the chip's resident workgroups deep
+    // (6 per CU x 256 CUs), else 1 -- the per-step fields of a reverse chain (a few slices) keep one tile per workgroup
+    const long long tiles = (long long)((a->W + 63) / 64) * ((a->H + 3) / 4) * a->nslices;
+    const int rpb = tiles >= 4ll * 8 * 1536 ? 4 : (tiles >= 2ll * 8 * 1536 ? 2 : 1);
+    dim3 grid((a->W + 63) / 64, ((a->H + 3) / 4 + rpb - 1) / rpb, a->nslices);
     ANODDPM_REQUIRE(grid.y <= 65535, "simplex3_octaves: H too large");
 #ifdef ANODDPM_ABLATE           // timing ablations (wrong results): measurement builds only
     const int abl = anoddpm::g_debug[7];
-    if (abl == 1) hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 1>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
-    else if (abl == 2) hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 2>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
-    else if (abl == 3) hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 3>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
+    if (abl == 1) hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 1>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a, rpb);
+    else if (abl == 2) hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 2>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a, rpb);
+    else if (abl == 3) hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 3>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a, rpb);
     else
 #endif
-    hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 0>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a);
+    hipLaunchKernelGGL((simplex3_octaves_kernel<OutT, 0>), grid, dim3(256), 0, anoddpm::as_stream(stream), *a, rpb);
     return anoddpm::check_launch("simplex3_octaves");
 }
 

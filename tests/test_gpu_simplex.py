@@ -77,6 +77,25 @@ def test_config4_volume_crops_and_oracle_slices(kat):
     assert np.isfinite(vol).all() and abs(vol.mean()) < 0.05 and 0.2 < vol.std() < 1.5
 
 
+@pytest.mark.parametrize("nz,freq", [(1300, 64.0), (2600, 24.0)])
+def test_deep_ragged_volumes_walk_several_row_tiles_per_workgroup(nz, freq):
+    """Volumes deep enough that a workgroup of the octave kernel walks 2 (nz 1300: 26 000 tiles) / 4 (nz 2600: 52 000) four-row tiles with one copy of
+    its tables (csrc/simplex.hip launch_simplex), on a shape whose height is neither a multiple of 4 nor of the tile walk: every
+    slice of a spread, incl. the last rows and columns, against the C oracle; frequency 24 takes the IEEE-division octave loop."""
+    from simplex import Simplex_CLASS
+    from oracle.simplex_oracle import OracleSimplex
+    s = Simplex_CLASS()
+    s.newSeed(-987654321)
+    vol = s.rand_3d_octaves((nz, 38, 70), 4, 0.8, freq)
+    assert vol.shape == (nz, 38, 70)
+    o = OracleSimplex(-987654321)
+    zs = np.array([0, 1, nz // 3, nz // 2 + 1, nz - 2, nz - 1])
+    ref = o._octaves(zs, 38, 70, 4, 0.8, freq)
+    for i, z in enumerate(zs):
+        assert (bits(vol[z]) == bits(ref[i])).all(), z
+    assert np.isfinite(vol).all()
+
+
 def test_random_seeds_vs_oracle_and_f32_fill():
     from simplex import Simplex_CLASS
     from oracle.simplex_oracle import OracleSimplex

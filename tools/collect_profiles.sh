@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/c2_write -
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/c2_sq -o c2 -- $B > $OUT/c2_sq.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_stats -o c3 -- $B --config c3 --steps 3 --warmup 1 > $OUT/c3_stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stats -o c4 -- $B --config c4 > $OUT/c4_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY --output-format csv -d $OUT/c4_sq -o c4 -- $B --config c4 > $OUT/c4_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/c4_sq -o c4 -- $B --config c4 > $OUT/c4_sq.log 2>&1
 unset ANODDPM_NO_GRAPH
 cd $GRAFT_REPO_ROOT
 # per-layer profile from the executor's own HIP events (round 4: bench.py --dump-layers; split-K tails are inside their layer's time)
