@@ -411,7 +411,7 @@ def hbm_kernel_rows(plan, B, ms, cnt, steps, extra=()):
         elif code == _lib.OP_CHAN_STATS:
             by["chan_stats"] += 4.0 * st.B * st.P * st.C
     slots = {"stem": (_lib.OP_STEM, "conv_stem_strip (3x3, Cin=1 -> base channels, NCHW in / NHWC out)"),
-             "head": (_lib.OP_HEAD, "conv_head_taps (GroupNorm-apply + SiLU + 3x3 -> 1 channel)"),
+             "head": (_lib.OP_HEAD, "conv_head_mfma2 (GroupNorm-apply + SiLU + 3x3 -> 1 channel)"),
              "resample": (_lib.OP_RESAMPLE, "resample2x (avg-pool / nearest x2 of the skip path, + pooled activated operand)"),
              "chan_stats": (_lib.OP_CHAN_STATS, "chan_stats (GroupNorm partial sums of the stem output)")}
     rows = []
