@@ -391,6 +391,34 @@ class TrainPlan(_Plan):
         self.temb = temb
         g_temb, g_z1 = self.G(temb), self.G(z1)
 
+        # Forward: every ResBlock's embedding projection in ONE launch (round 6: 22 launches of ~8 us at config 3) when the projections'
+        # weights and biases are consecutive in memory in one order -- training.FlatBuffers stores them that way; a model with
+        # separately allocated parameters keeps one launch per block.  linear_small computes one output feature per wave, so the
+        # values are the per-block launches' bit for bit.
+        self._emb_all, self._emb_off, self._emb_tot = None, {}, 0
+        ekeys = [k[:-len(".weight")] for k in self.named if k.endswith(".embed_layers.1.weight")]
+        if len(ekeys) > 1 and os.environ.get("ANODDPM_BATCH_EMB_FWD", "1") != "0":
+            wp, bp, ok = self.W(ekeys[0] + ".weight"), self.W(ekeys[0] + ".bias"), True
+            for k in ekeys:
+                w = self.named[k + ".weight"]
+                ok = ok and self.W(k + ".weight") == wp and self.W(k + ".bias") == bp and w.shape[1] == ted
+                self._emb_off[k[:-len(".embed_layers.1")]] = self._emb_tot
+                wp += 4 * w.numel()
+                bp += 4 * w.shape[0]
+                self._emb_tot += w.shape[0]
+            if ok:
+                st = LinearArgs()
+                st.inp, st.w, st.bias = temb.data_ptr(), self.W(ekeys[0] + ".weight"), self.W(ekeys[0] + ".bias")
+                self._emb_all = self.buf(B, self._emb_tot)
+                st.out, st.B, st.K, st.N, st.act_in, st.act_out = self._emb_all.data_ptr(), B, ted, self._emb_tot, 1, 0
+                self.add(_lib.OP_LINEAR, st)
+
+        def emb_of(prefix, cout):
+            """(pointer, row pitch) of a block's embedding projection: a column range of the batched launch, or its own launch."""
+            if self._emb_all is not None:
+                return self._emb_all.data_ptr() + 4 * self._emb_off[prefix], self._emb_tot
+            return self.linear_t(temb, prefix + ".embed_layers.1.weight", prefix + ".embed_layers.1.bias", ted, cout, 1).data_ptr(), cout
+
         self._emb_jobs = []          # (weight key, bias key, d_emb buffer, cout) of every ResBlock's embedding projection
         # One batched launch for all of them at the END of the backward.  With a data-parallel reducer attached that is still
         # right: training.FlatBuffers stores the embedding projections (and the timestep MLP) at the bottom of the flat buffer,
@@ -447,7 +475,7 @@ class TrainPlan(_Plan):
             Pin, Pout = Hin * Hin, Hout * Hout
             am = {None: 0, "up": 1, "down": 2}[resample]
             g1 = self.gn_t(srcs, Pin, prefix + ".in_layers.0")
-            emb = self.linear_t(temb, prefix + ".embed_layers.1.weight", prefix + ".embed_layers.1.bias", ted, cout, 1)
+            emb_ptr, emb_ld = emb_of(prefix, cout)
             h1 = self.buf(B, Pout, cout)
             sk_pool = None
             if resample == "down":
@@ -463,10 +491,10 @@ class TrainPlan(_Plan):
                 wk, bk = prefix + ".in_layers.2.weight", prefix + ".in_layers.2.bias"
                 self.igemm(srcs=[(pooled, cin)], H=Hout, W=Hout, ks=3, N=cout, bmat=lambda: self.pack(wk, 0),
                            wino=lambda: self.pack(wk, 1), wino43=lambda: self.pack(wk, 5), bias=bias(bk),
-                           temb=emb.data_ptr(), temb_ld=cout, out=h1, want_stats=True)
+                           temb=emb_ptr, temb_ld=emb_ld, out=h1, want_stats=True)
             else:
                 conv3(srcs, Hout, cout, g1, am, prefix + ".in_layers.2.weight", prefix + ".in_layers.2.bias", h1,
-                      temb_ptr=emb.data_ptr(), temb_ld=cout)
+                      temb_ptr=emb_ptr, temb_ld=emb_ld)
             g2 = self.gn_t([(h1, cout)], Pout, prefix + ".out_layers.0")
             skip_kind = "identity"
             if cin != cout:

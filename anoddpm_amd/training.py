@@ -78,7 +78,14 @@ class FlatBuffers:
         assert dt == torch.float32 and all(p.device == dev and p.dtype == dt for p in self.params)
         late = late or self._late
         idx = range(len(self.params))
-        self.layout = [i for i in idx if late(self.names[i])] + [i for i in idx if not late(self.names[i])]
+        # inside the late group: the timestep MLP, then every block's embedding-projection WEIGHT, then every projection's BIAS (module
+        # order each) -- the concatenated weights / biases are then one [sum cout][ted] matrix and one vector in memory, and the
+        # training plan computes all projections of a step with ONE linear launch (train_plan: `emb_all`), as the inference plan does
+        # on its packed copy
+        def rank(i):
+            k = self.names[i]
+            return (1 if k.endswith("embed_layers.1.weight") else 2 if k.endswith("embed_layers.1.bias") else 0) if late(k) else 3
+        self.layout = sorted(idx, key=lambda i: (rank(i), i))
         self.offsets = [0] * len(self.params)
         n = 0
         for i in self.layout:

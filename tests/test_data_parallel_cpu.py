@@ -182,7 +182,15 @@ def test_flat_layout_puts_embedding_projections_in_the_last_bucket_and_module_pi
     flat = FlatBuffers(net)
     late = [i for i, k in enumerate(flat.names) if "embed_layers." in k or k.startswith("time_embedding.")]
     early = [i for i in range(len(flat.names)) if i not in late]
-    assert flat.layout == late + early and len(late) == 6
+    assert sorted(flat.layout[:len(late)]) == late and flat.layout[len(late):] == early and len(late) == 6
+    # inside the late group the blocks' projection weights are ONE matrix in memory and their biases one vector (round 6: the
+    # training plan computes every block's projection of a step with one linear launch)
+    ew = [i for i in late if flat.names[i].endswith("embed_layers.1.weight")]
+    eb = [i for i in late if flat.names[i].endswith("embed_layers.1.bias")]
+    assert len(ew) == 2 and len(eb) == 2
+    assert flat.offsets[ew[1]] == flat.offsets[ew[0]] + flat.params[ew[0]].numel()
+    assert flat.offsets[eb[0]] == flat.offsets[ew[1]] + flat.params[ew[1]].numel()
+    assert flat.offsets[eb[1]] == flat.offsets[eb[0]] + flat.params[eb[0]].numel()
     assert max(flat.offsets[i] for i in late) < min(flat.offsets[i] for i in early)
     assert flat.names == [k for k, _ in net.named_parameters()]              # optimiser state-dict order is the module's
     red = GradAllReducer(flat, bucket_bytes=64)
