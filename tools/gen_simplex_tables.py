@@ -204,7 +204,10 @@ def main():
     for g in grads:
         out.append("    " + ", ".join(f"0x{u64(float(v)):016x}ull" for v in g) + ", 0, 0, 0,")
     out += ["};", ""]
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "anoddpm_amd", "csrc", "simplex_tables.h")
+    import sys
+    # optional argument: write somewhere else (tests/test_simplex_tables.py compares a fresh copy with the committed header)
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                               "anoddpm_amd", "csrc", "simplex_tables.h")
     with open(path, "w") as fh:
         fh.write("\n".join(out))
     print(path, len(lut), "lut entries, 128 vertices")
